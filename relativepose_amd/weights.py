@@ -1,0 +1,92 @@
+"""SCNet parameter inventory + a portable seeded generator.
+
+Key names and shapes follow the reference module tree (model/mymodel.py:142-257):
+``<block>.0.weight`` conv / transposed-conv weight (no bias when BatchNorm
+follows), ``<block>.1.weight|bias`` BatchNorm affine, ``deconv1{rgb,n,d,s,f}``
+1x1 heads with bias.  ConvTranspose2d weights are ``[Cin, Cout, kh, kw]``.
+
+The real checkpoints are Google-Drive downloads that do not ship with the
+reference, so tests and the bench use ``make_state_dict`` (RandomState driven,
+fixed key order, independent of torch's RNG so the same numbers come out on any
+box).  A real ``state_dict`` with these keys loads the same way.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+NGF = 64
+
+
+def layer_table(snumclass=15):
+    """[(name, kind, cin, cout, k, stride, pad)] in forward order; kind in
+    {'conv','deconv','head'}."""
+    g = NGF
+    t = []
+    for m, cin in (("rgb", 4), ("n", 4), ("d", 2)):
+        t += [(f"conv1{m}", "conv", cin, g // 2, 3, 1, 1),
+              (f"conv2{m}", "conv", g // 2, g, 4, 2, 1),
+              (f"conv3{m}", "conv", g, g * 2, 4, 2, 1)]
+    t += [("conv4", "conv", g * 12, g * 4, 4, 2, 1),
+          ("conv5", "conv", g * 4, g * 8, 4, 2, 1),
+          ("conv6", "conv", g * 8, g * 8, 4, 2, 1),
+          ("conv7", "conv", g * 8, g * 8, 3, 2, 0),
+          ("conv8", "conv", g * 8, g * 8, 3, 1, 1),
+          ("conv9", "conv", g * 8, g * 16, 3, 1, 0),
+          ("deconv9", "deconv", g * 16, g * 8, 3, 1, 0),
+          ("deconv8", "deconv", g * 16, g * 8, 3, 1, 1),
+          ("deconv7", "deconv", g * 16, g * 8, 3, 2, 0),
+          ("deconv6", "deconv", g * 16, g * 8, 4, 2, 1),
+          ("deconv5", "deconv", g * 16, g * 4, 4, 2, 1),
+          ("deconv4", "deconv", g * 8, g * 2, 4, 2, 1)]
+    for m, cout in (("rgb", 3), ("n", 3), ("d", 1)):
+        t += [(f"deconv3{m}", "deconv", g * 4, g, 4, 2, 1),
+              (f"deconv2{m}", "deconv", g * 2, g // 2, 4, 2, 1),
+              (f"deconv1{m}", "head", g, cout, 1, 1, 0)]
+    for m, cout in (("s", snumclass), ("f", 32)):
+        t += [(f"deconv3{m}", "deconv", g * 2, g, 4, 2, 1),
+              (f"deconv2{m}", "deconv", g, g, 4, 2, 1),
+              (f"deconv1{m}", "head", g, cout, 1, 1, 0)]
+    return t
+
+
+def state_dict_spec(snumclass=15):
+    """OrderedDict key -> shape, in the reference's registration order."""
+    spec = OrderedDict()
+    for name, kind, cin, cout, k, s, p in layer_table(snumclass):
+        if kind == "conv":
+            spec[f"{name}.0.weight"] = (cout, cin, k, k)
+            spec[f"{name}.1.weight"] = (cout,)
+            spec[f"{name}.1.bias"] = (cout,)
+        elif kind == "deconv":
+            spec[f"{name}.0.weight"] = (cin, cout, k, k)
+            spec[f"{name}.1.weight"] = (cout,)
+            spec[f"{name}.1.bias"] = (cout,)
+        else:
+            spec[f"{name}.weight"] = (cout, cin, 1, 1)
+            spec[f"{name}.bias"] = (cout,)
+    return spec
+
+
+def make_state_dict(seed=0, snumclass=15):
+    """Xavier-normal conv weights, BN gamma ~ N(1,.02), beta = small noise,
+    head bias ~ N(0,.05) -- the reference's init (mymodel.py:6-13) with non-zero
+    betas/biases so that every parameter is exercised by parity tests."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for key, shape in state_dict_spec(snumclass).items():
+        if len(shape) == 4:
+            rf = shape[2] * shape[3]
+            fan_in, fan_out = shape[1] * rf, shape[0] * rf
+            std = np.sqrt(2.0 / (fan_in + fan_out))
+            sd[key] = (rs.randn(*shape) * std).astype(np.float32)
+        elif key.endswith(".1.weight"):
+            sd[key] = (1.0 + 0.02 * rs.randn(*shape)).astype(np.float32)
+        elif key.endswith(".1.bias"):
+            sd[key] = (0.05 * rs.randn(*shape)).astype(np.float32)
+        else:
+            sd[key] = (0.05 * rs.randn(*shape)).astype(np.float32)
+    return sd
+
+
+def num_params(snumclass=15):
+    return int(sum(np.prod(s) for s in state_dict_spec(snumclass).values()))

@@ -1,0 +1,20 @@
+"""Case tables shared by make_golden.py (generation, needs the reference) and
+the parity tests (which only read the .npz fixtures)."""
+
+MATCH_CASES = [  # (N, Nt, seed, dataset, param row, inlier fraction)
+    (50, 50, 11, "suncg", 0, 0.6), (50, 37, 12, "matterport", 1, 0.6), (120, 120, 13, "scannet", 2, 0.6),
+    (200, 200, 14, "suncg", 0, 0.6), (200, 200, 15, "suncg", 2, 0.6), (200, 180, 16, "matterport", 0, 0.3),
+    (400, 400, 17, "matterport", 1, 0.6), (400, 400, 18, "matterport", 2, 0.1),
+    (2, 2, 19, "suncg", 0, 0.6), (6, 4, 20, "suncg", 0, 0.6), (30, 30, 21, "suncg", 0, 0.0),
+]
+MATCH_METHODS = ("irls+sm", "horn87", "irls", "spectral")
+
+GEOM_CASES = (("suncg", "second", 100), ("matterport", "second", 200), ("scannet", "kinect", 300))
+WARP_ANGLES = (0.3, 1.5, 3.141592653589793)
+
+SCNET_CASES = (("a", 15, 1, 3, "suncg", "second"), ("b", 21, 0, 4, "scannet", "kinect"))
+
+E2E_CASES = [("suncg", "second", 15, 1, 1000 + i) for i in range(4)] + \
+    [("matterport", "second", 21, 1, 3000), ("scannet", "kinect", 21, 0, 4000)]
+E2E_N = 80
+E2E_WEIGHT_SEED = 7

@@ -1,0 +1,279 @@
+"""Generate the golden fixtures in tests/golden/*.npz by running the UPSTREAM
+REFERENCE (imported in place from /root/reference, CPU) on seeded synthetic
+inputs.  Runs only in the build container; the fixtures (data: inputs are
+regenerated from seeds, expected outputs are stored) travel with the repo.
+
+    python tests/golden/make_golden.py            # all groups
+    python tests/golden/make_golden.py matcher    # one group
+
+Groups: matcher, geometry, scnet, e2e.  See SURVEY.md §8c for the plan.
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_loader  # noqa: E402
+from relativepose_amd import synth, weights  # noqa: E402
+
+PARAM_ROWS = {
+    # data/relativePoseModule/final_param_*_rlevel_3.txt read at run time from the reference
+}
+
+
+def load_params():
+    out = {}
+    for ds in ("suncg", "matterport", "scannet"):
+        out[ds] = np.loadtxt(os.path.join(ref_loader.REF, "data", "relativePoseModule",
+                                          f"final_param_{ds}_rlevel_3.txt")).reshape(-1, 4)
+    return out
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def sample_idx(n, k, seed):
+    return np.random.RandomState(seed).randint(0, n, size=k)
+
+
+from cases import MATCH_CASES, MATCH_METHODS, GEOM_CASES, WARP_ANGLES, SCNET_CASES, E2E_CASES, E2E_N, E2E_WEIGHT_SEED  # noqa: E402
+
+
+def gen_matcher():
+    R = ref_loader.load()
+    rp, ru = R["rpmodule"], R["rputil"]
+    params = load_params()
+    out = {}
+    for ci, (N, Nt, seed, ds, row, inl) in enumerate(MATCH_CASES):
+        S, T, _ = synth.make_match_case(N, seed, inlier=inl, Nt=Nt)
+        for method in MATCH_METHODS:
+            if method != "irls+sm" and N > 200:
+                continue
+            para = ru.opts(*params[ds][row])
+            para.method = method
+            t = time.time()
+            pose = rp.RelativePoseEstimation_helper(S, T, para)
+            print(f"matcher case {ci} N={N}/{Nt} {method}: {time.time()-t:.2f}s")
+            out[f"pose_{ci}_{method}"] = pose
+    out["params_suncg"], out["params_matterport"], out["params_scannet"] = (params[k] for k in ("suncg", "matterport", "scannet"))
+    np.savez_compressed(os.path.join(HERE, "matcher.npz"), **out)
+
+
+def _views(ds, seed, method):
+    import torch
+    R = ref_loader.load()
+    util = R["util"]
+    d = synth.make_pairs(1, seed, ds)
+    comp = torch.from_numpy(np.concatenate((d["rgb"][0, 0], d["norm"][0, 0], d["depth"][0, 0][None]), 0)[None])
+    v, m, _ = util.apply_mask(comp.clone(), method)
+    v = torch.cat((v, (v[:, 6:7] != 0).float()), 1)
+    return d, v, m
+
+
+def gen_geometry():
+    import torch
+    R = ref_loader.load()
+    util, ru = R["util"], R["rputil"]
+    out = {}
+    for ds, mm, seed in GEOM_CASES:
+        d, v, m = _views(ds, seed, mm)
+        out[f"mask_{ds}"] = np.packbits(m.numpy().astype(np.uint8))
+        out[f"view_{ds}_sha"] = digest(v.numpy())
+        pc = util.Pano2PointCloud(d["depth"][0, 0], ds)
+        idx = sample_idx(pc.shape[1], 2048, 1)
+        out[f"pano2pc_{ds}_shape"] = np.array(pc.shape)
+        out[f"pano2pc_{ds}_idx"], out[f"pano2pc_{ds}_val"] = idx, pc[:, idx]
+        out[f"pano2pc_{ds}_sum"] = pc.sum(1)
+        rs = np.random.RandomState(seed + 1)
+        for k in range(3):
+            T = synth.random_rigid(rs, WARP_ANGLES[k], 0.8)
+            w = np.asarray(util.warping(v.numpy(), T, ds))
+            w32 = w.astype(np.float32)
+            idx = sample_idx(w32.size, 8192, 2 + k)
+            out[f"warp_{ds}_{k}_T"] = T
+            out[f"warp_{ds}_{k}_idx"], out[f"warp_{ds}_{k}_val"] = idx, w.reshape(-1)[idx]
+            out[f"warp_{ds}_{k}_chsum"] = w.sum((0, 2, 3))
+            out[f"warp_{ds}_{k}_nnz"] = np.array([(w[0, c] != 0).sum() for c in range(8)])
+            out[f"warp_{ds}_{k}_maskbits"] = np.packbits((w[0, 7] != 0).astype(np.uint8))
+            out[f"warp_{ds}_{k}_sha32"] = digest(w32)
+        wI = util.warping(v.numpy(), np.eye(4), ds)
+        out[f"warp_{ds}_I_absmax"] = np.array(float(np.abs(np.asarray(wI)).max()))
+        # keypoint sampling on a "completed" map = the full synthetic maps
+        pts, _ = synth.make_keypoints(1, 64, seed + 5, mm)
+        pts = pts[0, 0]
+        depth = d["depth"][0, 0]
+        normal = d["norm"][0, 0].transpose(1, 2, 0)
+        pc, nn = ru.getPixel(depth, normal, pts, dataset=ds)
+        out[f"getpixel_{ds}_pc"], out[f"getpixel_{ds}_nn"] = pc, nn
+        feat = np.random.RandomState(seed + 6).randn(32, 160, 640).astype(np.float32)
+        ptn = pts.copy()
+        ptn[:, 0] /= 640
+        ptn[:, 1] /= 160
+        out[f"interp_{ds}"] = ru.interpolate(torch.from_numpy(feat), torch.from_numpy(ptn).float()).numpy()
+    # depth2pc on the observed face / crop
+    for ds in ("suncg", "matterport", "scannet"):
+        d = synth.make_pairs(1, 400, ds)
+        dep = d["depth"][0, 0]
+        crop = dep[47:113, 196:284] if ds == "scannet" else dep[:, 160:320]
+        pc, mask = util.depth2pc(crop, ds)
+        out[f"depth2pc_{ds}_sum"], out[f"depth2pc_{ds}_n"] = pc.sum(0), np.array(pc.shape[0])
+        out[f"depth2pc_{ds}_head"] = pc[:256]
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out)
+
+
+class _Args:
+    batchnorm, skipLayer, outputType = 1, 1, "rgbdnsf"
+
+    def __init__(self, S, tanh):
+        self.snumclass, self.useTanh = S, tanh
+
+
+def ref_net(S, tanh, seed):
+    import torch
+    R = ref_loader.load()
+    net = R["mymodel"].SCNet(_Args(S, tanh))
+    sd = {k: torch.from_numpy(v) for k, v in weights.make_state_dict(seed, S).items()}
+    net.load_state_dict(sd, strict=True)
+    return net
+
+
+def scnet_input(seed, ds="suncg", mm="second", step_R=None):
+    """A realistic [2,16,160,640] net input: masked views + warped other view."""
+    R = ref_loader.load()
+    util = R["util"]
+    import torch
+    d = synth.make_pairs(1, seed, ds)
+    vs = []
+    for v in range(2):
+        comp = torch.from_numpy(np.concatenate((d["rgb"][0, v], d["norm"][0, v], d["depth"][0, v][None]), 0)[None])
+        x, m, _ = util.apply_mask(comp.clone(), mm)
+        vs.append(torch.cat((x, (x[:, 6:7] != 0).float()), 1))
+    Rg = d["R"][0]
+    T = np.linalg.inv(Rg[1]) @ Rg[0] if step_R is None else step_R
+    t2s = torch.from_numpy(np.asarray(util.warping(vs[1].numpy(), np.linalg.inv(T), ds))).float()
+    s2t = torch.from_numpy(np.asarray(util.warping(vs[0].numpy(), T, ds))).float()
+    return torch.cat((torch.cat((vs[0], t2s), 1), torch.cat((vs[1], s2t), 1))), d
+
+
+def gen_scnet():
+    import torch
+    out = {}
+    for tag, S, tanh, seed, ds, mm in SCNET_CASES:
+        net = ref_net(S, tanh, seed)
+        x, _ = scnet_input(500 + seed, ds, mm)
+        taps = {}
+        hooks = []
+        for name, mod in net.named_modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                hooks.append(mod.register_forward_hook(
+                    lambda m, i, o, name=name: taps.setdefault(name, []).append(o.detach())))
+        with torch.no_grad():
+            t = time.time()
+            y = net(x)
+            print(f"scnet {tag}: {time.time()-t:.2f}s out {tuple(y.shape)}")
+        for h in hooks:
+            h.remove()
+        out[f"{tag}_cfg"] = np.array([S, tanh, seed, 500 + seed])
+        out[f"{tag}_ds"] = np.array([ds, mm])
+        out[f"{tag}_out_crop"] = y[:, :, 40:72, 300:332].numpy()
+        out[f"{tag}_out_chmean"] = y.mean((2, 3)).numpy()
+        out[f"{tag}_out_chabsmax"] = y.abs().amax((2, 3)).numpy()
+        idx = sample_idx(y.numel(), 20000, 9)
+        out[f"{tag}_out_idx"], out[f"{tag}_out_val"] = idx, y.reshape(-1)[idx].numpy()
+        for name, lst in taps.items():
+            # first call of a shared-weight block = self stream, second = t2s stream
+            for ci, o in enumerate(lst):
+                out[f"{tag}_tap_{name}_{ci}_mean"] = o.mean((0, 2, 3)).numpy()
+                out[f"{tag}_tap_{name}_{ci}_std"] = o.std((0, 2, 3)).numpy()
+    np.savez_compressed(os.path.join(HERE, "scnet.npz"), **out)
+
+
+def gen_e2e():
+    """evaluation.py:217-284 driven through the reference's own functions with
+    rputil.getKeypoint replaced by injected keypoints (4 SUNCG-shaped pairs,
+    config 1 of BASELINE.json, + 1 matterport + 1 scannet pair)."""
+    import torch
+    R = ref_loader.load()
+    util, rp, ru, top = R["util"], R["rpmodule"], R["rputil"], R["torch_op"]
+    params = load_params()
+    out = {}
+    cases = E2E_CASES
+    N = E2E_N
+    nets = {}
+    for ci, (ds, mm, S, tanh, seed) in enumerate(cases):
+        key = (S, tanh)
+        if key not in nets:
+            nets[key] = ref_net(S, tanh, E2E_WEIGHT_SEED)
+        net = nets[key]
+        d = synth.make_pairs(1, seed, ds)
+        pts, ptw = synth.make_keypoints(1, N, seed, mm)
+        inj = {}
+
+        def fake_kp(rs, rt, fs, ft, *a, **k):
+            ps, pt = pts[0, 0], pts[0, 1]
+            pn, tn = ps.copy(), pt.copy()
+            pn[:, 0] /= 640; pn[:, 1] /= 160; tn[:, 0] /= 640; tn[:, 1] /= 160
+            return ps, pn, ptw[0, 0], pt, tn, ptw[0, 1]
+
+        rp.getKeypoint = fake_kp
+        rp.getKeypoint_kinect = fake_kp
+        data = {k: torch.from_numpy(v) for k, v in d.items()}
+        rgb_u8 = (d["rgb"] * 255).clip(0, 255).astype("uint8")
+        with torch.no_grad():
+            R_hat = np.eye(4)
+            comp = [torch.cat((top.v(data["rgb"][:, v]), top.v(data["norm"][:, v]), top.v(data["depth"][:, v:v + 1])), 1)
+                    for v in range(2)]
+            views, masks = [], []
+            for v in range(2):
+                x, m, _ = util.apply_mask(comp[v].clone(), mm)
+                masks.append(top.npy(m[0]).transpose(1, 2, 0))
+                views.append(torch.cat((x, (x[:, 6:7] != 0).float()), 1))
+            obs = [{"rgb": rgb_u8[0, v].transpose(1, 2, 0), "depth": d["depth"][0, v],
+                    "normal": d["norm"][0, v].transpose(1, 2, 0)} for v in range(2)]
+            fs, fe = 7 + S, 7 + S + 32
+            t0 = time.time()
+            for step in range(3):
+                t2s = top.v(util.warping(top.npy(views[1]), np.linalg.inv(R_hat), ds))
+                s2t = top.v(util.warping(top.npy(views[0]), R_hat, ds))
+                f = net(torch.cat((torch.cat((views[0], t2s), 1), torch.cat((views[1], s2t), 1))))
+                dc = []
+                for v in range(2):
+                    fv = top.npy(f[v])
+                    m = masks[v]
+                    c = {}
+                    c["normal"] = ((1 - m) * fv[3:6].transpose(1, 2, 0) + m * obs[v]["normal"]) \
+                        / (np.linalg.norm(obs[v]["normal"], axis=2, keepdims=True) + 1e-6)
+                    c["depth"] = (1 - m[:, :, 0]) * fv[6] + m[:, :, 0] * obs[v]["depth"]
+                    c["rgb"] = (m * obs[v]["rgb"]).astype("uint8")
+                    c["rgb_full"] = c["rgb"]
+                    c["feat"] = f[v, fs:fe]
+                    dc.append(c)
+                para = ru.opts(*params[ds][step])
+                prim = rp.getMatchingPrimitive(dc[0], dc[1], ds, "skybox", 1)
+                p3s, p3t, ns_, nt_, des, det, ws, wt = prim
+                R_hat = rp.RelativePoseEstimation_helper({"pc": p3s.T, "normal": ns_, "feat": des, "weight": ws},
+                                                         {"pc": p3t.T, "normal": nt_, "feat": det, "weight": wt}, para)
+                out[f"e2e_{ci}_R{step}"] = R_hat
+                if step == 0:
+                    out[f"e2e_{ci}_prim_pc"], out[f"e2e_{ci}_prim_n"] = p3s, ns_
+                    out[f"e2e_{ci}_prim_des"] = des
+                    out[f"e2e_{ci}_prim_pct"], out[f"e2e_{ci}_prim_nt"], out[f"e2e_{ci}_prim_dest"] = p3t, nt_, det
+            print(f"e2e case {ci} {ds}: {time.time()-t0:.1f}s")
+        out[f"e2e_{ci}_cfg"] = np.array([ds, mm, str(S), str(tanh), str(seed), str(N)])
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
+
+
+if __name__ == "__main__":
+    assert ref_loader.available(), "reference not present"
+    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e"]
+    for g in groups:
+        t = time.time()
+        globals()["gen_" + g]()
+        print(f"[{g}] done in {time.time()-t:.1f}s")

@@ -1,0 +1,140 @@
+"""CPU: the numpy/torch oracle reproduces the golden vectors that
+tests/golden/make_golden.py captured from the upstream reference."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import (E2E_CASES, E2E_N, E2E_WEIGHT_SEED, GEOM_CASES, MATCH_CASES, MATCH_METHODS, SCNET_CASES)
+from oracle import geom_oracle as G
+from oracle import pipeline_oracle as P
+from oracle import rp_oracle as M
+from oracle.scnet_oracle import SCNetOracle
+from relativepose_amd import synth, weights
+
+
+@pytest.fixture(scope="module")
+def gm(golden_dir):
+    return np.load(os.path.join(golden_dir, "matcher.npz"))
+
+
+@pytest.mark.parametrize("ci", range(len(MATCH_CASES)))
+def test_matcher_pose_matches_reference(gm, ci):
+    N, Nt, seed, ds, row, inl = MATCH_CASES[ci]
+    S, T, _ = synth.make_match_case(N, seed, inlier=inl, Nt=Nt)
+    for method in MATCH_METHODS:
+        key = f"pose_{ci}_{method}"
+        if key not in gm:
+            continue
+        if inl == 0.0 and method == "spectral":
+            continue  # all-outlier case: degenerate leading eigenspace, ARPACK start-vector dependent
+        p = M.Params(*gm[f"params_{ds}"][row])
+        p.method = method
+        got = M.relative_pose_helper(S, T, p)
+        assert np.abs(got - gm[key]).max() < 1e-9, (ci, method)
+
+
+def test_matcher_degenerate_returns_identity(gm):
+    for m in MATCH_METHODS:
+        assert np.array_equal(gm[f"pose_8_{m}"], np.eye(4))
+
+
+def test_sum_order_equals_numpy_reduction():
+    rs = np.random.RandomState(0)
+    a = rs.randn(300, 32).astype(np.float32) ** 2
+    assert np.array_equal(M.sum32_lanes8(a), a.sum(1))
+
+
+@pytest.fixture(scope="module")
+def gg(golden_dir):
+    return np.load(os.path.join(golden_dir, "geometry.npz"))
+
+
+@pytest.mark.parametrize("ds,mm,seed", GEOM_CASES)
+def test_geometry_matches_reference(gg, ds, mm, seed):
+    d = synth.make_pairs(1, seed, ds)
+    view, mask = G.build_view(d["rgb"][0, 0], d["norm"][0, 0], d["depth"][0, 0], mm)
+    assert np.array_equal(np.packbits(mask.transpose(2, 0, 1)[None].astype(np.uint8)), gg[f"mask_{ds}"])
+    pc = G.pano2pc(d["depth"][0, 0], ds)
+    assert tuple(gg[f"pano2pc_{ds}_shape"]) == pc.shape
+    assert np.array_equal(pc[:, gg[f"pano2pc_{ds}_idx"]], gg[f"pano2pc_{ds}_val"])
+    for k in range(3):
+        T = gg[f"warp_{ds}_{k}_T"]
+        w = G.warping(view, T, ds)
+        assert np.array_equal(w.reshape(-1)[gg[f"warp_{ds}_{k}_idx"]], gg[f"warp_{ds}_{k}_val"])
+        assert np.array_equal(np.packbits((w[0, 7] != 0).astype(np.uint8)), gg[f"warp_{ds}_{k}_maskbits"])
+        assert np.allclose(w.sum((0, 2, 3)), gg[f"warp_{ds}_{k}_chsum"], rtol=1e-12, atol=1e-9)
+    assert np.abs(G.warping(view, np.eye(4), ds)).max() == 0
+    pts, _ = synth.make_keypoints(1, 64, seed + 5, mm)
+    pc, nn = G.get_pixel(d["depth"][0, 0], d["norm"][0, 0].transpose(1, 2, 0), pts[0, 0], ds)
+    assert np.allclose(pc, gg[f"getpixel_{ds}_pc"], rtol=0, atol=1e-12)
+    assert np.allclose(nn, gg[f"getpixel_{ds}_nn"], rtol=0, atol=1e-12)
+    feat = np.random.RandomState(seed + 6).randn(32, 160, 640).astype(np.float32)
+    ptn = pts[0, 0].copy()
+    ptn[:, 0] /= 640
+    ptn[:, 1] /= 160
+    assert np.array_equal(G.interpolate(feat, ptn.astype(np.float32)), gg[f"interp_{ds}"])
+
+
+@pytest.mark.parametrize("ds", ["suncg", "matterport", "scannet"])
+def test_depth2pc_matches_reference(gg, ds):
+    d = synth.make_pairs(1, 400, ds)
+    dep = d["depth"][0, 0]
+    crop = dep[47:113, 196:284] if ds == "scannet" else dep[:, 160:320]
+    pc, _ = G.depth2pc(crop, ds)
+    assert pc.shape[0] == int(gg[f"depth2pc_{ds}_n"])
+    assert np.array_equal(pc[:256], gg[f"depth2pc_{ds}_head"])
+
+
+@pytest.fixture(scope="module")
+def gs(golden_dir):
+    return np.load(os.path.join(golden_dir, "scnet.npz"))
+
+
+def oracle_scnet_input(seed, ds, mm):
+    """Same construction as make_golden.scnet_input, through the oracle."""
+    d = synth.make_pairs(1, seed, ds)
+    views = [G.build_view(d["rgb"][0, v], d["norm"][0, v], d["depth"][0, v], mm)[0] for v in range(2)]
+    Rg = d["R"][0]
+    T = np.linalg.inv(Rg[1]) @ Rg[0]
+    t2s = G.warping(views[1], np.linalg.inv(T), ds).astype(np.float32)
+    s2t = G.warping(views[0], T, ds).astype(np.float32)
+    return np.concatenate((np.concatenate((views[0], t2s), 1), np.concatenate((views[1], s2t), 1)))
+
+
+@pytest.mark.parametrize("case", SCNET_CASES)
+def test_scnet_matches_reference(gs, case):
+    tag, S, tanh, seed, ds, mm = case
+    net = SCNetOracle(weights.make_state_dict(seed, S), S, tanh)
+    x = oracle_scnet_input(500 + seed, ds, mm)
+    y = net.forward_pairs(x).numpy()
+    ref = gs[f"{tag}_out_val"]
+    got = y.reshape(-1)[gs[f"{tag}_out_idx"]]
+    # same torch build, same ops -> expect (near) bit equality
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    assert np.allclose(y[:, :, 40:72, 300:332], gs[f"{tag}_out_crop"], atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def ge(golden_dir):
+    return np.load(os.path.join(golden_dir, "e2e.npz"))
+
+
+@pytest.mark.parametrize("ci", [0, 4, 5])
+def test_e2e_loop_matches_reference(ge, gm, ci):
+    ds, mm, S, tanh, seed = E2E_CASES[ci]
+    d = synth.make_pairs(1, seed, ds)
+    pts, ptw = synth.make_keypoints(1, E2E_N, seed, mm)
+    net = SCNetOracle(weights.make_state_dict(E2E_WEIGHT_SEED, S), S, tanh)
+    detail = []
+    # teacher-forced: step s warps with the reference's pose of step s-1
+    forced = [np.eye(4)] + [ge[f"e2e_{ci}_R{s}"] for s in range(2)]
+    _, trace = P.run_pair(net, d["rgb"][0], d["norm"][0], d["depth"][0], pts[0], ptw[0],
+                          gm[f"params_{ds}"], ds, mm, S, detail=detail, R_forced=forced)
+    assert np.array_equal(detail[0]["prim"][0]["pc"].T, ge[f"e2e_{ci}_prim_pc"])
+    assert np.array_equal(detail[0]["prim"][0]["feat"], ge[f"e2e_{ci}_prim_des"])
+    assert np.array_equal(detail[0]["prim"][1]["normal"], ge[f"e2e_{ci}_prim_nt"])
+    for step in range(3):
+        # random-init features make the fit ill-conditioned: roundoff-level
+        # differences (summation order) are amplified to ~1e-6 per step
+        assert np.abs(trace[step] - ge[f"e2e_{ci}_R{step}"]).max() < 1e-4, (ci, step)
