@@ -1,0 +1,180 @@
+/*
+ * relpose.h -- C ABI of librelpose_hip.so, the MI355X (gfx950) implementation of
+ * the relative-pose inference hot path of zhenpeiyang/RelativePose.
+ *
+ * The reference has no FFI: its boundary is a set of Python call sites.  Each
+ * entry point below names the reference function it replaces (file:line in the
+ * upstream tree).  INTEGRATION.md shows the ctypes stubs a maintainer would add
+ * to the reference to route those call sites here.
+ *
+ * Conventions
+ *  - every pointer argument is DEVICE memory unless its name ends in _host;
+ *  - the caller owns all buffers; the library never frees caller memory and
+ *    allocates only inside relpose_scnet_create (packed weights, freed by
+ *    relpose_scnet_destroy); scratch comes from caller-provided workspaces whose
+ *    size is returned by the *_workspace_bytes functions;
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream); no entry point synchronises;
+ *  - return value: 0 = enqueued, <0 = invalid argument (RELPOSE_EINVAL) or HIP
+ *    error (-(1000+hipError_t)).  Per-pair degenerate inputs are NOT errors: the
+ *    reference returns identity for them (rpmodule.py:346-348,377-379,406-408,
+ *    440-443,469-472) and so do we, with the reason in status[b];
+ *  - panoramas are four-face skyboxes, h rows x 4h columns (the reference
+ *    hard-codes h = 160); images are NCHW float32 like the reference tensors.
+ */
+#ifndef RELPOSE_H
+#define RELPOSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RELPOSE_EINVAL (-1)
+#define RELPOSE_ENOMEM (-2)
+
+/* status[b] of relpose_match_pairs */
+enum {
+    RELPOSE_OK = 0,
+    RELPOSE_FEW_KEYPOINTS = 1, /* <3 keypoints or <3 correspondences      rpmodule.py:346,377 */
+    RELPOSE_DIST_FILTER = 2,   /* <3 pairs pass the distance test          rpmodule.py:406 */
+    RELPOSE_ANGLE_FILTER = 3,  /* <3 pairs pass the angle test             rpmodule.py:440 */
+    RELPOSE_ZERO_WEIGHT = 4,   /* every pair weight is 0                   rpmodule.py:469 */
+    RELPOSE_EDGE_OVERFLOW = 5  /* more surviving pairs than the workspace was sized for */
+};
+
+enum { RELPOSE_SUNCG = 0, RELPOSE_MATTERPORT = 1, RELPOSE_SCANNET = 2 };   /* dataset conventions */
+enum { RELPOSE_MASK_SECOND = 0, RELPOSE_MASK_KINECT = 1 };                   /* util.apply_mask methods */
+enum { RELPOSE_FIT_IRLS_SM = 0, RELPOSE_FIT_HORN87 = 1, RELPOSE_FIT_IRLS = 2, RELPOSE_FIT_SPECTRAL = 3 };
+
+/* Hyper-parameters of the pose module: class opts, RPModule/rputil.py:11-22. */
+typedef struct RelposeParams {
+    double distThre;    /* 0.08 */
+    double distSepThre; /* 1.5*0.08 */
+    double angleThre;   /* pi/4 */
+    double sigmaAngle1, sigmaAngle2, sigmaDist, sigmaFeat;
+    double mu;          /* 0.3 */
+    int32_t topK;       /* 5 (<= 8) */
+    int32_t method;     /* RELPOSE_FIT_* ; 'irls+sm' by default */
+} RelposeParams;
+
+void relpose_default_params(RelposeParams* p_host);
+const char* relpose_version(void);
+
+/* ------------------------------------------------------------------ matcher
+ * Keypoint sets of B scan pairs, padded to ns_max / nt_max rows.
+ * Mirrors the dict the reference helper takes (rpmodule.py:317-326):
+ * 'pc'[k,3] f64, 'normal'[k,3] f64, 'feat'[k,32] f32, 'weight'[k] f64. */
+typedef struct RelposeKeypoints {
+    int32_t B, ns_max, nt_max;
+    const int32_t* ns;      /* [B] valid source keypoints per pair */
+    const int32_t* nt;      /* [B] */
+    const double* pc_s;     /* [B, ns_max, 3] */
+    const double* normal_s; /* [B, ns_max, 3] */
+    const float* feat_s;    /* [B, ns_max, 32] (unscaled; /100 happens inside, rpmodule.py:342) */
+    const double* weight_s; /* [B, ns_max] */
+    const double* pc_t;     /* [B, nt_max, 3] */
+    const double* normal_t;
+    const float* feat_t;
+    const double* weight_t;
+} RelposeKeypoints;
+
+/* Optional intermediate outputs of the matcher (any pointer may be NULL). */
+typedef struct RelposeMatchDebug {
+    float* wij;          /* [B, ns_max, nt_max] row-normalised affinity (rpmodule.py:354-363), f32 */
+    int32_t* corres_j;   /* [B, ns_max, topK]   target index of each top-K correspondence (:367-374) */
+    double* corres_w;    /* [B, ns_max, topK]   wij at those entries, f64 */
+    int32_t* counts;     /* [B, 4]  {#pairs passing distance test, #surviving pairs M, #nonzero weights, K_eff} */
+    double* trace;       /* [B, 6, 16] pose after the initial IRLS and after each of the 5 spectral rounds */
+    int32_t* eig_iters;  /* [B, 5]  power iterations used per spectral round */
+} RelposeMatchDebug;
+
+/* max_edges = capacity, per pair, of the symmetric pair-compatibility graph
+ * (2 x surviving pairs); 0 = worst case ns_max*topK*(ns_max*topK-1). */
+size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, int32_t topK, int64_t max_edges);
+
+/* Replaces RelativePoseEstimation_helper (RPModule/rpmodule.py:317-508) for a
+ * batch of pairs: affinity + top-K + pairwise consistency + fit.  pose [B,16]
+ * row-major 4x4 float64, status [B]. */
+int relpose_match_pairs(const RelposeParams* params_host, const RelposeKeypoints* kp_host,
+                        void* workspace, size_t workspace_bytes, int64_t max_edges,
+                        double* pose, int32_t* status, const RelposeMatchDebug* debug_host, void* stream);
+
+/* Stage A+B alone (rpmodule.py:342-379): N x N affinity build and row top-K.
+ * wij may be NULL (fused variant: the matrix is never materialised). */
+int relpose_affinity_topk(const RelposeParams* params_host, const RelposeKeypoints* kp_host,
+                          float* wij, int32_t* corres_j, double* corres_w, int32_t* k_eff, void* stream);
+
+/* ----------------------------------------------------------------- geometry */
+
+/* util.apply_mask (util.py:209-232): x [n,c,h,4h] -> x*mask in place, mask [n,1,h,4h] (may be NULL). */
+int relpose_apply_mask(float* x, float* mask, int32_t n, int32_t c, int32_t h, int32_t method, void* stream);
+
+/* evaluation.py:217-230: view [n,8,h,4h] = mask*(rgb,norm,depth) ++ (masked depth != 0). */
+int relpose_build_view(const float* rgb, const float* norm, const float* depth, float* view,
+                       int32_t n, int32_t h, int32_t method, void* stream);
+
+/* util.Pano2PointCloud (util.py:751-811): depth [n,h,4h] f32 -> pc [n,3,4*h*h] f64 in face-major point
+ * order; valid [n,4*h*h] u8 marks the points the reference keeps (scannet drops depth==0). */
+int relpose_pano2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, int32_t h, int32_t dataset, void* stream);
+
+/* util.warping (util.py:94-172) incl. depth2pc (:468-523) and reproj_helper (:537-749):
+ * view [n,8,h,4h] f32, pose [n,16] f64 -> out [n,8,h,4h] f32 (the f64 result cast like torch_op.v);
+ * identity pose gives zeros.  workspace: relpose_warp_workspace_bytes(n,h). */
+size_t relpose_warp_workspace_bytes(int32_t n, int32_t h);
+int relpose_warp(const float* view, const double* pose, float* out, void* workspace,
+                 int32_t n, int32_t h, int32_t dataset, void* stream);
+
+/* np.linalg.inv of n 4x4 poses (evaluation.py:235). */
+int relpose_pose_inverse(const double* pose, double* inv, int32_t n, void* stream);
+
+/* evaluation.py:246-253 + getMatchingPrimitive after keypoint detection (rpmodule.py:526-532):
+ * compose completed normal/depth, bilinear-sample them at the keypoints (rputil.getPixel :88-119),
+ * unproject, and gather 32-d descriptors (rputil.interpolate :43-58).
+ *   f        [n, cf, h, 4h]  network output; normal = ch 3:6, depth = ch 6, feat = ch feat_off:feat_off+32
+ *   obs_norm [n,3,h,4h], obs_depth [n,h,4h]  the complete input scan (evaluation.py:248-253)
+ *   pts      [n, npts_max, 2] f64 pixel coords (x,y), x<=4h-2, y<=h-2 ; npts [n]
+ *   outputs  pc [n,npts_max,3] f64, normal [n,npts_max,3] f64, feat [n,npts_max,32] f32 */
+int relpose_sample_primitives(const float* f, int32_t cf, int32_t feat_off,
+                              const float* obs_norm, const float* obs_depth,
+                              const double* pts, const int32_t* npts, int32_t npts_max,
+                              double* pc, double* normal, float* feat,
+                              int32_t n, int32_t h, int32_t mask_method, int32_t dataset, void* stream);
+
+/* -------------------------------------------------------------------- SCNet
+ * Replaces SCNet (model/mymodel.py:141-380; skipLayer=1, batchnorm=1, outputType 'rgbdnsf'). */
+typedef struct RelposeSCNet RelposeSCNet;
+
+RelposeSCNet* relpose_scnet_create(int32_t snumclass, int32_t use_tanh);
+void relpose_scnet_destroy(RelposeSCNet* net);
+
+/* One state_dict entry (key names = the reference module tree, e.g. "conv4.0.weight",
+ * "deconv3rgb.1.bias", "deconv1f.weight"); data_host float32 in torch layout. */
+int relpose_scnet_set_param(RelposeSCNet* net, const char* key, const float* data_host, size_t numel);
+/* Pack + upload once all keys are set; returns <0 and lists nothing if a key is missing. */
+int relpose_scnet_finalize(RelposeSCNet* net);
+int64_t relpose_scnet_num_params(const RelposeSCNet* net);
+
+size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n_images, int32_t H, int32_t W);
+
+/* forward: x [n,16,H,W] -> out [n,7+S+32,H,W]; n even, BatchNorm statistics over each
+ * consecutive group of 2 images (the reference always feeds batch 2, evaluation.py:242). */
+int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Debug: copy a raw (pre-BatchNorm) layer output of the last forward, NHWC float32, to out (device).
+ * Returns the number of floats written (or needed if out is NULL), <0 if unknown. */
+int64_t relpose_scnet_read_tap(RelposeSCNet* net, const char* layer, float* out, void* workspace, void* stream);
+
+/* Per-kernel timing of the conv stack for the bench roofline (HIP events on `stream`):
+ * runs `iters` forwards and returns mean ms of the implicit-GEMM kernels and of everything else. */
+int relpose_scnet_profile(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
+                          void* workspace, size_t workspace_bytes, int32_t iters,
+                          double* ms_gemm_host, double* ms_other_host, int64_t* n_gemm_launches_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELPOSE_H */

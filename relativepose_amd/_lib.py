@@ -1,0 +1,100 @@
+"""ctypes binding of librelpose_hip.so (the C ABI in include/relpose.h).
+
+The product path has no CPU fallback: if the library is missing or a call is
+made without a GPU, it raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librelpose_hip.so")
+
+c_void_p, c_int, c_int64, c_size_t, c_double, c_char_p = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_double, C.c_char_p
+
+
+class Params(C.Structure):
+    _fields_ = [("distThre", c_double), ("distSepThre", c_double), ("angleThre", c_double),
+                ("sigmaAngle1", c_double), ("sigmaAngle2", c_double), ("sigmaDist", c_double),
+                ("sigmaFeat", c_double), ("mu", c_double), ("topK", c_int), ("method", c_int)]
+
+
+class Keypoints(C.Structure):
+    _fields_ = [("B", c_int), ("ns_max", c_int), ("nt_max", c_int),
+                ("ns", c_void_p), ("nt", c_void_p),
+                ("pc_s", c_void_p), ("normal_s", c_void_p), ("feat_s", c_void_p), ("weight_s", c_void_p),
+                ("pc_t", c_void_p), ("normal_t", c_void_p), ("feat_t", c_void_p), ("weight_t", c_void_p)]
+
+
+class MatchDebug(C.Structure):
+    _fields_ = [("wij", c_void_p), ("corres_j", c_void_p), ("corres_w", c_void_p),
+                ("counts", c_void_p), ("trace", c_void_p), ("eig_iters", c_void_p)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/relpose.h
+SIGNATURES = {
+    "relpose_default_params": (None, [C.POINTER(Params)]),
+    "relpose_version": (c_char_p, []),
+    "relpose_match_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int64]),
+    "relpose_match_pairs": (c_int, [C.POINTER(Params), C.POINTER(Keypoints), c_void_p, c_size_t, c_int64,
+                                    c_void_p, c_void_p, C.POINTER(MatchDebug), c_void_p]),
+    "relpose_affinity_topk": (c_int, [C.POINTER(Params), C.POINTER(Keypoints), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "relpose_apply_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "relpose_build_view": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "relpose_pano2pc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "relpose_warp_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "relpose_warp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "relpose_pose_inverse": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "relpose_sample_primitives": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "relpose_scnet_create": (c_void_p, [c_int, c_int]),
+    "relpose_scnet_destroy": (None, [c_void_p]),
+    "relpose_scnet_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "relpose_scnet_finalize": (c_int, [c_void_p]),
+    "relpose_scnet_num_params": (c_int64, [c_void_p]),
+    "relpose_scnet_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "relpose_scnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "relpose_scnet_read_tap": (c_int64, [c_void_p, c_char_p, c_void_p, c_void_p, c_void_p]),
+    "relpose_scnet_profile": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_int,
+                                      C.POINTER(c_double), C.POINTER(c_double), C.POINTER(c_int64), c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built: run `python -m relativepose_amd.build` "
+                               "(or __graft_entry__.build()). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        missing = [name for name in SIGNATURES if not hasattr(l, name)]
+        if missing:
+            raise RuntimeError(f"{LIB_PATH} is stale, missing symbols: {missing}")
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}" + (" (HIP error %d)" % (-rc - 1000) if rc <= -1000 else ""))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("relativepose_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,363 @@
+// Panorama geometry on gfx950: mask, unprojection, rigid warp with deterministic
+// scatter re-projection, output composition + keypoint sampling.  One thread per
+// pixel / point / keypoint; these kernels are HBM-bound streaming passes.
+//
+// Reference sites: util.py apply_mask :209-232, warping :94-172, depth2pc :468-523,
+// reproj_helper :537-749, Pano2PointCloud :751-811; rputil.py interpolate :43-58,
+// getPixel :61-119; evaluation.py :217-270.
+//
+// Compiled with -ffp-contract=off: pixel rounding and the float32 bilinear
+// descriptor gather must round like numpy / torch (no FMA fusion).
+#include "common.h"
+#include "rp_math.h"
+
+namespace {
+
+// Face rotations Rs[k] of the skybox (util.py:757-761).  Entries are 0/+-1, so applying
+// them is an exact permutation/sign flip.  ROT(k, v) = Rs[k] @ v ;  ROTT = Rs[k]^T @ v.
+__device__ __forceinline__ void face_rot(int k, double x, double y, double z, double& ox, double& oy, double& oz) {
+    switch (k & 3) {
+        case 0: ox = x; oy = y; oz = z; break;
+        case 1: ox = -z; oy = y; oz = x; break;
+        case 2: ox = -x; oy = y; oz = -z; break;
+        default: ox = z; oy = y; oz = -x; break;
+    }
+}
+__device__ __forceinline__ void face_rot_t(int k, double x, double y, double z, double& ox, double& oy, double& oz) {
+    switch (k & 3) {
+        case 0: ox = x; oy = y; oz = z; break;
+        case 1: ox = z; oy = y; oz = -x; break;
+        case 2: ox = -x; oy = y; oz = -z; break;
+        default: ox = -z; oy = y; oz = x; break;
+    }
+}
+__device__ __forceinline__ int face_index(int dataset, int slot) { return dataset == RELPOSE_SUNCG ? slot : (slot + 3) & 3; }
+
+struct Box { int y0, y1, x0, x1; };
+__host__ __device__ inline Box observed_box(int method, int h) {
+    Box b;
+    if (method == RELPOSE_MASK_SECOND) { b.y0 = 0; b.y1 = h; b.x0 = h; b.x1 = 2 * h; }
+    else {
+        // util.py:226-228: dw = int(89.67//2) = 44, dh = int(67.25//2) = 33 at h = 160
+        int dw = (int)(44 * (h / 160.0)), dh = (int)(33 * (h / 160.0));
+        b.y0 = h / 2 - dh; b.y1 = h / 2 + dh; b.x0 = h + h / 2 - dw; b.x1 = h + h / 2 + dw;
+    }
+    return b;
+}
+
+__global__ void apply_mask_kernel(float* x, float* mask, int n, int c, int h, Box bx) {
+    const size_t hw = (size_t)h * 4 * h;
+    const size_t total = (size_t)n * hw;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = idx / hw, p = idx - img * hw;
+        const int y = (int)(p / (4 * h)), xx = (int)(p - (size_t)y * 4 * h);
+        const float m = (y >= bx.y0 && y < bx.y1 && xx >= bx.x0 && xx < bx.x1) ? 1.0f : 0.0f;
+        if (mask) mask[idx] = m;
+        for (int ch = 0; ch < c; ++ch) { float* q = x + (img * c + ch) * hw + p; *q = *q * m; }
+    }
+}
+
+__global__ void build_view_kernel(const float* __restrict__ rgb, const float* __restrict__ nrm, const float* __restrict__ dep,
+                                  float* __restrict__ view, int n, int h, Box bx) {
+    const size_t hw = (size_t)h * 4 * h;
+    const size_t total = (size_t)n * hw;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = idx / hw, p = idx - img * hw;
+        const int y = (int)(p / (4 * h)), xx = (int)(p - (size_t)y * 4 * h);
+        const float m = (y >= bx.y0 && y < bx.y1 && xx >= bx.x0 && xx < bx.x1) ? 1.0f : 0.0f;
+        float* v = view + img * 8 * hw + p;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            v[ch * hw] = rgb[(img * 3 + ch) * hw + p] * m;
+            v[(3 + ch) * hw] = nrm[(img * 3 + ch) * hw + p] * m;
+        }
+        const float d = dep[img * hw + p] * m;
+        v[6 * hw] = d;
+        v[7 * hw] = (d != 0.0f) ? 1.0f : 0.0f;
+    }
+}
+
+// util.py:763-771: (x,y,-z) = ((u/h-.5)*2*z, (.5-v/h)*2*z, -z), rotated by the face rotation.
+__global__ void pano2pc_kernel(const float* __restrict__ depth, double* __restrict__ pc, uint8_t* __restrict__ valid,
+                               int n, int h, int dataset) {
+    const size_t hw = (size_t)h * 4 * h;
+    const size_t total = (size_t)n * hw;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t img = idx / hw, q = idx - img * hw;          // q = face-major point index
+        const int face = (int)(q / ((size_t)h * h));
+        const int r = (int)(q - (size_t)face * h * h);
+        const int v = r / h, u = r - v * h;
+        const double z = (double)depth[img * hw + (size_t)v * 4 * h + face * h + u];
+        double xs = ((double)u / h - 0.5) * 2, ys = (0.5 - (double)v / h) * 2;
+        double x, y;
+        if (dataset == RELPOSE_SCANNET) { y = ys * z / (1.1895 * 2); x = xs * z / (0.8921875 * 2); }
+        else { y = ys * z; x = xs * z; }
+        double ox, oy, oz;
+        face_rot(face_index(dataset, face), x, y, -z, ox, oy, oz);
+        double* o = pc + img * 3 * hw;
+        o[q] = ox; o[hw + q] = oy; o[2 * hw + q] = oz;
+        if (valid) valid[idx] = (dataset == RELPOSE_SCANNET) ? (z != 0.0) : 1;
+    }
+}
+
+// ---- warp ------------------------------------------------------------------------------------
+struct WarpSrc { int npts, pw; int y0, x0; };   // observed block: pw columns starting at (y0,x0)
+
+__host__ __device__ inline WarpSrc warp_src(int dataset, int h) {
+    WarpSrc s;
+    if (dataset == RELPOSE_SCANNET) {
+        Box b = observed_box(RELPOSE_MASK_KINECT, h);
+        s.y0 = b.y0; s.x0 = b.x0; s.pw = b.x1 - b.x0; s.npts = (b.y1 - b.y0) * s.pw;
+    } else { s.y0 = 0; s.x0 = h; s.pw = h; s.npts = h * h; }
+    return s;
+}
+
+// Source point p of image `img` in the panorama frame, then moved by the pose.  Returns false if
+// the reference drops the point (depth == 0 for matterport / scannet; suncg keeps everything).
+__device__ __forceinline__ bool warp_point(const float* view, const double* T, int h, int dataset, const WarpSrc& s, int p,
+                                           double* q, int& py, int& px) {
+    const size_t hw = (size_t)h * 4 * h;
+    const int v = p / s.pw, u = p - v * s.pw;
+    py = s.y0 + v; px = s.x0 + u;
+    const double z = (double)view[6 * hw + (size_t)py * 4 * h + px];
+    if (dataset != RELPOSE_SUNCG && z == 0.0) return false;
+    double x, y, X, Y, Z;
+    if (dataset == RELPOSE_SCANNET) {
+        const int ph = s.npts / s.pw;
+        const double xs = ((double)u / s.pw - 0.5) * 2, ys = (0.5 - (double)v / ph) * 2;
+        x = (xs * z) * s.pw / 160; y = (ys * z) * ph / 160;      // util.py:519-521
+        X = x; Y = y; Z = -z;
+    } else {
+        const double xs = ((double)u / h - 0.5) * 2, ys = (0.5 - (double)v / h) * 2;
+        x = xs * z; y = ys * z;
+        if (dataset == RELPOSE_SUNCG) face_rot(1, x, y, -z, X, Y, Z);   // observed face = slot 1, Rs[1]
+        else { X = x; Y = y; Z = -z; }                                  // matterport: Rs[(1-1)%4] = I
+    }
+    // np.matmul(R44, [p;1])[:3]
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q[a] = ((T[a * 4 + 0] * X + T[a * 4 + 1] * Y) + T[a * 4 + 2] * Z) + T[a * 4 + 3] * 1.0;
+    return true;
+}
+
+// Projection of a moved point into face slot `slot` (reproj_helper).  Returns pixel or -1.
+__device__ __forceinline__ int warp_project(const double* q, int h, int dataset, int slot, double& depth_out) {
+    double x, y, z;
+    face_rot_t(face_index(dataset, slot), q[0], q[1], q[2], x, y, z);
+    const double az = fabs(z) + 1e-32;
+    const double xn = x / az, yn = y / az;
+    if (!((z < 0) && (fabs(xn) < 1) && (fabs(yn) < 1))) return -1;
+    double cx = (xn + 1) * 0.5 * h, cy = (1 - yn) * 0.5 * h;
+    cx = rint(cx); cy = rint(cy);                       // np.round = round-half-even
+    cx = cx < 0 ? 0 : (cx > h - 1 ? h - 1 : cx);
+    cy = cy < 0 ? 0 : (cy > h - 1 ? h - 1 : cy);
+    depth_out = -z;
+    return (int)cy * 4 * h + slot * h + (int)cx;
+}
+
+__device__ __forceinline__ bool pose_is_identity(const double* T) {
+    bool id = true;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) id = id && (T[a] == ((a % 5 == 0) ? 1.0 : 0.0));
+    return id;
+}
+
+// pass 1: every source point claims its target pixel in each face with atomicMax(point index + 1):
+// numpy fancy assignment = the last point in point order wins (util.py:603-608).
+__global__ void warp_scatter_kernel(const float* __restrict__ view, const double* __restrict__ pose, int* __restrict__ keys,
+                                    int n, int h, int dataset, WarpSrc s) {
+    const int img = blockIdx.y;
+    const double* T = pose + (size_t)img * 16;
+    if (pose_is_identity(T)) return;
+    const size_t hw = (size_t)h * 4 * h;
+    const float* vw = view + (size_t)img * 8 * hw;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < s.npts; p += gridDim.x * blockDim.x) {
+        double q[3]; int py, px;
+        if (!warp_point(vw, T, h, dataset, s, p, q, py, px)) continue;
+#pragma unroll
+        for (int slot = 0; slot < 4; ++slot) {
+            double dz;
+            const int pix = warp_project(q, h, dataset, slot, dz);
+            if (pix >= 0) atomicMax(&keys[(size_t)img * hw + pix], p + 1);
+        }
+    }
+}
+
+// pass 2: every output pixel gathers from the winning point.
+__global__ void warp_gather_kernel(const float* __restrict__ view, const double* __restrict__ pose, const int* __restrict__ keys,
+                                   float* __restrict__ out, int n, int h, int dataset, WarpSrc s) {
+    const int img = blockIdx.y;
+    const double* T = pose + (size_t)img * 16;
+    const bool ident = pose_is_identity(T);
+    const size_t hw = (size_t)h * 4 * h;
+    const float* vw = view + (size_t)img * 8 * hw;
+    float* o = out + (size_t)img * 8 * hw;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < (int)hw; pix += gridDim.x * blockDim.x) {
+        float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int key = ident ? 0 : keys[(size_t)img * hw + pix];
+        if (key > 0) {
+            const int p = key - 1;
+            double q[3]; int py, px;
+            warp_point(vw, T, h, dataset, s, p, q, py, px);
+            const int xx = pix % (4 * h);
+            double dz;
+            warp_project(q, h, dataset, xx / h, dz);
+            const size_t sp = (size_t)py * 4 * h + px;
+            const double n0 = (double)vw[3 * hw + sp], n1 = (double)vw[4 * hw + sp], n2 = (double)vw[5 * hw + sp];
+            r[0] = vw[sp]; r[1] = vw[hw + sp]; r[2] = vw[2 * hw + sp];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) r[3 + a] = (float)((T[a * 4 + 0] * n0 + T[a * 4 + 1] * n1) + T[a * 4 + 2] * n2);
+            r[6] = (float)dz;
+            r[7] = (dz != 0.0) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) o[ch * hw + pix] = r[ch];
+    }
+}
+
+__global__ void pose_inverse_kernel(const double* __restrict__ pose, double* __restrict__ inv, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a[16], o[16];
+    for (int k = 0; k < 16; ++k) a[k] = pose[(size_t)i * 16 + k];
+    if (!rp_inv4(a, o)) for (int k = 0; k < 16; ++k) o[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    for (int k = 0; k < 16; ++k) inv[(size_t)i * 16 + k] = o[k];
+}
+
+// ---- compose + sample ------------------------------------------------------------------------
+// evaluation.py:248-253 in float32 exactly as numpy evaluates it:
+//   normal = ((1-m)*f_n + m*obs_n) / (||obs_n|| + 1e-6) ;  depth = (1-m)*f_d + m*obs_d
+__device__ __forceinline__ void composed_pixel(const float* f, int cf, const float* on, const float* od, size_t hw, int h, Box bx,
+                                               int y, int x, float* nout, float& dout) {
+    const size_t p = (size_t)y * 4 * h + x;
+    const float m = (y >= bx.y0 && y < bx.y1 && x >= bx.x0 && x < bx.x1) ? 1.0f : 0.0f;
+    const float om = 1.0f - m;
+    const float o0 = on[p], o1 = on[hw + p], o2 = on[2 * hw + p];
+    const float nn = sqrtf((o0 * o0 + o1 * o1) + o2 * o2) + 1e-6f;
+    nout[0] = (om * f[3 * hw + p] + m * o0) / nn;
+    nout[1] = (om * f[4 * hw + p] + m * o1) / nn;
+    nout[2] = (om * f[5 * hw + p] + m * o2) / nn;
+    dout = om * f[6 * hw + p] + m * od[p];
+}
+
+__global__ void sample_primitives_kernel(const float* __restrict__ f, int cf, int feat_off, const float* __restrict__ obs_norm,
+                                         const float* __restrict__ obs_depth, const double* __restrict__ pts,
+                                         const int* __restrict__ npts, int npts_max, double* __restrict__ pc,
+                                         double* __restrict__ normal, float* __restrict__ feat, int n, int h, Box bx, int dataset) {
+    const int img = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= npts[img]) return;
+    const size_t hw = (size_t)h * 4 * h;
+    const int W = 4 * h;
+    const float* fi = f + (size_t)img * cf * hw;
+    const float* on = obs_norm + (size_t)img * 3 * hw;
+    const float* od = obs_depth + (size_t)img * hw;
+    const double px = pts[((size_t)img * npts_max + k) * 2 + 0], py = pts[((size_t)img * npts_max + k) * 2 + 1];
+    // rputil.getPixel :88-119 (float64 bilinear of the float32 composed maps)
+    const int tx = (int)floor(px), ty = (int)floor(py);
+    const double fx1 = px - tx, fx0 = tx + 1 - px, fy1 = py - ty, fy0 = ty + 1 - py;
+    float n00[3], n01[3], n10[3], n11[3], d00, d01, d10, d11;
+    composed_pixel(fi, cf, on, od, hw, h, bx, ty, tx, n00, d00);
+    composed_pixel(fi, cf, on, od, hw, h, bx, ty, tx + 1, n01, d01);
+    composed_pixel(fi, cf, on, od, hw, h, bx, ty + 1, tx, n10, d10);
+    composed_pixel(fi, cf, on, od, hw, h, bx, ty + 1, tx + 1, n11, d11);
+    const double val = (((double)d00 * fy0 * fx0 + (double)d01 * fx1 * fy0) + (double)d10 * fy1 * fx0) + (double)d11 * fx1 * fy1;
+    double nn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        nn[a] = (((double)n00[a] * fy0 * fx0 + (double)n01[a] * fx1 * fy0) + (double)n10[a] * fy1 * fx0) + (double)n11[a] * fx1 * fy1;
+    const double nl = rp_norm3(nn[0], nn[1], nn[2]);
+    double* no = normal + ((size_t)img * npts_max + k) * 3;
+    no[0] = nn[0] / nl; no[1] = nn[1] / nl; no[2] = nn[2] / nl;
+    // getPixel_helper :61-86
+    const int slot = (int)floor(px / h);          // xs // H
+    const double ystp = (0.5 - py / h) * 2, xstp = ((px - slot * h) / h - 0.5) * 2;
+    double ox, oy, oz;
+    face_rot(face_index(dataset, slot), xstp * val, ystp * val, -val, ox, oy, oz);
+    double* po = pc + ((size_t)img * npts_max + k) * 3;
+    po[0] = ox; po[1] = oy; po[2] = oz;
+    // rputil.interpolate :43-58 in float32: pt = (x/W, y/H) cast to float32, x = pt*(W-1)
+    const float ptx = (float)(px / W), pty = (float)(py / h);
+    const float x = ptx * (float)(W - 1), y = pty * (float)(h - 1);
+    const float x0 = floorf(x), y0 = floorf(y);
+    const int xi = (int)x0, yi = (int)y0;
+    const float wx0 = x0 + 1.0f - x, wy0 = y0 + 1.0f - y, wx1 = x - x0, wy1 = y - y0;
+    const float* ff = fi + (size_t)feat_off * hw;
+    float* fo = feat + ((size_t)img * npts_max + k) * 32;
+    for (int c = 0; c < 32; ++c) {
+        const float* fc = ff + (size_t)c * hw;
+        const float v00 = fc[(size_t)yi * W + xi], v10 = fc[(size_t)(yi + 1) * W + xi];
+        const float v01 = fc[(size_t)yi * W + xi + 1], v11 = fc[(size_t)(yi + 1) * W + xi + 1];
+        fo[c] = ((v00 * wx0 * wy0 + v10 * wx0 * wy1) + v01 * wx1 * wy0) + v11 * wx1 * wy1;
+    }
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 4096) {
+    size_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int relpose_apply_mask(float* x, float* mask, int32_t n, int32_t c, int32_t h, int32_t method, void* stream) {
+    if (!x || n <= 0 || c <= 0 || h <= 0 || method < 0 || method > 1) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(apply_mask_kernel, dim3(grid_for((size_t)n * h * 4 * h)), dim3(256), 0, (hipStream_t)stream, x, mask, n, c, h,
+                       observed_box(method, h));
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int relpose_build_view(const float* rgb, const float* norm, const float* depth, float* view, int32_t n, int32_t h, int32_t method,
+                       void* stream) {
+    if (!rgb || !norm || !depth || !view || n <= 0 || h <= 0 || method < 0 || method > 1) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(build_view_kernel, dim3(grid_for((size_t)n * h * 4 * h)), dim3(256), 0, (hipStream_t)stream, rgb, norm, depth,
+                       view, n, h, observed_box(method, h));
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int relpose_pano2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, int32_t h, int32_t dataset, void* stream) {
+    if (!depth || !pc || n <= 0 || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(pano2pc_kernel, dim3(grid_for((size_t)n * h * 4 * h, 256, 8192)), dim3(256), 0, (hipStream_t)stream, depth, pc,
+                       valid, n, h, dataset);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+size_t relpose_warp_workspace_bytes(int32_t n, int32_t h) { return (n <= 0 || h <= 0) ? 0 : rp_align((size_t)n * h * 4 * h * 4); }
+
+int relpose_warp(const float* view, const double* pose, float* out, void* workspace, int32_t n, int32_t h, int32_t dataset, void* stream) {
+    if (!view || !pose || !out || !workspace || n <= 0 || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t hw = (size_t)h * 4 * h;
+    int* keys = (int*)workspace;
+    RP_HIP(hipMemsetAsync(keys, 0, (size_t)n * hw * 4, s));
+    const WarpSrc src = warp_src(dataset, h);
+    hipLaunchKernelGGL(warp_scatter_kernel, dim3((src.npts + 255) / 256, n), dim3(256), 0, s, view, pose, keys, n, h, dataset, src);
+    RP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(warp_gather_kernel, dim3((int)((hw + 255) / 256), n), dim3(256), 0, s, view, pose, keys, out, n, h, dataset, src);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int relpose_pose_inverse(const double* pose, double* inv, int32_t n, void* stream) {
+    if (!pose || !inv || n <= 0) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(pose_inverse_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, inv, n);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int relpose_sample_primitives(const float* f, int32_t cf, int32_t feat_off, const float* obs_norm, const float* obs_depth,
+                              const double* pts, const int32_t* npts, int32_t npts_max, double* pc, double* normal, float* feat,
+                              int32_t n, int32_t h, int32_t mask_method, int32_t dataset, void* stream) {
+    if (!f || !obs_norm || !obs_depth || !pts || !npts || !pc || !normal || !feat || n <= 0 || h <= 0 || npts_max <= 0 ||
+        cf < 7 || feat_off < 7 || feat_off + 32 > cf || mask_method < 0 || mask_method > 1 || dataset < 0 || dataset > 2)
+        return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(sample_primitives_kernel, dim3((npts_max + 63) / 64, n), dim3(64), 0, (hipStream_t)stream, f, cf, feat_off,
+                       obs_norm, obs_depth, pts, npts, npts_max, pc, normal, feat, n, h, observed_box(mask_method, h), dataset);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,656 @@
+// Spectral-matching pose module on gfx950: batched replacement of
+// RelativePoseEstimation_helper (reference RPModule/rpmodule.py:317-508).
+//
+// Kernel sequence per batch of scan pairs (all on one stream, no host sync):
+//   affinity_topk   rpmodule.py:342-379  N x N descriptor affinity (f32 distance in numpy's
+//                                         summation order, f64 weights), row norm, row top-K
+//   pair_flags      rpmodule.py:381-451  all C(C-1)/2 correspondence pairs: distance + angle tests,
+//                                         one wave per row, survivors as a bitmap (ballot)
+//   pair_scan                            CSR row pointers of the symmetric compatibility graph, status
+//   pair_fill       rpmodule.py:453-467  weights of the survivors, written in deterministic CSR order
+//   fit             rpmodule.py:212-315  IRLS + spectral rounds; one workgroup per scan pair
+//
+// The fit never materialises the reference's [4M] stacked arrays: a pair's IRLS weight factorises
+// into (pair weight) x (per-correspondence reweighting product), so every weighted sum over 4M
+// elements collapses to a sum over the C correspondences with the graph's weighted degree
+// (DESIGN.md "fit").  The leading eigenvector is a power iteration on the C x C compressed
+// graph instead of ARPACK on the (Ns*Nt)^2 sparse matrix.
+//
+// Compiled with -ffp-contract=off: the f32 distance and the f64 threshold tests must round like numpy.
+#include "common.h"
+#include "rp_math.h"
+#include <limits.h>
+#include <string.h>
+
+#define RP_MAXK 8
+#define RP_FEAT 32
+#define RP_FIT_THREADS 1024
+#define RP_EPS 1e-12
+#define RP_OFFSET 50.0
+
+namespace {
+
+struct Graph {                 // per-batch device arrays of the pair-compatibility graph
+    int32_t Cmax, Wmax;
+    int64_t max_edges;
+    const int32_t* corres_j;   // [B, ns_max, topK]
+    const double* corres_w;    // [B, ns_max, topK]
+    const int32_t* keff;       // [B]
+    unsigned long long* bitmap;  // [B, Cmax, Wmax]
+    int32_t* upcnt;            // [B, Cmax]
+    int32_t* lowcnt;           // [B, Cmax]
+    int32_t* counters;         // [B, 4]  n_dist, M, nnz(x2), unused
+    int32_t* rowptr;           // [B, Cmax+1]
+    int32_t* col;              // [B, max_edges]
+    double* wv;                // [B, max_edges]
+    double* xe;                // [B, max_edges]
+    double* state;             // [B, 4, Cmax]  deg, gP, gN, rsum
+};
+
+__device__ __forceinline__ int pair_C(const RelposeKeypoints& kp, const Graph& g, int b) {
+    int ns = kp.ns[b], nt = kp.nt[b];
+    if (ns < 3 || nt < 3) return 0;
+    return ns * g.keff[b];
+}
+
+struct Corr { double ps[3], ns[3], pt[3], nt[3]; double f, ws, wt; };
+
+__device__ __forceinline__ void load_corr(const RelposeKeypoints& kp, const Graph& g, int b, int topK, int keff, int c, Corr& o) {
+    int i = c / keff, kk = c - i * keff;
+    size_t si = (size_t)b * kp.ns_max + i;
+    int j = g.corres_j[si * topK + kk];
+    size_t ti = (size_t)b * kp.nt_max + j;
+    o.f = g.corres_w[si * topK + kk];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o.ps[a] = kp.pc_s[si * 3 + a]; o.ns[a] = kp.normal_s[si * 3 + a];
+        o.pt[a] = kp.pc_t[ti * 3 + a]; o.nt[a] = kp.normal_t[ti * 3 + a];
+    }
+    o.ws = kp.weight_s[si]; o.wt = kp.weight_t[ti];
+}
+
+// ------------------------------------------------------------------ affinity + top-K
+__device__ __forceinline__ float desc_dist(float fs, const float* ftT, int ldt, int j) {
+    float r[8];
+#pragma unroll
+    for (int c = 0; c < RP_FEAT; ++c) {
+        float s = __shfl(fs, c, 64);
+        float df = s - ftT[c * ldt + j];
+        float sq = df * df;
+        if (c < 8) r[c] = sq; else r[c & 7] = r[c & 7] + sq;
+    }
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
+template <bool WRITE_WIJ>
+__global__ __launch_bounds__(256) void affinity_topk_kernel(RelposeKeypoints kp, RpPairConsts kc, int topK, int rows_per_block,
+                                                             float* __restrict__ wij, int32_t* __restrict__ corres_j,
+                                                             double* __restrict__ corres_w, int32_t* __restrict__ keff_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y;
+    const int ns = kp.ns[b], nt = kp.nt[b];
+    const int ntp = (kp.nt_max + 63) & ~63;
+    const int ldt = ntp + 1;
+    double* wt_s = (double*)smem;                       // [ntp]
+    float* ftT = (float*)(smem + (size_t)ntp * 8);      // [32][ldt]
+    const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
+    if (keff == 0) return;
+    const float* ft = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
+    for (int idx = threadIdx.x; idx < ntp * RP_FEAT; idx += 256) {
+        int j = idx >> 5, c = idx & 31;
+        ftT[c * ldt + j] = (j < nt) ? ft[(size_t)j * RP_FEAT + c] / 100.0f : 0.0f;
+    }
+    for (int j = threadIdx.x; j < ntp; j += 256) wt_s[j] = (j < nt) ? kp.weight_t[(size_t)b * kp.nt_max + j] : 0.0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int rr = wave; rr < rows_per_block; rr += 4) {
+        const int i = blockIdx.x * rows_per_block + rr;
+        if (i >= ns) break;
+        const size_t si = (size_t)b * kp.ns_max + i;
+        const float fs = (lane < RP_FEAT) ? kp.feat_s[si * RP_FEAT + lane] / 100.0f : 0.0f;
+        const double wsi = kp.weight_s[si];
+        double te[RP_MAXK];
+        int tj[RP_MAXK];
+#pragma unroll
+        for (int q = 0; q < RP_MAXK; ++q) { te[q] = -INFINITY; tj[q] = INT_MAX; }
+        double sumsq = 0.0;
+        for (int j0 = 0; j0 < nt; j0 += 64) {
+            const int j = j0 + lane;
+            const bool valid = j < nt;
+            const int jj = valid ? j : 0;
+            const float d = desc_dist(fs, ftT, ldt, jj);
+            const double den = (wsi * wt_s[jj] == 1.0) ? kc.den_both : kc.den_other;
+            const double e = (-(double)d) / den;
+            const double w = exp(e);
+            if (valid) {
+                sumsq += w * w;
+                if (e > te[RP_MAXK - 1]) {            // strict: equal e keeps the smaller (earlier) j
+                    te[RP_MAXK - 1] = e; tj[RP_MAXK - 1] = j;
+#pragma unroll
+                    for (int q = RP_MAXK - 1; q > 0; --q) {
+                        if (te[q] > te[q - 1]) {
+                            double t0 = te[q]; te[q] = te[q - 1]; te[q - 1] = t0;
+                            int t1 = tj[q]; tj[q] = tj[q - 1]; tj[q - 1] = t1;
+                        }
+                    }
+                }
+            }
+        }
+        const double nm = sqrt(rp_wave_sum(sumsq));
+        for (int k = 0; k < keff; ++k) {
+            double be = te[0];
+            int bj = tj[0];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                double oe = rp_shfl_xor_d(be, m);
+                int oj = __shfl_xor(bj, m, 64);
+                if (oe > be || (oe == be && oj < bj)) { be = oe; bj = oj; }
+            }
+            if (tj[0] == bj && bj != INT_MAX) {       // this lane owned the winner: pop it
+#pragma unroll
+                for (int q = 0; q < RP_MAXK - 1; ++q) { te[q] = te[q + 1]; tj[q] = tj[q + 1]; }
+                te[RP_MAXK - 1] = -INFINITY; tj[RP_MAXK - 1] = INT_MAX;
+            }
+            if (lane == 0) {
+                const bool ok = bj >= 0 && bj < nt;
+                corres_j[si * topK + k] = ok ? bj : 0;
+                corres_w[si * topK + k] = (ok && nm != 0.0) ? exp(be) / nm : 0.0;
+            }
+        }
+        if (WRITE_WIJ) {
+            float* row = wij + si * kp.nt_max;
+            for (int j0 = 0; j0 < nt; j0 += 64) {
+                const int j = j0 + lane;
+                const bool valid = j < nt;
+                const int jj = valid ? j : 0;
+                const float d = desc_dist(fs, ftT, ldt, jj);
+                const double den = (wsi * wt_s[jj] == 1.0) ? kc.den_both : kc.den_other;
+                const double w = exp((-(double)d) / den);
+                if (valid) row[j] = (nm != 0.0) ? (float)(w / nm) : 0.0f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pair consistency
+__global__ __launch_bounds__(256) void pair_flags_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK) {
+    const int b = blockIdx.y;
+    const int C = pair_C(kp, g, b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= C) return;
+    const int keff = g.keff[b];
+    Corr a;
+    load_corr(kp, g, b, topK, keff, r, a);
+    const int nch = (C + 63) >> 6;
+    int cnt_up = 0, nd = 0;
+    for (int ch = r >> 6; ch < nch; ++ch) {
+        const int c = ch * 64 + lane;
+        bool pd = false, pa = false;
+        if (c > r && c < C) {
+            Corr o;
+            load_corr(kp, g, b, topK, keff, c, o);
+            RpPairEval ev = rp_pair_eval(a.ps, a.ns, a.pt, a.nt, o.ps, o.ns, o.pt, o.nt, kc);
+            pd = ev.pass_dist; pa = ev.pass_all;
+        }
+        const unsigned long long md = __ballot(pd), ma = __ballot(pa);
+        if (lane == 0) g.bitmap[((size_t)b * g.Cmax + r) * g.Wmax + ch] = ma;
+        nd += __popcll(md);
+        cnt_up += __popcll(ma);
+        if (pa) atomicAdd(&g.lowcnt[(size_t)b * g.Cmax + c], 1);
+    }
+    if (lane == 0) {
+        g.upcnt[(size_t)b * g.Cmax + r] = cnt_up;
+        if (nd) atomicAdd(&g.counters[b * 4 + 0], nd);
+        if (cnt_up) atomicAdd(&g.counters[b * 4 + 1], cnt_up);
+    }
+}
+
+__global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Graph g, int32_t* __restrict__ status) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int b = blockIdx.x;
+    const int C = pair_C(kp, g, b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < C; base += 1024) {
+        const int c = base + threadIdx.x;
+        int v = (c < C) ? g.upcnt[(size_t)b * g.Cmax + c] + g.lowcnt[(size_t)b * g.Cmax + c] : 0;
+        int inc = v;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { int t = __shfl_up(inc, m, 64); if (lane >= m) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int pre = carry_s;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+        if (c < C) rp[c] = pre + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = pre + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int total = carry_s;
+        rp[C] = total;
+        int st = RELPOSE_OK;
+        if (C < 3) st = RELPOSE_FEW_KEYPOINTS;
+        else if (g.counters[b * 4 + 0] < 3) st = RELPOSE_DIST_FILTER;
+        else if (g.counters[b * 4 + 1] < 3) st = RELPOSE_ANGLE_FILTER;
+        else if ((int64_t)total > g.max_edges) st = RELPOSE_EDGE_OVERFLOW;
+        status[b] = st;
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK,
+                                                         const int32_t* __restrict__ status) {
+    const int b = blockIdx.y;
+    if (status[b] != RELPOSE_OK) return;
+    const int C = pair_C(kp, g, b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    const int keff = g.keff[b];
+    Corr me;
+    load_corr(kp, g, b, topK, keff, c, me);
+    const size_t eoff = (size_t)b * g.max_edges;
+    int run = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
+    int nz = 0;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // lower part: pairs (r, c), r < c  -- canonical orientation "1" = r, "2" = c
+    for (int ch = 0; ch * 64 < c; ++ch) {
+        const int r = ch * 64 + lane;
+        bool bit = false;
+        if (r < c) bit = (g.bitmap[((size_t)b * g.Cmax + r) * g.Wmax + (c >> 6)] >> (c & 63)) & 1ull;
+        double w = 0.0;
+        if (bit) {
+            Corr o;
+            load_corr(kp, g, b, topK, keff, r, o);
+            RpPairEval ev = rp_pair_eval(o.ps, o.ns, o.pt, o.nt, me.ps, me.ns, me.pt, me.nt, kc);
+            w = rp_pair_weight(ev, o.f, me.f, o.ws, me.ws, o.wt, me.wt, kc);
+        }
+        const unsigned long long m = __ballot(bit);
+        if (bit) {
+            const int pos = run + __popcll(m & lt);
+            g.col[eoff + pos] = r;
+            g.wv[eoff + pos] = w;
+        }
+        run += __popcll(m);
+        nz += __popcll(__ballot(bit && w != 0.0));
+    }
+    // upper part: pairs (c, c2), c2 > c
+    const int nch = (C + 63) >> 6;
+    for (int ch = c >> 6; ch < nch; ++ch) {
+        const int c2 = ch * 64 + lane;
+        const unsigned long long word = g.bitmap[((size_t)b * g.Cmax + c) * g.Wmax + ch];
+        const bool bit = (word >> lane) & 1ull;
+        double w = 0.0;
+        if (bit) {
+            Corr o;
+            load_corr(kp, g, b, topK, keff, c2, o);
+            RpPairEval ev = rp_pair_eval(me.ps, me.ns, me.pt, me.nt, o.ps, o.ns, o.pt, o.nt, kc);
+            w = rp_pair_weight(ev, me.f, o.f, me.ws, o.ws, me.wt, o.wt, kc);
+        }
+        if (bit) {
+            const int pos = run + __popcll(word & lt);
+            g.col[eoff + pos] = c2;
+            g.wv[eoff + pos] = w;
+        }
+        run += __popcll(word);
+        nz += __popcll(__ballot(bit && w != 0.0));
+    }
+    if (lane == 0 && nz) atomicAdd(&g.counters[b * 4 + 2], nz);
+}
+
+// ------------------------------------------------------------------ fit
+struct FitCtx {
+    const double *pc_s, *pc_t, *normal_s, *normal_t;
+    const int32_t* corres_j;
+    int ns_max, nt_max;
+    int b, C, keff, topK;
+    double mu;
+    double* deg; double* gP; double* gN; double* rsum;
+    double* red;        // LDS reduction scratch
+};
+
+__device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, double* tp, double* sn, double* tn) {
+    int i = c / f.keff, kk = c - i * f.keff;
+    size_t si = (size_t)f.b * f.ns_max + i;
+    int j = f.corres_j[si * f.topK + kk];
+    size_t ti = (size_t)f.b * f.nt_max + j;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        sp[a] = f.pc_s[si * 3 + a]; sn[a] = f.normal_s[si * 3 + a];
+        tp[a] = f.pc_t[ti * 3 + a]; tn[a] = f.normal_t[ti * 3 + a];
+    }
+}
+
+// centre with position weights, Horn, residuals; optionally IRLS-reweight (rpmodule.py:236-255).
+__device__ void fit_solve(const FitCtx& f, bool reweight, double R[3][3], double t[3]) {
+    double s7[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
+        double sp[3], tp[3], sn[3], tn[3];
+        corr_geom(f, c, sp, tp, sn, tn);
+        const double wp = f.mu * f.deg[c] * f.gP[c];
+        s7[0] += wp;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s7[1 + a] += wp * sp[a]; s7[4 + a] += wp * tp[a]; }
+    }
+    rp_block_sum<7>(s7, f.red);
+    const double den = s7[0] + RP_EPS;
+    double ms[3], mt[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ms[a] = s7[1 + a] / den; mt[a] = s7[4 + a] / den; }
+    double m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
+        double sp[3], tp[3], sn[3], tn[3];
+        corr_geom(f, c, sp, tp, sn, tn);
+        const double d = f.deg[c];
+        const double wp = f.mu * d * f.gP[c], wn = d * f.gN[c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb)
+                m9[a * 3 + bb] += (sp[a] - ms[a]) * ((tp[bb] - mt[bb]) * wp) + sn[a] * (tn[bb] * wn);
+    }
+    rp_block_sum<9>(m9, f.red);
+    double M[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) M[a][bb] = m9[a * 3 + bb];
+    rp_horn_rotation(M, R);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t[a] = -((R[a][0] * ms[0] + R[a][1] * ms[1]) + R[a][2] * ms[2]) + mt[a];
+    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
+        double sp[3], tp[3], sn[3], tn[3];
+        corr_geom(f, c, sp, tp, sn, tn);
+        double rP = 0.0, rN = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double x0 = sp[0] - ms[0], x1 = sp[1] - ms[1], x2 = sp[2] - ms[2];
+            const double ep = ((R[a][0] * x0 + R[a][1] * x1) + R[a][2] * x2) - (tp[a] - mt[a]);
+            const double en = ((R[a][0] * sn[0] + R[a][1] * sn[1]) + R[a][2] * sn[2]) - tn[a];
+            rP += ep * ep; rN += en * en;
+        }
+        rP *= f.mu;
+        f.rsum[c] = rP + rN;
+        if (reweight) { f.gP[c] = f.gP[c] / (1.0 + rP); f.gN[c] = f.gN[c] / (1.0 + rN); }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void write_pose(double* out, const double R[3][3], const double t[3]) {
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; ++a) { out[a * 4 + 0] = R[a][0]; out[a * 4 + 1] = R[a][1]; out[a * 4 + 2] = R[a][2]; out[a * 4 + 3] = t[a]; }
+        out[12] = 0; out[13] = 0; out[14] = 0; out[15] = 1;
+    }
+}
+
+__global__ __launch_bounds__(RP_FIT_THREADS) void fit_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK, int method,
+                                                              int32_t* __restrict__ status, double* __restrict__ pose,
+                                                              double* __restrict__ trace, int32_t* __restrict__ eig_iters,
+                                                              int32_t* __restrict__ counts_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    const int C = pair_C(kp, g, b);
+    double* u = (double*)smem;            // [Cmax]
+    double* y = u + g.Cmax;               // [Cmax]
+    double* h = y + g.Cmax;               // [Cmax]
+    double* red = h + g.Cmax;             // [9*16 + 16]
+    __shared__ int flag_s;
+    int st = status[b];
+    if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
+    if (threadIdx.x == 0) {
+        status[b] = st;
+        if (counts_out) {
+            counts_out[b * 4 + 0] = g.counters[b * 4 + 0];
+            counts_out[b * 4 + 1] = g.counters[b * 4 + 1];
+            counts_out[b * 4 + 2] = g.counters[b * 4 + 2] / 2;
+            counts_out[b * 4 + 3] = (kp.ns[b] >= 3 && kp.nt[b] >= 3) ? g.keff[b] : 0;
+        }
+    }
+    double* P = pose + (size_t)b * 16;
+    if (st != RELPOSE_OK) {
+        if (threadIdx.x < 16) P[threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;
+        if (trace) for (int q = threadIdx.x; q < 96; q += blockDim.x) trace[(size_t)b * 96 + q] = ((q % 16) % 5 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    FitCtx f;
+    f.pc_s = kp.pc_s; f.pc_t = kp.pc_t; f.normal_s = kp.normal_s; f.normal_t = kp.normal_t;
+    f.corres_j = g.corres_j; f.ns_max = kp.ns_max; f.nt_max = kp.nt_max; f.b = b; f.C = C; f.keff = g.keff[b]; f.topK = topK; f.mu = kc.mu;
+    f.deg = g.state + ((size_t)b * 4 + 0) * g.Cmax; f.gP = g.state + ((size_t)b * 4 + 1) * g.Cmax;
+    f.gN = g.state + ((size_t)b * 4 + 2) * g.Cmax; f.rsum = g.state + ((size_t)b * 4 + 3) * g.Cmax;
+    f.red = red;
+    const size_t eoff = (size_t)b * g.max_edges;
+    const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
+    const int32_t* col = g.col + eoff;
+    const double* wv = g.wv + eoff;
+    double* xe = g.xe + eoff;
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, ngrp = blockDim.x >> 4;
+
+    // weighted degree with the raw pair weights (allWP = [w, w], rpmodule.py:488)
+    for (int c = grp; c < C; c += ngrp) {
+        double s = 0.0;
+        for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) s += wv[k];
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
+        if (gl == 0) f.deg[c] = s;
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { f.gP[c] = 1.0; f.gN[c] = 1.0; }
+    __syncthreads();
+
+    double R[3][3], t[3];
+    const int n_irls = (method == RELPOSE_FIT_HORN87 || method == RELPOSE_FIT_SPECTRAL) ? 1 : 5;
+    for (int it = 0; it < n_irls; ++it) fit_solve(f, n_irls > 1, R, t);
+    if (trace) write_pose(trace + (size_t)b * 96, R, t);
+
+    if (method == RELPOSE_FIT_IRLS_SM || method == RELPOSE_FIT_SPECTRAL) {
+        for (int round = 0; round < 5; ++round) {
+            // a = base * relu(50 - r), summed over the two halves (rpmodule.py:262-267): base*(h[c1]+h[c2])
+            for (int c = threadIdx.x; c < C; c += blockDim.x) {
+                double v = RP_OFFSET - f.rsum[c];
+                h[c] = v < 0.0 ? 0.0 : v;
+                u[c] = 1.0 / sqrt((double)C);
+            }
+            __syncthreads();
+            const bool use_xe = (method == RELPOSE_FIT_SPECTRAL) && round > 0;
+            int iters = 0;
+            for (; iters < 300; ++iters) {
+                for (int c = grp; c < C; c += ngrp) {
+                    double s = 0.0;
+                    const double hc = h[c];
+                    for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) {
+                        const int cc = col[k];
+                        const double base = use_xe ? f.mu * xe[k] : wv[k];
+                        s += (base * (hc + h[cc])) * u[cc];
+                    }
+#pragma unroll
+                    for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
+                    if (gl == 0) y[c] = s;
+                }
+                __syncthreads();
+                double n2[1] = {0.0};
+                for (int c = threadIdx.x; c < C; c += blockDim.x) n2[0] += y[c] * y[c];
+                rp_block_sum<1>(n2, red);
+                const double nrm = sqrt(n2[0]);
+                if (!(nrm > 0.0)) break;                 // zero matrix: keep the uniform vector
+                int moved = 0;
+                for (int c = threadIdx.x; c < C; c += blockDim.x) {
+                    const double un = y[c] / nrm;
+                    if (fabs(un - u[c]) > 1e-15) moved = 1;
+                    u[c] = un;
+                }
+                if (threadIdx.x == 0) flag_s = 0;
+                __syncthreads();
+                if (moved) flag_s = 1;
+                __syncthreads();
+                const int any = flag_s;
+                __syncthreads();
+                if (!any) { ++iters; break; }
+            }
+            if (eig_iters && threadIdx.x == 0) eig_iters[b * 5 + round] = iters;
+            // x = relu(u[c1]*u[c2]) * w  (rpmodule.py:277-280); new degrees
+            for (int c = grp; c < C; c += ngrp) {
+                double s = 0.0;
+                const double uc = u[c];
+                for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) {
+                    double x = uc * u[col[k]];
+                    x = (x < 0.0 ? 0.0 : x) * wv[k];
+                    xe[k] = x;
+                    s += x;
+                }
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
+                if (gl == 0) f.deg[c] = s;
+            }
+            for (int c = threadIdx.x; c < C; c += blockDim.x) { f.gP[c] = 1.0; f.gN[c] = 1.0; }
+            __syncthreads();
+            const int n_in = (method == RELPOSE_FIT_SPECTRAL) ? 1 : 5;
+            for (int it = 0; it < n_in; ++it) fit_solve(f, n_in > 1, R, t);
+            if (trace) write_pose(trace + (size_t)b * 96 + (round + 1) * 16, R, t);
+        }
+    } else if (trace) {
+        for (int q = 1; q < 6; ++q) write_pose(trace + (size_t)b * 96 + q * 16, R, t);
+    }
+    write_pose(P, R, t);
+}
+
+RpPairConsts make_consts(const RelposeParams& p) {
+    RpPairConsts k;
+    k.dist_thre2 = p.distThre * p.distThre;
+    k.sep_thre = 1.5 * (p.distSepThre * p.distSepThre);
+    k.angle_thre2 = p.angleThre * p.angleThre;
+    k.two_sd2 = 2 * (p.sigmaDist * p.sigmaDist);
+    k.two_sa1_2 = 2 * (p.sigmaAngle1 * p.sigmaAngle1);
+    k.two_sa2_2 = 2 * (p.sigmaAngle2 * p.sigmaAngle2);
+    double s1 = (p.sigmaFeat / 1.2) / 5, s0 = p.sigmaFeat / 5;
+    k.den_both = 2 * (s1 * s1);
+    k.den_other = 2 * (s0 * s0);
+    k.mu = p.mu;
+    return k;
+}
+
+bool kp_ok(const RelposeKeypoints* kp, const RelposeParams* p) {
+    return kp && p && kp->B > 0 && kp->ns_max > 0 && kp->nt_max > 0 && kp->nt_max <= 4096 && p->topK >= 1 && p->topK <= RP_MAXK &&
+           kp->ns && kp->nt && kp->pc_s && kp->pc_t && kp->normal_s && kp->normal_t && kp->feat_s && kp->feat_t &&
+           kp->weight_s && kp->weight_t;
+}
+
+int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
+    const int ntp = (kp.nt_max + 63) & ~63;
+    const size_t lds = (size_t)ntp * 8 + (size_t)RP_FEAT * (ntp + 1) * 4;
+    if (lds > 160 * 1024) return RELPOSE_EINVAL;
+    const int rows = 8;
+    dim3 grid((kp.ns_max + rows - 1) / rows, kp.B);
+    RpPairConsts kc = make_consts(p);
+    if (wij) {
+        RP_HIP(hipFuncSetAttribute((const void*)affinity_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(affinity_topk_kernel<true>, grid, dim3(256), lds, s, kp, kc, p.topK, rows, wij, cj, cw, keff);
+    } else {
+        RP_HIP(hipFuncSetAttribute((const void*)affinity_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(affinity_topk_kernel<false>, grid, dim3(256), lds, s, kp, kc, p.topK, rows, wij, cj, cw, keff);
+    }
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+struct WsLayout {
+    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, total;
+    int32_t Cmax, Wmax;
+    int64_t max_edges;
+};
+
+WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
+    WsLayout L;
+    L.Cmax = ns_max * topK;
+    L.Wmax = (L.Cmax + 63) / 64;
+    const int64_t worst = (int64_t)L.Cmax * (L.Cmax - 1);
+    L.max_edges = (max_edges <= 0 || max_edges > worst) ? worst : max_edges;
+    if (L.max_edges < 16) L.max_edges = 16;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += rp_align(bytes); return r; };
+    L.corres_j = take((size_t)B * ns_max * topK * 4);
+    L.corres_w = take((size_t)B * ns_max * topK * 8);
+    L.keff = take((size_t)B * 4);
+    L.bitmap = take((size_t)B * L.Cmax * L.Wmax * 8);
+    L.upcnt = take((size_t)B * L.Cmax * 4);
+    L.lowcnt = take((size_t)B * L.Cmax * 4);      // lowcnt and counters are contiguous: one memset
+    L.counters = take((size_t)B * 4 * 4);
+    L.rowptr = take((size_t)B * (L.Cmax + 1) * 4);
+    L.col = take((size_t)B * L.max_edges * 4);
+    L.wv = take((size_t)B * L.max_edges * 8);
+    L.xe = take((size_t)B * L.max_edges * 8);
+    L.state = take((size_t)B * 4 * L.Cmax * 8);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+void relpose_default_params(RelposeParams* p) {
+    p->distThre = 0.08; p->distSepThre = 1.5 * 0.08; p->angleThre = 45 / 180. * M_PI;
+    p->sigmaAngle1 = 0.523 / 2; p->sigmaAngle2 = 0.523 / 2; p->sigmaDist = 0.08 / 2; p->sigmaFeat = 0.01;
+    p->mu = 0.3; p->topK = 5; p->method = RELPOSE_FIT_IRLS_SM;
+}
+
+const char* relpose_version(void) { return "relpose-hip 0.1 (gfx950)"; }
+
+size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, int32_t topK, int64_t max_edges) {
+    (void)nt_max;
+    if (B <= 0 || ns_max <= 0 || topK < 1 || topK > RP_MAXK) return 0;
+    return ws_layout(B, ns_max, topK, max_edges).total;
+}
+
+int relpose_affinity_topk(const RelposeParams* p, const RelposeKeypoints* kp, float* wij, int32_t* corres_j, double* corres_w,
+                          int32_t* k_eff, void* stream) {
+    if (!kp_ok(kp, p) || !corres_j || !corres_w || !k_eff) return RELPOSE_EINVAL;
+    return launch_affinity(*p, *kp, wij, corres_j, corres_w, k_eff, (hipStream_t)stream);
+}
+
+int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void* workspace, size_t workspace_bytes, int64_t max_edges,
+                        double* pose, int32_t* status, const RelposeMatchDebug* dbg, void* stream) {
+    if (!kp_ok(kp, p) || !workspace || !pose || !status) return RELPOSE_EINVAL;
+    if (p->method < 0 || p->method > 3) return RELPOSE_EINVAL;
+    const WsLayout L = ws_layout(kp->B, kp->ns_max, p->topK, max_edges);
+    if (workspace_bytes < L.total) return RELPOSE_ENOMEM;
+    if ((size_t)L.Cmax * 24 + (9 * 16 + 16) * 8 > 150 * 1024) return RELPOSE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    int32_t* cj = (int32_t*)(ws + L.corres_j);
+    double* cw = (double*)(ws + L.corres_w);
+    int32_t* keff = (int32_t*)(ws + L.keff);
+    Graph g;
+    g.Cmax = L.Cmax; g.Wmax = L.Wmax; g.max_edges = L.max_edges;
+    g.corres_j = cj; g.corres_w = cw; g.keff = keff;
+    g.bitmap = (unsigned long long*)(ws + L.bitmap);
+    g.upcnt = (int32_t*)(ws + L.upcnt); g.lowcnt = (int32_t*)(ws + L.lowcnt); g.counters = (int32_t*)(ws + L.counters);
+    g.rowptr = (int32_t*)(ws + L.rowptr); g.col = (int32_t*)(ws + L.col);
+    g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state);
+    RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
+    int rc = launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
+    if (rc) return rc;
+    const RpPairConsts kc = make_consts(*p);
+    dim3 grid_rows((L.Cmax + 3) / 4, kp->B);
+    hipLaunchKernelGGL(pair_flags_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK);
+    RP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(kp->B), dim3(1024), 0, s, *kp, g, status);
+    RP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_fill_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK, status);
+    RP_CHECK_LAUNCH();
+    const size_t lds = (size_t)L.Cmax * 24 + (9 * 16 + 16) * 8;
+    RP_HIP(hipFuncSetAttribute((const void*)fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fit_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), lds, s, *kp, g, kc, p->topK, p->method, status, pose,
+                       dbg ? dbg->trace : nullptr, dbg ? dbg->eig_iters : nullptr, dbg ? dbg->counts : nullptr);
+    RP_CHECK_LAUNCH();
+    if (dbg && dbg->corres_j)
+        RP_HIP(hipMemcpyAsync(dbg->corres_j, cj, (size_t)kp->B * kp->ns_max * p->topK * 4, hipMemcpyDeviceToDevice, s));
+    if (dbg && dbg->corres_w)
+        RP_HIP(hipMemcpyAsync(dbg->corres_w, cw, (size_t)kp->B * kp->ns_max * p->topK * 8, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+}  // extern "C"

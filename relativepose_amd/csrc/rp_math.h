@@ -1,0 +1,144 @@
+// Scalar double-precision math shared by the matcher kernels.  Everything here is
+// __host__ __device__ so tests/test_host_math.py can compile it with g++ and check
+// it against the numpy oracle on a box without a GPU.
+//
+// Operation order follows the numpy expressions of the reference
+// (RPModule/rpmodule.py:399-467 pair tests and weights, :17-58 Horn) so that
+// thresholded decisions agree with the float64 reference; this file is compiled
+// with -ffp-contract=off (no FMA fusion).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define RP_HD __host__ __device__ __forceinline__
+#else
+#define RP_HD inline
+#endif
+
+struct RpPairConsts {       // derived on the host in double, exactly as numpy does
+    double dist_thre2;      // np.power(distThre, 2)
+    double sep_thre;        // 1.5 * np.power(distSepThre, 2)   (sic: a distance vs a squared threshold)
+    double angle_thre2;     // np.power(angleThre, 2)
+    double two_sd2;         // 2 * sigmaDist**2
+    double two_sa1_2;       // 2 * sigmaAngle1**2
+    double two_sa2_2;       // 2 * sigmaAngle2**2
+    double den_both;        // 2 * np.power((sigmaFeat/1.2)/5, 2)   both keypoints observed
+    double den_other;       // 2 * np.power(sigmaFeat/5, 2)
+    double mu;
+};
+
+RP_HD double rp_norm3(double x, double y, double z) { return sqrt((x * x + y * y) + z * z); }
+RP_HD double rp_dot3(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+RP_HD double rp_clip1(double v) { return v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v); }   // NaN stays NaN
+
+struct RpPairEval { double d, alpha, beta, gamma; int pass_dist, pass_all; };
+
+// One correspondence pair: "1" = (ps1,ns1 -> pt1,nt1), "2" = (ps2,ns2 -> pt2,nt2).
+// rpmodule.py:399-404 (distance test) and :424-436 (angle test).
+RP_HD RpPairEval rp_pair_eval(const double* ps1, const double* ns1, const double* pt1, const double* nt1,
+                              const double* ps2, const double* ns2, const double* pt2, const double* nt2,
+                              const RpPairConsts& k) {
+    RpPairEval r;
+    double es[3] = {ps1[0] - ps2[0], ps1[1] - ps2[1], ps1[2] - ps2[2]};
+    double et[3] = {pt1[0] - pt2[0], pt1[1] - pt2[1], pt1[2] - pt2[2]};
+    double dis_s = rp_norm3(es[0], es[1], es[2]);
+    double dis_t = rp_norm3(et[0], et[1], et[2]);
+    double dd = dis_s - dis_t;
+    r.d = dd * dd;
+    double mn = dis_s < dis_t ? dis_s : dis_t;     // np.minimum (NaN-propagation irrelevant: compare below is false)
+    r.pass_dist = (r.d < k.dist_thre2) && (mn > k.sep_thre);
+    r.alpha = r.beta = r.gamma = 0.0;
+    r.pass_all = 0;
+    if (!r.pass_dist) return r;
+    for (int a = 0; a < 3; ++a) { es[a] = es[a] / dis_s; et[a] = et[a] / dis_t; }
+    double a0 = acos(rp_clip1(rp_dot3(ns1, ns2))) - acos(rp_clip1(rp_dot3(nt1, nt2)));
+    double b0 = acos(rp_clip1(rp_dot3(ns1, es))) - acos(rp_clip1(rp_dot3(nt1, et)));
+    double g0 = acos(rp_clip1(rp_dot3(ns2, es))) - acos(rp_clip1(rp_dot3(nt2, et)));
+    r.alpha = a0 * a0; r.beta = b0 * b0; r.gamma = g0 * g0;
+    r.pass_all = (r.alpha < k.angle_thre2) && (r.beta < k.angle_thre2) && (r.gamma < k.angle_thre2);
+    return r;
+}
+
+// rpmodule.py:457-467: f1*f2*exp(-d/2sd^2 - a/2sa1^2 - b/2sa2^2 - g/2sa2^2), x0.6 unless all four observed.
+RP_HD double rp_pair_weight(const RpPairEval& e, double f1, double f2, double ws1, double ws2, double wt1, double wt2,
+                            const RpPairConsts& k) {
+    double ex = exp(((-e.d / k.two_sd2 - e.alpha / k.two_sa1_2) - e.beta / k.two_sa2_2) - e.gamma / k.two_sa2_2);
+    double w = (f1 * f2) * ex;
+    double ww = ((ws1 * ws2) * wt1) * wt2;
+    if (ww != 1.0) w *= 0.6;
+    return w;
+}
+
+// Leading eigenvector of a symmetric 4x4 (cyclic Jacobi), the quaternion of Horn's
+// method (rpmodule.py:46-53 uses np.linalg.eig + argmax).  N is destroyed.
+RP_HD void rp_sym4_max_eigvec(double N[4][4], double q[4]) {
+    double V[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 32; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += N[i][j] * N[i][j];
+        double diag = 0.0;
+        for (int i = 0; i < 4; ++i) diag += N[i][i] * N[i][i];
+        if (off <= 1e-60 || off <= 1e-34 * diag) break;
+        for (int p = 0; p < 3; ++p) for (int qq = p + 1; qq < 4; ++qq) {
+            double apq = N[p][qq];
+            if (apq == 0.0) continue;
+            double theta = (N[qq][qq] - N[p][p]) / (2.0 * apq);
+            double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 4; ++k) {           // columns p,q of N
+                double nkp = N[k][p], nkq = N[k][qq];
+                N[k][p] = c * nkp - s * nkq; N[k][qq] = s * nkp + c * nkq;
+            }
+            for (int k = 0; k < 4; ++k) {           // rows p,q of N
+                double npk = N[p][k], nqk = N[qq][k];
+                N[p][k] = c * npk - s * nqk; N[qq][k] = s * npk + c * nqk;
+            }
+            for (int k = 0; k < 4; ++k) {
+                double vkp = V[k][p], vkq = V[k][qq];
+                V[k][p] = c * vkp - s * vkq; V[k][qq] = s * vkp + c * vkq;
+            }
+        }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i) if (N[i][i] > N[best][best]) best = i;
+    double nrm = 0.0;
+    for (int i = 0; i < 4; ++i) nrm += V[i][best] * V[i][best];
+    nrm = sqrt(nrm);
+    for (int i = 0; i < 4; ++i) q[i] = V[i][best] / nrm;
+}
+
+// Horn '87: rotation from the 3x3 weighted covariance M = sum_k w_k s_k t_k^T (rpmodule.py:43-56).
+RP_HD void rp_horn_rotation(const double M[3][3], double R[3][3]) {
+    double N[4][4] = {
+        {M[0][0] + M[1][1] + M[2][2], M[1][2] - M[2][1], M[2][0] - M[0][2], M[0][1] - M[1][0]},
+        {M[1][2] - M[2][1], M[0][0] - M[1][1] - M[2][2], M[0][1] + M[1][0], M[0][2] + M[2][0]},
+        {M[2][0] - M[0][2], M[0][1] + M[1][0], M[1][1] - M[0][0] - M[2][2], M[1][2] + M[2][1]},
+        {M[0][1] - M[1][0], M[2][0] + M[0][2], M[1][2] + M[2][1], M[2][2] - M[0][0] - M[1][1]}};
+    double q[4];
+    rp_sym4_max_eigvec(N, q);
+    double a = q[0], b = q[1], c = q[2], d = q[3];
+    R[0][0] = a * a + b * b - c * c - d * d; R[0][1] = 2 * (b * c - a * d); R[0][2] = 2 * (b * d + a * c);
+    R[1][0] = 2 * (c * b + a * d); R[1][1] = a * a - b * b + c * c - d * d; R[1][2] = 2 * (c * d - a * b);
+    R[2][0] = 2 * (d * b - a * c); R[2][1] = 2 * (d * c + a * b); R[2][2] = a * a - b * b - c * c + d * d;
+}
+
+// General 4x4 inverse by Gauss-Jordan with partial pivoting (np.linalg.inv, evaluation.py:235).
+RP_HD bool rp_inv4(const double* A, double* out) {
+    double m[4][8];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { m[i][j] = A[i * 4 + j]; m[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(m[r][c]) > fabs(m[piv][c])) piv = r;
+        if (m[piv][c] == 0.0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) { double t = m[c][j]; m[c][j] = m[piv][j]; m[piv][j] = t; }
+        double inv = 1.0 / m[c][c];
+        for (int j = 0; j < 8; ++j) m[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) if (r != c) {
+            double f = m[r][c];
+            if (f != 0.0) for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = m[i][4 + j];
+    return true;
+}

@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference's panorama geometry (util.py), backed by
+the HIP library.  The *_dev functions take/return CUDA tensors (batched, no host
+round trip); the reference-named wrappers keep the reference's numpy signatures.
+
+  apply_mask       util.py:209      warping          util.py:94
+  Pano2PointCloud  util.py:751      build_view       evaluation.py:217-230
+  sample_primitives  evaluation.py:246-253 + rpmodule.getMatchingPrimitive :526-532
+"""
+import numpy as np
+
+from . import _lib
+
+DATASETS = {"suncg": 0, "matterport": 1, "scannet": 2}
+MASKS = {"second": 0, "kinect": 1}
+
+
+def dataset_id(name):
+    for k, v in DATASETS.items():
+        if k in name:
+            return v
+    raise ValueError(f"unknown dataset {name}")
+
+
+def build_view_dev(rgb, norm, depth, mask_method):
+    """rgb/norm [n,3,h,4h], depth [n,h,4h] f32 CUDA -> view [n,8,h,4h]."""
+    import torch
+    _lib.require_gpu()
+    n, _, h, w = rgb.shape
+    assert w == 4 * h
+    view = torch.empty(n, 8, h, w, dtype=torch.float32, device=rgb.device)
+    rc = _lib.lib().relpose_build_view(_lib.ptr(rgb.contiguous()), _lib.ptr(norm.contiguous()), _lib.ptr(depth.contiguous()),
+                                       _lib.ptr(view), n, h, MASKS[mask_method], _lib.stream_ptr())
+    _lib.check(rc, "relpose_build_view")
+    return view
+
+
+def apply_mask_dev(x, mask_method):
+    import torch
+    _lib.require_gpu()
+    n, c, h, w = x.shape
+    assert w == 4 * h and x.is_contiguous() and x.dtype == torch.float32
+    mask = torch.empty(n, 1, h, w, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().relpose_apply_mask(_lib.ptr(x), _lib.ptr(mask), n, c, h, MASKS[mask_method], _lib.stream_ptr())
+    _lib.check(rc, "relpose_apply_mask")
+    return x, mask
+
+
+_warp_ws = {}
+
+
+def warping_dev(view, pose, dataset, out=None):
+    """view [n,8,h,4h] f32, pose [n,4,4] f64 (CUDA) -> warped view [n,8,h,4h] f32."""
+    import torch
+    _lib.require_gpu()
+    n, c, h, w = view.shape
+    assert c == 8 and w == 4 * h and view.is_contiguous() and pose.is_contiguous() and pose.dtype == torch.float64
+    L = _lib.lib()
+    nbytes = L.relpose_warp_workspace_bytes(n, h)
+    key = view.device.index
+    ws = _warp_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=view.device)
+        _warp_ws[key] = ws
+    if out is None:
+        out = torch.empty_like(view)
+    rc = L.relpose_warp(_lib.ptr(view), _lib.ptr(pose), _lib.ptr(out), _lib.ptr(ws), n, h, dataset_id(dataset), _lib.stream_ptr())
+    _lib.check(rc, "relpose_warp")
+    return out
+
+
+def pose_inverse_dev(pose):
+    import torch
+    out = torch.empty_like(pose)
+    rc = _lib.lib().relpose_pose_inverse(_lib.ptr(pose), _lib.ptr(out), pose.shape[0], _lib.stream_ptr())
+    _lib.check(rc, "relpose_pose_inverse")
+    return out
+
+
+def pano2pc_dev(depth, dataset):
+    """depth [n,h,4h] f32 -> (pc [n,3,4hh] f64, valid [n,4hh] uint8)."""
+    import torch
+    _lib.require_gpu()
+    n, h, w = depth.shape
+    pc = torch.empty(n, 3, h * w, dtype=torch.float64, device=depth.device)
+    valid = torch.empty(n, h * w, dtype=torch.uint8, device=depth.device)
+    rc = _lib.lib().relpose_pano2pc(_lib.ptr(depth.contiguous()), _lib.ptr(pc), _lib.ptr(valid), n, h, dataset_id(dataset),
+                                    _lib.stream_ptr())
+    _lib.check(rc, "relpose_pano2pc")
+    return pc, valid
+
+
+def sample_primitives_dev(f, feat_off, obs_norm, obs_depth, pts, npts, mask_method, dataset):
+    """f [n,cf,h,4h] net output, obs_norm [n,3,h,4h], obs_depth [n,h,4h] f32, pts [n,N,2] f64, npts [n] i32
+    -> pc [n,N,3] f64, normal [n,N,3] f64, feat [n,N,32] f32."""
+    import torch
+    _lib.require_gpu()
+    n, cf, h, w = f.shape
+    N = pts.shape[1]
+    dev = f.device
+    pc = torch.zeros(n, N, 3, dtype=torch.float64, device=dev)
+    nn = torch.zeros(n, N, 3, dtype=torch.float64, device=dev)
+    ft = torch.zeros(n, N, 32, dtype=torch.float32, device=dev)
+    for t in (f, obs_norm, obs_depth, pts, npts):
+        assert t.is_contiguous() and t.is_cuda
+    rc = _lib.lib().relpose_sample_primitives(_lib.ptr(f), cf, feat_off, _lib.ptr(obs_norm), _lib.ptr(obs_depth), _lib.ptr(pts),
+                                              _lib.ptr(npts), N, _lib.ptr(pc), _lib.ptr(nn), _lib.ptr(ft), n, h,
+                                              MASKS[mask_method], dataset_id(dataset), _lib.stream_ptr())
+    _lib.check(rc, "relpose_sample_primitives")
+    return pc, nn, ft
+
+
+# ---- reference-named numpy wrappers -------------------------------------------------------------
+
+def apply_mask(x, maskMethod, *arg):
+    """util.py:209: x torch tensor [n,c,h,w] -> (x*mask, mask, geow).  geow (a training-only
+    geometric weight) is not computed on the inference path and is returned as None."""
+    import torch
+    dev = _lib.require_gpu()
+    xd = x.to(dev, torch.float32).contiguous().clone()
+    xd, m = apply_mask_dev(xd, maskMethod)
+    return xd, m, None
+
+
+def warping(view, R, dataList):
+    """util.py:94: view numpy [1,8,h,4h], R [4,4] -> numpy [1,8,h,4h] (float32 values; zeros for identity)."""
+    import torch
+    dev = _lib.require_gpu()
+    v = torch.from_numpy(np.ascontiguousarray(view, dtype=np.float32)).to(dev)
+    T = torch.from_numpy(np.ascontiguousarray(R, dtype=np.float64)[None]).to(dev)
+    return warping_dev(v, T, dataList).cpu().numpy()
+
+
+def Pano2PointCloud(depth, dataList):
+    """util.py:751: depth numpy [h,4h] -> [3,n] float64 (scannet: zero-depth points dropped)."""
+    import torch
+    dev = _lib.require_gpu()
+    d = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32)[None]).to(dev)
+    pc, valid = pano2pc_dev(d, dataList)
+    pc, valid = pc[0].cpu().numpy(), valid[0].cpu().numpy().astype(bool)
+    return pc[:, valid]
