@@ -1,13 +1,782 @@
-// placeholder until the conv stack lands (next commit): entry points exist so the library links.
+// SCNet (completion + feature encoder-decoder) on gfx950.
+// Replaces the reference module model/mymodel.py:141-380 (skipLayer=1, batchnorm=1, 'rgbdnsf').
+//
+// Design (DESIGN.md "SCNet"):
+//  * activations live in HBM as NHWC float32, RAW conv outputs (pre-BatchNorm); every buffer has a
+//    companion per-(group,channel) {scale,shift} table produced by a two-stage float64 statistics
+//    pass (BatchNorm uses batch statistics over each group of 2 images, mymodel.py:19,32);
+//  * one implicit-GEMM kernel for every conv / transposed conv / 1x1 head: M = output pixels,
+//    N = Cout, K = taps x Cin.  The A-tile loader gathers the im2col slice from up to two NHWC
+//    sources (skip concatenations are never materialised), applies scale/shift + LeakyReLU(0.1)
+//    on the fly and zero-pads; B = weights pre-packed [Cout][K].  Tiles are staged through LDS
+//    (row stride 20 floats: conflict-free ds_read_b128) and contracted with
+//    v_mfma_f32_32x32x2_f32 (exact fp32, 64 lanes);
+//  * stride-2 transposed convs are decomposed into their sub-pixel phases (4 launches of a 2x2-tap
+//    conv) so no multiply-by-zero work is issued; shared-weight encoder streams (self / warped
+//    view) are channel blocks of one concatenated buffer;
+//  * bilinear resize kernels (align_corners=False) in and out.
 #include "common.h"
-extern "C" {
-RelposeSCNet* relpose_scnet_create(int32_t, int32_t) { return nullptr; }
-void relpose_scnet_destroy(RelposeSCNet*) {}
-int relpose_scnet_set_param(RelposeSCNet*, const char*, const float*, size_t) { return RELPOSE_EINVAL; }
-int relpose_scnet_finalize(RelposeSCNet*) { return RELPOSE_EINVAL; }
-int64_t relpose_scnet_num_params(const RelposeSCNet*) { return 0; }
-size_t relpose_scnet_workspace_bytes(const RelposeSCNet*, int32_t, int32_t, int32_t) { return 0; }
-int relpose_scnet_forward(RelposeSCNet*, const float*, float*, int32_t, int32_t, int32_t, void*, size_t, void*) { return RELPOSE_EINVAL; }
-int64_t relpose_scnet_read_tap(RelposeSCNet*, const char*, float*, void*, void*) { return -1; }
-int relpose_scnet_profile(RelposeSCNet*, const float*, float*, int32_t, int32_t, int32_t, void*, size_t, int32_t, double*, double*, int64_t*, void*) { return RELPOSE_EINVAL; }
+#include <map>
+#include <string>
+#include <vector>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;          // K-tile (floats)
+constexpr int LDK = 20;         // LDS row stride in floats (80 B: 16-B aligned, conflict-free b128 reads)
+constexpr float LRELU = 0.1f;
+constexpr double BN_EPS = 1e-5;
+constexpr int RS = 224;         // internal resolution (mymodel.py:261)
+
+struct Src {
+    const float* x;        // NHWC base (+ channel offset)
+    const float2* ss;      // [G][sstride] {scale, shift} (+ channel offset) or nullptr = identity
+    int cstride;           // floats per pixel
+    int C;                 // channels read from this source
+    int sstride;           // float2 per group
+};
+
+struct ConvDesc {
+    Src src[2];
+    int nsrc, Cin;
+    int Nimg, Hin, Win;
+    int Hp, Wp, sy, sx;    // output grid of this launch and input step
+    int ntaps;
+    signed char offy[16], offx[16];
+    const float* w;        // [CoutPad][ntaps*Cin]
+    int Cout;
+    float* y;              // NHWC output
+    int Hout, Wout, ycstride, ychoff, osy, osx, py, px;
+    const float* bias;     // heads only
+    int tanh_out;
+    int M, K;
+};
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU * v; }
+
+// Tile: WM x WN waves (WM*WN = 4), each wave MI x NI MFMA 32x32 blocks.
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDesc d) {
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    constexpr int A_IT = BM / 64;                       // float4 slots per thread for the A tile
+    constexpr int B_IT = (BN * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    __shared__ int rowpix[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int hw = d.Hp * d.Wp;
+
+    // loader rows of this thread
+    const int kq = tid & 3;
+    int r_img[A_IT], r_y[A_IT], r_x[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = m0 + (tid >> 2) + it * 64;
+        if (m < d.M) {
+            const int img = m / hw, rem = m - img * hw;
+            const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
+            r_img[it] = img; r_y[it] = yp * d.sy; r_x[it] = xp * d.sx;
+        } else { r_img[it] = -1; r_y[it] = 0; r_x[it] = 0; }
+    }
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1;
+        if (m < d.M) {
+            const int img = m / hw, rem = m - img * hw;
+            const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
+            pix = (img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
+        }
+        rowpix[tid] = pix;
+    }
+
+    floatx16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_IT], rb[B_IT];
+    const int nkt = d.K / BK;
+    int tap = 0, c0 = 0;
+
+    auto load_tile = [&](int kt) {
+        // source + tap of this k-tile (all 16 k's share them: Cin and C0 are multiples of 16)
+        const int s = (d.nsrc > 1 && c0 >= d.src[0].C) ? 1 : 0;
+        const Src& S = d.src[s];
+        const int cc = c0 - (s ? d.src[0].C : 0) + kq * 4;
+        const int oy = d.offy[tap], ox = d.offx[tap];
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int iy = r_y[it] + oy, ix = r_x[it] + ox;
+            if (r_img[it] >= 0 && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) {
+                const size_t pix = ((size_t)r_img[it] * d.Hin + iy) * d.Win + ix;
+                v = *reinterpret_cast<const float4*>(S.x + pix * S.cstride + cc);
+                if (S.ss) {
+                    const float4* q = reinterpret_cast<const float4*>(S.ss + (size_t)(r_img[it] >> 1) * S.sstride + cc);
+                    const float4 q0 = q[0], q1 = q[1];      // {sc0,sh0,sc1,sh1} {sc2,sh2,sc3,sh3}
+                    v.x = lrelu(v.x * q0.x + q0.y); v.y = lrelu(v.y * q0.z + q0.w);
+                    v.z = lrelu(v.z * q1.x + q1.y); v.w = lrelu(v.w * q1.z + q1.w);
+                }
+            }
+            ra[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int slot = tid + it * 256;
+            const int row = slot >> 2;
+            if (BN * 4 >= 256 || slot < BN * 4)
+                rb[it] = *reinterpret_cast<const float4*>(d.w + (size_t)(n0 + row) * d.K + (size_t)kt * BK + kq * 4);
+        }
+        c0 += BK;
+        if (c0 == d.Cin) { c0 = 0; ++tap; }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + it * 64) * LDK + kq * 4]) = ra[it];
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int slot = tid + it * 256;
+            if (BN * 4 >= 256 || slot < BN * 4)
+                *reinterpret_cast<float4*>(&Bs[buf][(slot >> 2) * LDK + kq * 4]) = rb[it];
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int arow = (wm * MI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const int brow = (wn * NI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            float4 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][arow + i * 32 * LDK + kc * 8]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[buf][brow + j * 32 * LDK + kc * 8]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int pix = rowpix[row];
+            if (pix < 0) continue;
+            float* yo = d.y + (size_t)pix * d.ycstride + d.ychoff;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wn * NI * 32 + j * 32 + (lane & 31);
+                if (col < d.Cout) {
+                    float v = acc[i][j][r];
+                    if (d.bias) v += d.bias[col];
+                    if (d.tanh_out) v = tanhf(v);
+                    yo[col] = v;
+                }
+            }
+        }
 }
+
+// ---- BatchNorm batch statistics (per group of 2 images, per channel), float64 ---------------------
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int rows_per_group, int C, int chunk_rows,
+                                                          double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int q4 = C >> 2;
+    const int nrl = 256 / q4;
+    const int cq = threadIdx.x % q4, rl = threadIdx.x / q4;
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    if (rl < nrl) {
+        const int r1 = min((chunk + 1) * chunk_rows, rows_per_group);
+        const float* base = x + (size_t)g * rows_per_group * C + cq * 4;
+        for (int r = chunk * chunk_rows + rl; r < r1; r += nrl) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * C);
+            const double a = v.x, b = v.y, c = v.z, d = v.w;
+            s[0] += a; s[1] += b; s[2] += c; s[3] += d;
+            ss[0] += a * a; ss[1] += b * b; ss[2] += c * c; ss[3] += d * d;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sm[(rl * q4 + cq) * 8 + k] = s[k]; sm[(rl * q4 + cq) * 8 + 4 + k] = ss[k]; }
+    }
+    __syncthreads();
+    if (rl == 0) {
+        double* o = partial + (((size_t)g * nchunks + chunk) * C + cq * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double a = 0, b = 0;
+            for (int j = 0; j < nrl; ++j) { a += sm[(j * q4 + cq) * 8 + k]; b += sm[(j * q4 + cq) * 8 + 4 + k]; }
+            o[k * 2] = a; o[k * 2 + 1] = b;
+        }
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nchunks, int C, int rows_per_group,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float2* __restrict__ ss) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int k = 0; k < nchunks; ++k) {
+        const double* p = partial + (((size_t)g * nchunks + k) * C + c) * 2;
+        s += p[0]; q += p[1];
+    }
+    const double mean = s / rows_per_group;
+    double var = q / rows_per_group - mean * mean;       // biased variance (training-mode BN)
+    if (var < 0) var = 0;
+    const double sc = (double)gamma[c] / sqrt(var + BN_EPS);
+    ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
+}
+
+// ---- bilinear resize, align_corners=False (mymodel.py:261,379) --------------------------------------
+__device__ __forceinline__ void lin_coef(int dst, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * (dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - i0;
+    l0 = 1.f - l1;
+}
+
+// x [n,16,H,W] NCHW -> y [n,RS,RS,16] NHWC
+__global__ void resize_in_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int H, int W) {
+    const size_t total = (size_t)n * RS * RS;
+    const float shh = (float)H / RS, sww = (float)W / RS;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % RS), oy = (int)((idx / RS) % RS), img = (int)(idx / ((size_t)RS * RS));
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        lin_coef(oy, shh, H, y0, y1, ly0, ly1);
+        lin_coef(ox, sww, W, x0, x1, lx0, lx1);
+        float out[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float* p = x + ((size_t)img * 16 + c) * H * W;
+            out[c] = ly0 * (lx0 * p[(size_t)y0 * W + x0] + lx1 * p[(size_t)y0 * W + x1]) +
+                     ly1 * (lx0 * p[(size_t)y1 * W + x0] + lx1 * p[(size_t)y1 * W + x1]);
+        }
+        float4* o = reinterpret_cast<float4*>(y + idx * 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = make_float4(out[4 * c], out[4 * c + 1], out[4 * c + 2], out[4 * c + 3]);
+    }
+}
+
+// x [n,RS,RS,C] NHWC -> y [n,C,H,W] NCHW
+__global__ void resize_out_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C, int H, int W) {
+    const size_t total = (size_t)n * H * W;
+    const float shh = (float)RS / H, sww = (float)RS / W;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % W), oy = (int)((idx / W) % H), img = (int)(idx / ((size_t)H * W));
+        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+        lin_coef(oy, shh, RS, y0, y1, ly0, ly1);
+        lin_coef(ox, sww, RS, x0, x1, lx0, lx1);
+        const float* p00 = x + (((size_t)img * RS + y0) * RS + x0) * C;
+        const float* p01 = x + (((size_t)img * RS + y0) * RS + x1) * C;
+        const float* p10 = x + (((size_t)img * RS + y1) * RS + x0) * C;
+        const float* p11 = x + (((size_t)img * RS + y1) * RS + x1) * C;
+        float* o = y + (size_t)img * C * H * W + (size_t)oy * W + ox;
+        for (int c = 0; c < C; ++c)
+            o[(size_t)c * H * W] = ly0 * (lx0 * p00[c] + lx1 * p01[c]) + ly1 * (lx0 * p10[c] + lx1 * p11[c]);
+    }
+}
+
+// ---- host-side model ---------------------------------------------------------------------------------
+struct Phase {                       // one launch of the implicit GEMM
+    int ntaps; signed char offy[16], offx[16];
+    int py, px, Hp, Wp;              // Hp/Wp resolved against the layer's Hout/Wout
+    size_t w_off;                    // float offset into the packed-weight blob
+    int K;
+};
+
+struct Layer {
+    std::string name;                // reference block name ("conv4", "deconv3rgb", "deconv1f" ...)
+    int kind;                        // 0 conv, 1 deconv, 2 head
+    int cin, cout, k, stride, pad;
+    int cout_pad;
+    std::vector<Phase> phases;
+    size_t bias_off;                 // heads
+};
+
+struct Buf { std::string name; int H, C; size_t off /*floats per image*/, ss_off, gb_off; };
+
+}  // namespace
+
+struct RelposeSCNet {
+    int S, use_tanh, cf;
+    std::map<std::string, std::vector<float>> params;   // raw state dict (host)
+    std::map<std::string, std::vector<int64_t>> shapes;
+    bool finalized = false;
+    int64_t nparams = 0;
+    // device
+    float* d_w = nullptr;        // packed weights + biases
+    float* d_gb = nullptr;       // gamma/beta per activation buffer [2][C]
+    std::map<std::string, Layer> layers;
+    std::map<std::string, Buf> bufs;
+    size_t per_image_floats = 0, ss_float2_per_group = 0;
+    size_t gb_floats = 0;
+    // timing
+    int last_n = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_kind;
+};
+
+namespace {
+
+struct LayerSpec { const char* name; int kind, cin, cout, k, s, p; };
+
+std::vector<LayerSpec> layer_specs(int S) {
+    std::vector<LayerSpec> t;
+    const int g = 64;
+    t.push_back({"conv1", 0, 16, 192, 3, 1, 1});                       // fused conv1{rgb,n,d} x {self,t2s}
+    const char* mods[3] = {"rgb", "n", "d"};
+    static std::string names[64];
+    int ni = 0;
+    for (int m = 0; m < 3; ++m) {
+        names[ni] = std::string("conv2") + mods[m]; t.push_back({names[ni++].c_str(), 0, g / 2, g, 4, 2, 1});
+        names[ni] = std::string("conv3") + mods[m]; t.push_back({names[ni++].c_str(), 0, g, g * 2, 4, 2, 1});
+    }
+    t.push_back({"conv4", 0, g * 12, g * 4, 4, 2, 1});
+    t.push_back({"conv5", 0, g * 4, g * 8, 4, 2, 1});
+    t.push_back({"conv6", 0, g * 8, g * 8, 4, 2, 1});
+    t.push_back({"conv7", 0, g * 8, g * 8, 3, 2, 0});
+    t.push_back({"conv8", 0, g * 8, g * 8, 3, 1, 1});
+    t.push_back({"conv9", 0, g * 8, g * 16, 3, 1, 0});
+    t.push_back({"deconv9", 1, g * 16, g * 8, 3, 1, 0});
+    t.push_back({"deconv8", 1, g * 16, g * 8, 3, 1, 1});
+    t.push_back({"deconv7", 1, g * 16, g * 8, 3, 2, 0});
+    t.push_back({"deconv6", 1, g * 16, g * 8, 4, 2, 1});
+    t.push_back({"deconv5", 1, g * 16, g * 4, 4, 2, 1});
+    t.push_back({"deconv4", 1, g * 8, g * 2, 4, 2, 1});
+    const int hc[5] = {3, 3, 1, S, 32};
+    const char* heads[5] = {"rgb", "n", "d", "s", "f"};
+    for (int m = 0; m < 5; ++m) {
+        const bool skip = m < 3;
+        names[ni] = std::string("deconv3") + heads[m]; t.push_back({names[ni++].c_str(), 1, skip ? g * 4 : g * 2, g, 4, 2, 1});
+        names[ni] = std::string("deconv2") + heads[m]; t.push_back({names[ni++].c_str(), 1, skip ? g * 2 : g, skip ? g / 2 : g, 4, 2, 1});
+        names[ni] = std::string("deconv1") + heads[m]; t.push_back({names[ni++].c_str(), 2, g, hc[m], 1, 1, 0});
+    }
+    return t;
+}
+
+// input channels of the resized net input used by conv1 block q = 2*m + s  (mymodel.py:264-286)
+void conv1_inputs(int m, int s, int* ch, int& n) {
+    const int off = s * 8;
+    if (m == 0) { ch[0] = off + 0; ch[1] = off + 1; ch[2] = off + 2; ch[3] = off + 7; n = 4; }
+    else if (m == 1) { ch[0] = off + 3; ch[1] = off + 4; ch[2] = off + 5; ch[3] = off + 7; n = 4; }
+    else { ch[0] = off + 6; ch[1] = off + 7; n = 2; }
+}
+
+bool have(RelposeSCNet* net, const std::string& key, size_t numel) {
+    auto it = net->params.find(key);
+    if (it == net->params.end() || it->second.size() != numel) {
+        fprintf(stderr, "relpose_scnet: missing or mis-sized parameter %s (want %zu)\n", key.c_str(), numel);
+        return false;
+    }
+    return true;
+}
+
+int pack_layer(RelposeSCNet* net, const LayerSpec& sp, std::vector<float>& blob) {
+    Layer L;
+    L.name = sp.name; L.kind = sp.kind; L.cin = sp.cin; L.cout = sp.cout; L.k = sp.k; L.stride = sp.s; L.pad = sp.p;
+    L.cout_pad = sp.cout >= 128 ? (sp.cout + 127) / 128 * 128 : (sp.cout > 32 ? 64 : 32);
+    L.bias_off = 0;
+    const int k = sp.k;
+    if (L.name == "conv1") {
+        // block-sparse fusion of conv1rgb/conv1n/conv1d over both streams: zero weights outside each block
+        Phase P; P.ntaps = 9; P.py = P.px = 0; P.K = 9 * 16; P.w_off = blob.size();
+        for (int t = 0; t < 9; ++t) { P.offy[t] = (signed char)(t / 3 - 1); P.offx[t] = (signed char)(t % 3 - 1); }
+        blob.resize(blob.size() + (size_t)L.cout_pad * P.K, 0.f);
+        float* w = blob.data() + P.w_off;
+        const char* mods[3] = {"rgb", "n", "d"};
+        for (int m = 0; m < 3; ++m) {
+            const std::string key = std::string("conv1") + mods[m] + ".0.weight";
+            const int cin_m = m == 2 ? 2 : 4;
+            if (!have(net, key, (size_t)32 * cin_m * 9)) return RELPOSE_EINVAL;
+            const float* W = net->params[key].data();
+            for (int s = 0; s < 2; ++s) {
+                int ch[4], n; conv1_inputs(m, s, ch, n);
+                for (int co = 0; co < 32; ++co)
+                    for (int ci = 0; ci < n; ++ci)
+                        for (int t = 0; t < 9; ++t)
+                            w[(size_t)((2 * m + s) * 32 + co) * P.K + t * 16 + ch[ci]] = W[((size_t)co * cin_m + ci) * 9 + t];
+            }
+        }
+        L.phases.push_back(P);
+    } else if (sp.kind == 0 || sp.kind == 2) {
+        const std::string key = L.name + (sp.kind == 0 ? ".0.weight" : ".weight");
+        if (!have(net, key, (size_t)sp.cout * sp.cin * k * k)) return RELPOSE_EINVAL;
+        const float* W = net->params[key].data();
+        Phase P; P.ntaps = k * k; P.py = P.px = 0; P.K = k * k * sp.cin; P.w_off = blob.size();
+        for (int t = 0; t < k * k; ++t) { P.offy[t] = (signed char)(t / k - sp.p); P.offx[t] = (signed char)(t % k - sp.p); }
+        blob.resize(blob.size() + (size_t)L.cout_pad * P.K, 0.f);
+        float* w = blob.data() + P.w_off;
+        for (int co = 0; co < sp.cout; ++co)
+            for (int ci = 0; ci < sp.cin; ++ci)
+                for (int t = 0; t < k * k; ++t) w[(size_t)co * P.K + t * sp.cin + ci] = W[((size_t)co * sp.cin + ci) * k * k + t];
+        L.phases.push_back(P);
+        if (sp.kind == 2) {
+            if (!have(net, L.name + ".bias", sp.cout)) return RELPOSE_EINVAL;
+            L.bias_off = blob.size();
+            blob.resize(blob.size() + L.cout_pad, 0.f);
+            memcpy(blob.data() + L.bias_off, net->params[L.name + ".bias"].data(), sp.cout * sizeof(float));
+        }
+    } else {
+        // ConvTranspose2d weight [Cin][Cout][k][k]:  y = iy*s - p + ky.  Phase (py,px) = output pixels
+        // congruent to (py,px) mod s; its taps are the ky with (py + p - ky) % s == 0, dy = (py+p-ky)/s.
+        const std::string key = L.name + ".0.weight";
+        if (!have(net, key, (size_t)sp.cin * sp.cout * k * k)) return RELPOSE_EINVAL;
+        const float* W = net->params[key].data();
+        for (int py = 0; py < sp.s; ++py)
+            for (int px = 0; px < sp.s; ++px) {
+                Phase P; P.py = py; P.px = px; P.ntaps = 0; P.w_off = blob.size();
+                int kys[16], kxs[16];
+                for (int ky = 0; ky < k; ++ky) {
+                    if (((py + sp.p - ky) % sp.s + sp.s) % sp.s) continue;
+                    for (int kx = 0; kx < k; ++kx) {
+                        if (((px + sp.p - kx) % sp.s + sp.s) % sp.s) continue;
+                        const int t = P.ntaps++;
+                        kys[t] = ky; kxs[t] = kx;
+                        P.offy[t] = (signed char)((py + sp.p - ky) / sp.s);       // exact division
+                        P.offx[t] = (signed char)((px + sp.p - kx) / sp.s);
+                    }
+                }
+                P.K = P.ntaps * sp.cin;
+                blob.resize(blob.size() + (size_t)L.cout_pad * P.K, 0.f);
+                float* w = blob.data() + P.w_off;
+                for (int co = 0; co < sp.cout; ++co)
+                    for (int t = 0; t < P.ntaps; ++t)
+                        for (int ci = 0; ci < sp.cin; ++ci)
+                            w[(size_t)co * P.K + t * sp.cin + ci] = W[(((size_t)ci * sp.cout + co) * k + kys[t]) * k + kxs[t]];
+                L.phases.push_back(P);
+            }
+    }
+    net->layers[L.name] = L;
+    return 0;
+}
+
+struct BufSpec { const char* name; int H, C; };
+const BufSpec BUFS[] = {{"X0", 224, 16},  {"A1", 224, 192}, {"A2", 112, 384}, {"A3", 56, 768},  {"A4", 28, 256}, {"A5", 14, 512},
+                        {"A6", 7, 512},   {"A7", 3, 512},   {"A8", 3, 512},   {"A9", 1, 1024},  {"D9", 3, 512},  {"D8", 3, 512},
+                        {"D7", 7, 512},   {"D6", 14, 512},  {"D5", 28, 256},  {"D4", 56, 128},  {"D3", 112, 320}, {"D2", 224, 224},
+                        {"OUT", 224, 0}};
+
+// gamma/beta source blocks of each activation buffer: list of (bn key prefix, channels)
+std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
+    typedef std::pair<std::string, int> P;
+    if (b == "A1") return {P("conv1rgb", 32), P("conv1rgb", 32), P("conv1n", 32), P("conv1n", 32), P("conv1d", 32), P("conv1d", 32)};
+    if (b == "A2") return {P("conv2rgb", 64), P("conv2rgb", 64), P("conv2n", 64), P("conv2n", 64), P("conv2d", 64), P("conv2d", 64)};
+    if (b == "A3") return {P("conv3rgb", 128), P("conv3rgb", 128), P("conv3n", 128), P("conv3n", 128), P("conv3d", 128), P("conv3d", 128)};
+    if (b == "A4") return {P("conv4", 256)};
+    if (b == "A5") return {P("conv5", 512)};
+    if (b == "A6") return {P("conv6", 512)};
+    if (b == "A7") return {P("conv7", 512)};
+    if (b == "A8") return {P("conv8", 512)};
+    if (b == "A9") return {P("conv9", 1024)};
+    if (b == "D9") return {P("deconv9", 512)};
+    if (b == "D8") return {P("deconv8", 512)};
+    if (b == "D7") return {P("deconv7", 512)};
+    if (b == "D6") return {P("deconv6", 512)};
+    if (b == "D5") return {P("deconv5", 256)};
+    if (b == "D4") return {P("deconv4", 128)};
+    if (b == "D3") return {P("deconv3rgb", 64), P("deconv3n", 64), P("deconv3d", 64), P("deconv3s", 64), P("deconv3f", 64)};
+    if (b == "D2") return {P("deconv2rgb", 32), P("deconv2n", 32), P("deconv2d", 32), P("deconv2s", 64), P("deconv2f", 64)};
+    return {};
+}
+
+struct Runner {
+    RelposeSCNet* net; hipStream_t s; int n, G;
+    float* act; float2* ss; double* partial;
+    int rc = 0;
+
+    float* buf(const std::string& b) { return act + net->bufs[b].off * n; }
+    float2* ssb(const std::string& b) { return ss + net->bufs[b].ss_off * G; }
+
+    void mark(int kind) {
+        if (!net->profiling) return;
+        hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s);
+        net->ev.push_back(e); net->ev_kind.push_back(kind);
+    }
+
+    Src src(const std::string& b, int choff, int C) {
+        const Buf& B = net->bufs[b];
+        Src r; r.x = buf(b) + choff; r.cstride = B.C; r.C = C; r.sstride = B.C;
+        r.ss = (b == "X0") ? nullptr : ssb(b) + choff;
+        return r;
+    }
+
+    void conv(const std::string& layer, Src s0, const Src* s1, int Hin, const std::string& out, int ochoff) {
+        if (rc) return;
+        const Layer& L = net->layers[layer];
+        const Buf& O = net->bufs[out];
+        const int Hout = O.H;
+        for (const Phase& P : L.phases) {
+            ConvDesc d;
+            memset(&d, 0, sizeof(d));
+            d.src[0] = s0; d.nsrc = 1;
+            if (s1) { d.src[1] = *s1; d.nsrc = 2; }
+            d.Cin = s0.C + (s1 ? s1->C : 0);
+            d.Nimg = n; d.Hin = Hin; d.Win = Hin;
+            if (L.kind == 1) {
+                d.sy = d.sx = 1; d.osy = d.osx = L.stride; d.py = P.py; d.px = P.px;
+                d.Hp = (Hout - P.py + L.stride - 1) / L.stride; d.Wp = (Hout - P.px + L.stride - 1) / L.stride;
+            } else {
+                d.sy = d.sx = L.stride; d.osy = d.osx = 1; d.py = d.px = 0; d.Hp = Hout; d.Wp = Hout;
+            }
+            d.ntaps = P.ntaps;
+            memcpy(d.offy, P.offy, 16); memcpy(d.offx, P.offx, 16);
+            d.w = net->d_w + P.w_off;
+            d.Cout = L.cout;
+            d.y = buf(out); d.Hout = Hout; d.Wout = Hout; d.ycstride = (out == "OUT") ? net->cf : O.C; d.ychoff = ochoff;
+            d.bias = (L.kind == 2) ? net->d_w + L.bias_off : nullptr;
+            d.tanh_out = (L.kind == 2 && layer == "deconv1f" && net->use_tanh) ? 1 : 0;
+            d.M = n * d.Hp * d.Wp; d.K = P.K;
+            if (d.K != d.ntaps * d.Cin || d.Cin % BK || (s1 && s0.C % BK)) { rc = RELPOSE_EINVAL; return; }
+            mark(1);
+            if (L.cout_pad >= 128) {
+                dim3 grid((d.M + 127) / 128, L.cout_pad / 128);
+                hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, d);
+            } else if (L.cout_pad == 64) {
+                dim3 grid((d.M + 255) / 256, 1);
+                hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2>), grid, dim3(256), 0, s, d);
+            } else {
+                dim3 grid((d.M + 255) / 256, 1);
+                hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1>), grid, dim3(256), 0, s, d);
+            }
+            mark(-1);
+            if (hipGetLastError() != hipSuccess) { rc = -1001; return; }
+        }
+    }
+
+    void stats(const std::string& b) {
+        if (rc) return;
+        const Buf& B = net->bufs[b];
+        const int rows = 2 * B.H * B.H;
+        int nch = (2048 + G - 1) / G;
+        if (nch > (rows + 63) / 64) nch = (rows + 63) / 64;
+        if (nch > 64) nch = 64;
+        if (nch < 1) nch = 1;
+        const int chunk_rows = (rows + nch - 1) / nch;
+        nch = (rows + chunk_rows - 1) / chunk_rows;
+        const int q4 = B.C / 4, nrl = 256 / q4;
+        mark(2);
+        hipLaunchKernelGGL(bn_partial_kernel, dim3(nch, G), dim3(256), (size_t)nrl * q4 * 8 * sizeof(double), s, buf(b), rows, B.C,
+                           chunk_rows, partial);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((B.C + 255) / 256, G), dim3(256), 0, s, partial, nch, B.C, rows,
+                           net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssb(b));
+        mark(-2);
+        if (hipGetLastError() != hipSuccess) rc = -1002;
+    }
+};
+
+size_t partial_doubles(int G) { return (size_t)G * 64 * 1024 * 2; }
+
+}  // namespace
+
+extern "C" {
+
+RelposeSCNet* relpose_scnet_create(int32_t snumclass, int32_t use_tanh) {
+    if (snumclass < 1 || snumclass > 64) return nullptr;
+    RelposeSCNet* net = new RelposeSCNet();
+    net->S = snumclass; net->use_tanh = use_tanh; net->cf = 7 + snumclass + 32;
+    return net;
+}
+
+void relpose_scnet_destroy(RelposeSCNet* net) {
+    if (!net) return;
+    if (net->d_w) hipFree(net->d_w);
+    if (net->d_gb) hipFree(net->d_gb);
+    delete net;
+}
+
+int relpose_scnet_set_param(RelposeSCNet* net, const char* key, const float* data, size_t numel) {
+    if (!net || !key || !data) return RELPOSE_EINVAL;
+    net->params[key] = std::vector<float>(data, data + numel);
+    net->finalized = false;
+    return 0;
+}
+
+int64_t relpose_scnet_num_params(const RelposeSCNet* net) {
+    if (!net) return 0;
+    int64_t n = 0;
+    for (auto& kv : net->params) n += (int64_t)kv.second.size();
+    return n;
+}
+
+int relpose_scnet_finalize(RelposeSCNet* net) {
+    if (!net) return RELPOSE_EINVAL;
+    std::vector<float> blob;
+    net->layers.clear();
+    for (const LayerSpec& sp : layer_specs(net->S)) {
+        int rc = pack_layer(net, sp, blob);
+        if (rc) return rc;
+    }
+    // activation buffers
+    net->bufs.clear();
+    size_t off = 0, ssoff = 0, gboff = 0;
+    std::vector<float> gb;
+    for (const BufSpec& bs : BUFS) {
+        Buf b; b.name = bs.name; b.H = bs.H; b.C = bs.C ? bs.C : net->cf;
+        b.off = off; off += (size_t)b.H * b.H * b.C;
+        b.ss_off = ssoff; b.gb_off = gboff;
+        auto blocks = bn_blocks(b.name);
+        if (!blocks.empty()) {
+            ssoff += b.C;
+            gb.resize(gboff + 2 * (size_t)b.C, 0.f);
+            int c = 0;
+            for (auto& blk : blocks) {
+                if (!have(net, blk.first + ".1.weight", blk.second) || !have(net, blk.first + ".1.bias", blk.second)) return RELPOSE_EINVAL;
+                memcpy(gb.data() + gboff + c, net->params[blk.first + ".1.weight"].data(), blk.second * sizeof(float));
+                memcpy(gb.data() + gboff + b.C + c, net->params[blk.first + ".1.bias"].data(), blk.second * sizeof(float));
+                c += blk.second;
+            }
+            if (c != b.C) return RELPOSE_EINVAL;
+            gboff += 2 * (size_t)b.C;
+        }
+        net->bufs[b.name] = b;
+    }
+    net->per_image_floats = off; net->ss_float2_per_group = ssoff; net->gb_floats = gboff;
+    if (net->d_w) { hipFree(net->d_w); net->d_w = nullptr; }
+    if (net->d_gb) { hipFree(net->d_gb); net->d_gb = nullptr; }
+    RP_HIP(hipMalloc((void**)&net->d_w, blob.size() * sizeof(float)));
+    RP_HIP(hipMemcpy(net->d_w, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    RP_HIP(hipMalloc((void**)&net->d_gb, gb.size() * sizeof(float)));
+    RP_HIP(hipMemcpy(net->d_gb, gb.data(), gb.size() * sizeof(float), hipMemcpyHostToDevice));
+    net->finalized = true;
+    return 0;
+}
+
+size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n, int32_t H, int32_t W) {
+    if (!net || !net->finalized || n <= 0 || (n & 1) || H <= 0 || W <= 0) return 0;
+    const int G = n / 2;
+    return rp_align(net->per_image_floats * n * sizeof(float)) + rp_align(net->ss_float2_per_group * G * sizeof(float2)) +
+           rp_align(partial_doubles(G) * sizeof(double));
+}
+
+int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0) return RELPOSE_EINVAL;
+    if (workspace_bytes < relpose_scnet_workspace_bytes(net, n, H, W)) return RELPOSE_ENOMEM;
+    net->last_n = n;
+    Runner R;
+    R.net = net; R.s = (hipStream_t)stream; R.n = n; R.G = n / 2;
+    char* ws = (char*)workspace;
+    R.act = (float*)ws;
+    R.ss = (float2*)(ws + rp_align(net->per_image_floats * n * sizeof(float)));
+    R.partial = (double*)((char*)R.ss + rp_align(net->ss_float2_per_group * R.G * sizeof(float2)));
+
+    R.mark(3);
+    hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, R.s, x, R.buf("X0"), n, H, W);
+    R.mark(-3);
+    // encoder, three modalities x two streams in concatenated buffers (mymodel.py:266-291)
+    R.conv("conv1", R.src("X0", 0, 16), nullptr, 224, "A1", 0);
+    R.stats("A1");
+    const char* mods[3] = {"rgb", "n", "d"};
+    for (int q = 0; q < 6; ++q) R.conv(std::string("conv2") + mods[q / 2], R.src("A1", q * 32, 32), nullptr, 224, "A2", q * 64);
+    R.stats("A2");
+    for (int q = 0; q < 6; ++q) R.conv(std::string("conv3") + mods[q / 2], R.src("A2", q * 64, 64), nullptr, 112, "A3", q * 128);
+    R.stats("A3");
+    R.conv("conv4", R.src("A3", 0, 768), nullptr, 56, "A4", 0); R.stats("A4");
+    R.conv("conv5", R.src("A4", 0, 256), nullptr, 28, "A5", 0); R.stats("A5");
+    R.conv("conv6", R.src("A5", 0, 512), nullptr, 14, "A6", 0); R.stats("A6");
+    R.conv("conv7", R.src("A6", 0, 512), nullptr, 7, "A7", 0); R.stats("A7");
+    R.conv("conv8", R.src("A7", 0, 512), nullptr, 3, "A8", 0); R.stats("A8");
+    R.conv("conv9", R.src("A8", 0, 512), nullptr, 3, "A9", 0); R.stats("A9");
+    // decoder with skip concatenations (mymodel.py:302-307)
+    Src sk;
+    R.conv("deconv9", R.src("A9", 0, 1024), nullptr, 1, "D9", 0); R.stats("D9");
+    sk = R.src("A8", 0, 512); R.conv("deconv8", R.src("D9", 0, 512), &sk, 3, "D8", 0); R.stats("D8");
+    sk = R.src("A7", 0, 512); R.conv("deconv7", R.src("D8", 0, 512), &sk, 3, "D7", 0); R.stats("D7");
+    sk = R.src("A6", 0, 512); R.conv("deconv6", R.src("D7", 0, 512), &sk, 7, "D6", 0); R.stats("D6");
+    sk = R.src("A5", 0, 512); R.conv("deconv5", R.src("D6", 0, 512), &sk, 14, "D5", 0); R.stats("D5");
+    sk = R.src("A4", 0, 256); R.conv("deconv4", R.src("D5", 0, 256), &sk, 28, "D4", 0); R.stats("D4");
+    // heads (mymodel.py:309-376): rgb/n/d with skips from the self stream, s/f without
+    const char* heads[5] = {"rgb", "n", "d", "s", "f"};
+    for (int m = 0; m < 5; ++m) {
+        if (m < 3) { sk = R.src("A3", 2 * m * 128, 128); R.conv(std::string("deconv3") + heads[m], R.src("D4", 0, 128), &sk, 56, "D3", m * 64); }
+        else R.conv(std::string("deconv3") + heads[m], R.src("D4", 0, 128), nullptr, 56, "D3", m * 64);
+    }
+    R.stats("D3");
+    const int d2off[5] = {0, 32, 64, 96, 160};
+    for (int m = 0; m < 5; ++m) {
+        if (m < 3) { sk = R.src("A2", 2 * m * 64, 64); R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), &sk, 112, "D2", d2off[m]); }
+        else R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), nullptr, 112, "D2", d2off[m]);
+    }
+    R.stats("D2");
+    const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
+    for (int m = 0; m < 5; ++m) {
+        if (m < 3) { sk = R.src("A1", 2 * m * 32, 32); R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 32), &sk, 224, "OUT", ooff[m]); }
+        else R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 64), nullptr, 224, "OUT", ooff[m]);
+    }
+    if (R.rc) return R.rc;
+    R.mark(3);
+    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), 0, R.s, R.buf("OUT"), out, n, net->cf, H, W);
+    R.mark(-3);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int64_t relpose_scnet_read_tap(RelposeSCNet* net, const char* name, float* out, void* workspace, void* stream) {
+    if (!net || !net->finalized || !name || net->last_n <= 0) return -1;
+    auto it = net->bufs.find(name);
+    if (it == net->bufs.end()) return -1;
+    const Buf& B = it->second;
+    const int64_t count = (int64_t)net->last_n * B.H * B.H * B.C;
+    if (out) {
+        if (!workspace) return -1;
+        const float* src = (const float*)workspace + B.off * net->last_n;
+        if (hipMemcpyAsync(out, src, count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return -1;
+    }
+    return count;
+}
+
+int relpose_scnet_profile(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
+                          size_t workspace_bytes, int32_t iters, double* ms_gemm, double* ms_other, int64_t* n_gemm, void* stream) {
+    if (!net || iters <= 0) return RELPOSE_EINVAL;
+    double tg = 0, to = 0; int64_t ng = 0;
+    for (int it = 0; it < iters; ++it) {
+        net->profiling = true; net->ev.clear(); net->ev_kind.clear();
+        int rc = relpose_scnet_forward(net, x, out, n, H, W, workspace, workspace_bytes, stream);
+        net->profiling = false;
+        if (rc) return rc;
+        RP_HIP(hipStreamSynchronize((hipStream_t)stream));
+        for (size_t i = 0; i + 1 < net->ev.size(); i += 2) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, net->ev[i], net->ev[i + 1]);
+            if (net->ev_kind[i] == 1) { tg += ms; ++ng; } else to += ms;
+        }
+        for (auto e : net->ev) hipEventDestroy(e);
+        net->ev.clear(); net->ev_kind.clear();
+    }
+    if (ms_gemm) *ms_gemm = tg / iters;
+    if (ms_other) *ms_other = to / iters;
+    if (n_gemm) *n_gemm = ng / iters;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference network module (model/mymodel.py:141-380).
+
+``SCNet(args)`` keeps the reference constructor (reads ``args.batchnorm``,
+``useTanh``, ``skipLayer``, ``outputType``, ``snumclass``), ``load_state_dict``
+takes the reference's key names, and ``net(x)`` maps ``[n,16,H,W]`` to
+``[n,7+S+32,H,W]`` -- but every layer runs in the HIP library
+(csrc/scnet.hip): there is no torch.nn graph behind it and no CPU path.
+
+BatchNorm statistics are taken over consecutive groups of 2 images, which is
+what the reference computes for its fixed batch of 2 (evaluation.py:242); with
+n = 2B the call processes B scan pairs at once.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .weights import state_dict_spec
+
+BUFFER_SHAPES = {"X0": (224, 16), "A1": (224, 192), "A2": (112, 384), "A3": (56, 768), "A4": (28, 256), "A5": (14, 512),
+                 "A6": (7, 512), "A7": (3, 512), "A8": (3, 512), "A9": (1, 1024), "D9": (3, 512), "D8": (3, 512),
+                 "D7": (7, 512), "D6": (14, 512), "D5": (28, 256), "D4": (56, 128), "D3": (112, 320), "D2": (224, 224)}
+
+
+class SCNet:
+    def __init__(self, args):
+        if not getattr(args, "batchnorm", 1) or not getattr(args, "skipLayer", 1):
+            raise NotImplementedError("only batchnorm=1, skipLayer=1 (the evaluation.py configuration) is built")
+        if getattr(args, "outputType", "rgbdnsf") != "rgbdnsf":
+            raise NotImplementedError("only outputType='rgbdnsf' is built")
+        self.snumclass = int(args.snumclass)
+        self.useTanh = int(getattr(args, "useTanh", 1))
+        self.out_channels = 7 + self.snumclass + 32
+        self._h = _lib.lib().relpose_scnet_create(self.snumclass, self.useTanh)
+        if not self._h:
+            raise RuntimeError("relpose_scnet_create failed")
+        self._ws = None
+        self._loaded = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().relpose_scnet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # torch.nn.Module look-alikes used by the reference call sites
+    def cuda(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        L = _lib.lib()
+        spec = state_dict_spec(self.snumclass)
+        missing = [k for k in spec if k not in state_dict]
+        if missing and strict:
+            raise RuntimeError(f"Missing key(s) in state_dict: {missing[:4]}...")
+        for k, shape in spec.items():
+            v = state_dict[k]
+            a = np.ascontiguousarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
+            if tuple(a.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: {a.shape} vs {shape}")
+            _lib.check(L.relpose_scnet_set_param(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), f"set_param {k}")
+        _lib.require_gpu()
+        _lib.check(L.relpose_scnet_finalize(self._h), "relpose_scnet_finalize")
+        self._loaded = True
+        return self
+
+    def num_params(self):
+        return int(_lib.lib().relpose_scnet_num_params(self._h))
+
+    def _workspace(self, n, H, W, dev):
+        import torch
+        nbytes = _lib.lib().relpose_scnet_workspace_bytes(self._h, n, H, W)
+        if nbytes == 0:
+            raise RuntimeError("relpose_scnet_workspace_bytes: invalid shape (n must be even) or weights not loaded")
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def forward(self, x, out=None):
+        import torch
+        dev = _lib.require_gpu()
+        if not self._loaded:
+            raise RuntimeError("load_state_dict first")
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 16
+        x = x.contiguous()
+        n, _, H, W = x.shape
+        ws = self._workspace(n, H, W, x.device)
+        if out is None:
+            out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
+        rc = _lib.lib().relpose_scnet_forward(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "relpose_scnet_forward")
+        return out
+
+    __call__ = forward
+
+    def read_tap(self, name):
+        """Raw (pre-BatchNorm) NHWC activations of buffer ``name`` from the last forward: [n,H,H,C]."""
+        import torch
+        L = _lib.lib()
+        cnt = L.relpose_scnet_read_tap(self._h, name.encode(), None, None, None)
+        if cnt < 0:
+            raise KeyError(name)
+        H, Cc = BUFFER_SHAPES[name] if name != "OUT" else (224, self.out_channels)
+        out = torch.empty(cnt, dtype=torch.float32, device=self._ws.device)
+        L.relpose_scnet_read_tap(self._h, name.encode(), _lib.ptr(out), _lib.ptr(self._ws), _lib.stream_ptr())
+        return out.view(-1, H, H, Cc)
+
+    def profile(self, x, iters=3):
+        """(ms in implicit-GEMM kernels, ms in other kernels, #GEMM launches) per forward, HIP events."""
+        import torch
+        n, _, H, W = x.shape
+        ws = self._workspace(n, H, W, x.device)
+        out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
+        g, o, k = C.c_double(), C.c_double(), C.c_int64()
+        rc = _lib.lib().relpose_scnet_profile(self._h, _lib.ptr(x.contiguous()), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(),
+                                              iters, C.byref(g), C.byref(o), C.byref(k), _lib.stream_ptr())
+        _lib.check(rc, "relpose_scnet_profile")
+        return g.value, o.value, k.value
