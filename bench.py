@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Benchmark of the relative-pose hot path on MI355X.
+
+Metric (BASELINE.json): scan-pairs/sec end-to-end (completion + feat +
+spectral-match), 160x640 RGB-D.  One "step" = one pass of the whole hot path
+(3 recurrent levels of {warp, SCNet, compose+sample, match}) over one batch of
+synthetic scan pairs already resident in HBM.  Workload at N GPUs:
+BASELINE.json configs[1] per GPU -- SUNCG conventions, 160x640, 200 keypoints per
+view, 32 pairs per GPU (weak scaling: pairs shard across ranks, no data-path
+collective, one RCCL all_gather of the 4x4 poses per step).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: "roofline" (dominant kernel = the fp32-MFMA implicit-GEMM conv, live
+HIP-event timing) and "cpu_baseline" (the numpy/torch oracle on the host cores,
+bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SUNCG_SIGMAS = [[0.28884460993320005, 0.3723397110060548, 0.04471146704846696, 0.008681938149233242],
+                [0.3301724627277194, 0.22653872741771977, 0.03371542612584658, 0.009278392068704865],
+                [0.44732243168057817, 0.3039564896467746, 0.029312830444192497, 0.011085327519146518]]
+# data/relativePoseModule/final_param_suncg_rlevel_3.txt of the reference (36 tuned floats = config data)
+
+GFLOP_PER_IMAGE = 36.14            # SCNet conv+convT MACs x2 per 224x224 sample
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(args, data, pts, ptw, S):
+    """The oracle (CPU restatement of the reference loop) on ONE pair of the same workload."""
+    import torch
+    from oracle import pipeline_oracle as P
+    from oracle.scnet_oracle import SCNetOracle
+    from relativepose_amd import weights
+    net = SCNetOracle(weights.make_state_dict(7, S), S, 1)
+    tm = {}
+    t0 = time.time()
+    P.run_pair(net, data["rgb"][0], data["norm"][0], data["depth"][0], pts[0], ptw[0], np.array(SUNCG_SIGMAS), "suncg", "second", S,
+               timing=tm)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"1 scan pair x 3 recurrent levels of the same workload (N={args.keypoints} keypoints), "
+                      f"oracle = numpy/scipy matcher + torch-CPU fp32 SCNet; {dt:.1f}s",
+            "seconds_per_stage": {k: round(v, 3) for k, v in tm.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=32, help="scan pairs per GPU")
+    ap.add_argument("--keypoints", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from relativepose_amd import distributed as D
+    from relativepose_amd import synth, weights, rpmodule
+    from relativepose_amd.model import SCNet
+    from relativepose_amd.pipeline import RelativePosePipeline
+
+    rank, world, local = D.init_from_env()
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    S, B, N = 15, args.pairs, args.keypoints
+    total = B * world
+    lo, hi = D.shard_range(total, rank, world)
+
+    # synthetic inputs + random-init weights (no dataset / checkpoint ships with the reference)
+    data = synth.make_pairs(hi - lo, 2000 + lo, "suncg")      # seed = 1000*config + pair index
+    pts, ptw = synth.make_keypoints(hi - lo, N, 2000 + lo, "second")
+    net = SCNet(SimpleNamespace(batchnorm=1, useTanh=1, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+    net.load_state_dict(weights.make_state_dict(7, S))
+    Cc = N * 5
+    pipe = RelativePosePipeline(net, "suncg", "second", SUNCG_SIGMAS, max_edges=min(Cc * (Cc - 1), 1 << 20))
+    st = pipe.prepare(data["rgb"], data["norm"], data["depth"], pts, ptw, dev)
+
+    def step():
+        pose, status, _ = pipe.run(st)
+        return D.gather_poses(pose, status, total, world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    D.barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        poses, status = step()
+    torch.cuda.synchronize()
+    D.barrier(world)
+    dt = D.max_over_ranks(time.perf_counter() - t0, world, dev)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        res = {"metric": "scan-pairs/sec end-to-end (completion+feat+spectral-match), 160x640 RGB-D",
+               "value": total * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic (seeded box-room RGB-D panoramas, injected keypoints, random-init weights)",
+               "config": {"workload": "SUNCG 160x640, N=200 keypoints, batch=32 pairs per GPU, alterStep=3 (BASELINE configs[1])",
+                          "pairs_per_gpu": B, "keypoints": N, "recurrent_levels": 3, "parallelism": f"pairs sharded x{world}"},
+               "status_ok_fraction": float((status == 0).double().mean().item())}
+        # --- roofline of the dominant kernel: implicit-GEMM conv, HIP events on the launch stream
+        x = torch.randn(2 * B, 16, 160, 640, device=dev)
+        net.profile(x, 1)
+        g_ms, o_ms, n_gemm = net.profile(x, 3)
+        flops = GFLOP_PER_IMAGE * 1e9 * 2 * B
+        ach = flops / (g_ms * 1e-3) / 1e12
+        res["roofline"] = {"kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2)", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "launches_per_forward": int(n_gemm), "ms_per_forward_gemm": g_ms, "ms_per_forward_other": o_ms,
+                           "algorithmic_gflop_per_forward": flops / 1e9}
+        # --- N x N affinity build (materialised fp32 wij), the kernel the HBM target is stated on
+        cases = [synth.make_match_case(N, 5000 + b)[:2] for b in range(B)]
+        kp = rpmodule.pack_keypoints(cases, dev)
+        para = rpmodule.opts(*SUNCG_SIGMAS[0])
+        f_s, w_s, f_t, w_t, ns_, nt_ = kp[2], kp[3], kp[6], kp[7], kp[8], kp[9]
+        for _ in range(3):
+            rpmodule.affinity_topk(f_s, w_s, f_t, w_t, ns_, nt_, para, want_wij=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        tot = 0.0
+        for _ in range(reps):
+            e0.record()
+            rpmodule.affinity_topk(f_s, w_s, f_t, w_t, ns_, nt_, para, want_wij=True)
+            e1.record()
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        a_ms = tot / reps
+        abytes = ((N + N) * 33 * 4 + N * N * 4) * B
+        res["roofline_affinity"] = {"kernel": "affinity_topk_kernel<true>", "bound": "hbm", "achieved": abytes / (a_ms * 1e-3) / 1e9,
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": abytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                    "traffic": None, "ms_per_launch": a_ms, "algorithmic_bytes_per_launch": abytes,
+                                    "note": "event pair around one launch incl. launch latency; batch is 6.8 MB so the launch is latency-bound"}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, data, pts, ptw, S)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""Multi-GPU: scan pairs are independent, so they shard across ranks in
+contiguous blocks (the reference's manual ``--entrySplit``, evaluation.py:59 /
+datasets/SUNCG.py:68-69) with no data-path collective; one all_gather of the
+[B_local,16] poses (+ status) at the end -- RCCL over xGMI on the GPU box
+(backend "nccl"), gloo in the CPU tests."""
+import os
+
+
+def init_from_env(backend=None):
+    """torch.distributed init from RANK/WORLD_SIZE/MASTER_* (torchrun contract). Returns (rank, world, local_rank)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total, rank, world):
+    """Contiguous block [lo, hi) of pair indices owned by ``rank``; blocks differ by at most one pair."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_poses(pose_local, status_local, total, world):
+    """all_gather of per-rank [b_r,4,4] poses and [b_r] status into [total,4,4] / [total] on every rank
+    (ragged blocks are padded to the largest block)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return pose_local, status_local
+    bmax = (total + world - 1) // world
+    buf = torch.zeros(bmax, 17, dtype=torch.float64, device=pose_local.device)
+    b = pose_local.shape[0]
+    buf[:b, :16] = pose_local.reshape(b, 16)
+    buf[:b, 16] = status_local.to(torch.float64)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    poses, status = [], []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        poses.append(out[r][:hi - lo, :16].reshape(-1, 4, 4))
+        status.append(out[r][:hi - lo, 16].to(torch.int32))
+    return torch.cat(poses), torch.cat(status)
+
+
+def barrier(world):
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, world, device):
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,95 @@
+"""The per-pair recurrent loop of the reference's evaluation driver
+(evaluation.py:203-284; library form RPModule/rpmodule.py:569-662), batched over
+B scan pairs and kept on the device from the input panoramas to the 4x4 poses:
+
+    for step in range(alterStep):                     # 3 recurrent levels
+        warp the other view with the current pose     util.warping
+        SCNet on [2B,16,h,4h]                          (BatchNorm groups = pairs)
+        compose + sample keypoint primitives          evaluation.py:246-253, getMatchingPrimitive
+        spectral matching + robust fit -> R_hat        RelativePoseEstimation_helper
+
+Keypoints are an input (the reference detects them with cv2 SIFT + random
+sampling, rputil.getKeypoint; not part of this build -- SURVEY.md §8a a6.3).
+"""
+import numpy as np
+
+from . import rpmodule, util
+
+
+class RelativePosePipeline:
+    def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0):
+        self.net = net
+        self.dataset = dataset
+        self.mask_method = mask_method
+        self.alter_steps = alter_steps
+        self.completion = completion
+        self.max_edges = max_edges
+        if sigmas is None:
+            o = rpmodule.opts()
+            sigmas = [[o.sigmaAngle1, o.sigmaAngle2, o.sigmaDist, o.sigmaFeat]] * alter_steps
+        self.sigmas = np.asarray(sigmas, dtype=np.float64).reshape(-1, 4)
+        self.feat_off = 7 + net.snumclass
+
+    def prepare(self, rgb, norm, depth, pts, ptw, device):
+        """Host arrays (dataset dict layout: rgb/norm [B,2,3,h,4h], depth [B,2,h,4h] f32; pts [B,2,N,2],
+        ptw [B,2,N] f64) -> device-resident state.  Not part of the timed region."""
+        import torch
+        B, _, _, h, w = rgb.shape
+        pts = np.asarray(pts, dtype=np.float64)
+        ptw = np.asarray(ptw, dtype=np.float64)
+        N = pts.shape[2]
+        npts = np.full((B, 2), N, dtype=np.int32)
+        if not self.completion:                       # rpmodule.py:534-537: keep observed-region keypoints only
+            p2, w2 = np.zeros_like(pts), np.zeros_like(ptw)
+            for b in range(B):
+                for v in range(2):
+                    k = ptw[b, v] == 1
+                    npts[b, v] = int(k.sum())
+                    p2[b, v, :npts[b, v]] = pts[b, v][k]
+                    w2[b, v, :npts[b, v]] = ptw[b, v][k]
+            pts, ptw = p2, w2
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
+        st = {"B": B, "h": h, "N": N}
+        st["rgb"] = t(rgb.reshape(2 * B, 3, h, w), torch.float32)
+        st["norm"] = t(norm.reshape(2 * B, 3, h, w), torch.float32)
+        st["depth"] = t(depth.reshape(2 * B, h, w), torch.float32)
+        st["pts"] = t(pts.reshape(2 * B, N, 2), torch.float64)
+        st["npts"] = t(npts.reshape(2 * B), torch.int32)
+        st["w_s"] = t(ptw[:, 0], torch.float64)
+        st["w_t"] = t(ptw[:, 1], torch.float64)
+        st["ns"] = t(npts[:, 0], torch.int32)
+        st["nt"] = t(npts[:, 1], torch.int32)
+        st["eye"] = torch.eye(4, dtype=torch.float64, device=device).repeat(B, 1, 1).contiguous()
+        return st
+
+    def run(self, st, R_forced=None, keep=None):
+        """One pass of the hot path over the prepared batch.  Returns (pose [B,4,4] f64, status [B] i32,
+        [pose after each step]).  R_forced: optional list of [B,4,4] tensors (teacher forcing, tests)."""
+        import torch
+        B, h, N = st["B"], st["h"], st["N"]
+        view = util.build_view_dev(st["rgb"], st["norm"], st["depth"], self.mask_method)      # [2B,8,h,4h]
+        R_hat = st["eye"]
+        trace = []
+        status = None
+        for step in range(self.alter_steps):
+            if R_forced is not None:
+                R_hat = R_forced[step]
+            # image 2b (source) gets target warped by inv(R), image 2b+1 (target) gets source warped by R
+            inv = util.pose_inverse_dev(R_hat)
+            poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
+            other = view.view(B, 2, 8, h, 4 * h).flip(1).reshape(2 * B, 8, h, 4 * h).contiguous()
+            warped = util.warping_dev(other, poses, self.dataset)
+            x = torch.cat((view, warped), 1)
+            f = self.net(x)
+            pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
+                                                    self.mask_method, self.dataset)
+            pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
+            para = rpmodule.opts(*self.sigmas[min(step, len(self.sigmas) - 1)])
+            res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), st["w_s"],
+                                       pc[:, 1].contiguous(), nn[:, 1].contiguous(), ft[:, 1].contiguous(), st["w_t"],
+                                       st["ns"], st["nt"], para, max_edges=self.max_edges)
+            R_hat, status = res.pose, res.status
+            trace.append(R_hat)
+            if keep is not None:
+                keep.append({"x": x, "f": f, "pc": pc, "nn": nn, "ft": ft})
+        return R_hat, status, trace

@@ -1,0 +1,95 @@
+"""GPU parity of the whole recurrent loop vs the oracle pipeline and the
+reference golden poses (tests/golden/e2e.npz, captured from the reference).
+
+With random-init weights the matching problem is ill-conditioned (roundoff in
+the oracle alone moves the pose by 1e-6 per step, see test_oracle_golden), and
+the float32 network adds ~1e-4 to the feature maps, so the loop is compared
+teacher-forced, stage by stage:
+  * network output and sampled primitives within float32 tolerance,
+  * the matcher, fed the ORACLE's primitives of that step, within 1e-4,
+  * the end-to-end pose is logged (and bounded loosely)."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from cases import E2E_CASES, E2E_N, E2E_WEIGHT_SEED
+from gpu_util import log
+from oracle import pipeline_oracle as P
+from oracle.scnet_oracle import SCNetOracle
+from relativepose_amd import synth, weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_net(S, tanh, seed):
+    from relativepose_amd.model import SCNet
+    net = SCNet(SimpleNamespace(batchnorm=1, useTanh=tanh, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+    net.load_state_dict(weights.make_state_dict(seed, S))
+    return net
+
+
+@pytest.mark.parametrize("ci", [0, 4, 5])
+def test_pipeline_teacher_forced_vs_oracle(ci, golden_dir):
+    import torch
+    from relativepose_amd import rpmodule
+    from relativepose_amd.pipeline import RelativePosePipeline
+    ge = np.load(os.path.join(golden_dir, "e2e.npz"))
+    gm = np.load(os.path.join(golden_dir, "matcher.npz"))
+    ds, mm, S, tanh, seed = E2E_CASES[ci]
+    d = synth.make_pairs(1, seed, ds)
+    pts, ptw = synth.make_keypoints(1, E2E_N, seed, mm)
+    sig = gm[f"params_{ds}"]
+    forced = [np.eye(4)] + [ge[f"e2e_{ci}_R{s}"] for s in range(2)]
+    # oracle, teacher-forced with the reference's poses
+    onet = SCNetOracle(weights.make_state_dict(E2E_WEIGHT_SEED, S), S, tanh)
+    det = []
+    _, otrace = P.run_pair(onet, d["rgb"][0], d["norm"][0], d["depth"][0], pts[0], ptw[0], sig, ds, mm, S, detail=det, R_forced=forced)
+    # HIP pipeline
+    dev = torch.device("cuda:0")
+    pipe = RelativePosePipeline(_gpu_net(S, tanh, E2E_WEIGHT_SEED), ds, mm, sig)
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    keep = []
+    Rf = [torch.from_numpy(f[None]).to(dev) for f in forced]
+    pose, status, trace = pipe.run(st, R_forced=Rf, keep=keep)
+    for step in range(3):
+        x_g = keep[step]["x"].cpu().numpy()
+        nbad = int((x_g != det[step]["x"]).any(1).sum())
+        f_err = np.abs(keep[step]["f"].cpu().numpy() - det[step]["f"]).max()
+        prim = det[step]["prim"]
+        pc_err = max(np.abs(keep[step]["pc"][0, v].cpu().numpy() - prim[v]["pc"]).max() for v in range(2))
+        nn_err = max(np.abs(keep[step]["nn"][0, v].cpu().numpy() - prim[v]["normal"]).max() for v in range(2))
+        ft_err = max(np.abs(keep[step]["ft"][0, v].cpu().numpy() - prim[v]["feat"]).max() for v in range(2))
+        # matcher on the oracle's primitives of this step (isolates the fit from the fp32 network difference)
+        para = rpmodule.opts(*sig[step])
+        pose_iso = rpmodule.RelativePoseEstimation_helper(prim[0], prim[1], para)
+        iso_err = np.linalg.norm(pose_iso[:3, :3] - otrace[step][:3, :3])
+        e2e_err = np.linalg.norm(trace[step][0].cpu().numpy()[:3, :3] - otrace[step][:3, :3])
+        ref_err = np.linalg.norm(trace[step][0].cpu().numpy()[:3, :3] - ge[f"e2e_{ci}_R{step}"][:3, :3])
+        log("pipeline_step", case=ci, ds=ds, step=step, net_input_pixels_differ=nbad, net_out_abs_err=f_err, pc_err=pc_err,
+            normal_err=nn_err, feat_err=ft_err, matcher_iso_rot_err=iso_err, e2e_rot_err_vs_oracle=e2e_err, e2e_rot_err_vs_reference=ref_err)
+        assert nbad <= 8
+        assert f_err < 1e-3
+        assert pc_err < 1e-3 and ft_err < 1e-3
+        assert iso_err < 1e-4
+        assert e2e_err < 5e-2          # ill-conditioned with random weights; see module docstring
+
+
+def test_pipeline_batch_equals_single_and_is_deterministic():
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, mm, S, tanh = "suncg", "second", 15, 1
+    net = _gpu_net(S, tanh, E2E_WEIGHT_SEED)
+    d = synth.make_pairs(3, 1000, ds)
+    pts, ptw = synth.make_keypoints(3, 60, 1000, mm)
+    pipe = RelativePosePipeline(net, ds, mm)
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    pose, status, _ = pipe.run(st)
+    pose2, _, _ = pipe.run(st)
+    assert torch.equal(pose, pose2)
+    for b in range(3):
+        st1 = pipe.prepare(d["rgb"][b:b + 1], d["norm"][b:b + 1], d["depth"][b:b + 1], pts[b:b + 1], ptw[b:b + 1], dev)
+        p1, _, _ = pipe.run(st1)
+        assert torch.equal(p1[0], pose[b]), b
