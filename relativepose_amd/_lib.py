@@ -68,6 +68,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not built: run `python -m relativepose_amd.build` "
                                "(or __graft_entry__.build()). There is no CPU fallback.")
+        # torch ships its own libamdhip64; import it first so this library binds to the SAME HIP runtime
+        # (loading ours first pulls in /opt/rocm's copy and the second runtime then sees no device).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         missing = [name for name in SIGNATURES if not hasattr(l, name)]
         if missing:
