@@ -24,7 +24,7 @@
 
 #define RP_MAXK 8
 #define RP_FEAT 32
-#define RP_FIT_THREADS 1024
+#define RP_FIT_THREADS 512
 #define RP_EPS 1e-12
 #define RP_OFFSET 50.0
 
@@ -355,14 +355,28 @@ __device__ void fit_solve(const FitCtx& f, bool reweight, double R[3][3], double
                 m9[a * 3 + bb] += (sp[a] - ms[a]) * ((tp[bb] - mt[bb]) * wp) + sn[a] * (tn[bb] * wn);
     }
     rp_block_sum<9>(m9, f.red);
-    double M[3][3];
+    // Horn's 4x4 eigenproblem on one wave only; R,t broadcast through LDS (red[144..155])
+    if (threadIdx.x < 64) {
+        double M[3][3], Rl[3][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int bb = 0; bb < 3; ++bb) M[a][bb] = m9[a * 3 + bb];
-    rp_horn_rotation(M, R);
+            for (int bb = 0; bb < 3; ++bb) M[a][bb] = m9[a * 3 + bb];
+        rp_horn_rotation(M, Rl);
+        if (threadIdx.x == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) t[a] = -((R[a][0] * ms[0] + R[a][1] * ms[1]) + R[a][2] * ms[2]) + mt[a];
+            for (int a = 0; a < 3; ++a) {
+                f.red[144 + a * 3 + 0] = Rl[a][0]; f.red[144 + a * 3 + 1] = Rl[a][1]; f.red[144 + a * 3 + 2] = Rl[a][2];
+                f.red[153 + a] = -((Rl[a][0] * ms[0] + Rl[a][1] * ms[1]) + Rl[a][2] * ms[2]) + mt[a];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        R[a][0] = f.red[144 + a * 3 + 0]; R[a][1] = f.red[144 + a * 3 + 1]; R[a][2] = f.red[144 + a * 3 + 2];
+        t[a] = f.red[153 + a];
+    }
     for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
         double sp[3], tp[3], sn[3], tn[3];
         corr_geom(f, c, sp, tp, sn, tn);

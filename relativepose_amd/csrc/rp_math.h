@@ -71,41 +71,49 @@ RP_HD double rp_pair_weight(const RpPairEval& e, double f1, double f2, double ws
 
 // Leading eigenvector of a symmetric 4x4 (cyclic Jacobi), the quaternion of Horn's
 // method (rpmodule.py:46-53 uses np.linalg.eig + argmax).  N is destroyed.
+// Every index is a compile-time constant after unrolling so N and V stay in registers on the GPU.
+#define RP_JROT(P, Q)                                                                          \
+    {                                                                                          \
+        const double apq = N[P][Q];                                                            \
+        if (apq != 0.0) {                                                                      \
+            const double theta = (N[Q][Q] - N[P][P]) / (2.0 * apq);                            \
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;                               \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                   \
+                const double nkp = N[k][P], nkq = N[k][Q];                                     \
+                N[k][P] = c * nkp - s * nkq; N[k][Q] = s * nkp + c * nkq;                      \
+            }                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                   \
+                const double npk = N[P][k], nqk = N[Q][k];                                     \
+                N[P][k] = c * npk - s * nqk; N[Q][k] = s * npk + c * nqk;                      \
+            }                                                                                  \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                   \
+                const double vkp = V[k][P], vkq = V[k][Q];                                     \
+                V[k][P] = c * vkp - s * vkq; V[k][Q] = s * vkp + c * vkq;                      \
+            }                                                                                  \
+        }                                                                                      \
+    }
+
 RP_HD void rp_sym4_max_eigvec(double N[4][4], double q[4]) {
     double V[4][4];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 32; ++sweep) {
-        double off = 0.0;
-        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += N[i][j] * N[i][j];
-        double diag = 0.0;
-        for (int i = 0; i < 4; ++i) diag += N[i][i] * N[i][i];
+        const double off = ((N[0][1] * N[0][1] + N[0][2] * N[0][2]) + (N[0][3] * N[0][3] + N[1][2] * N[1][2])) +
+                           (N[1][3] * N[1][3] + N[2][3] * N[2][3]);
+        const double diag = (N[0][0] * N[0][0] + N[1][1] * N[1][1]) + (N[2][2] * N[2][2] + N[3][3] * N[3][3]);
         if (off <= 1e-60 || off <= 1e-34 * diag) break;
-        for (int p = 0; p < 3; ++p) for (int qq = p + 1; qq < 4; ++qq) {
-            double apq = N[p][qq];
-            if (apq == 0.0) continue;
-            double theta = (N[qq][qq] - N[p][p]) / (2.0 * apq);
-            double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            for (int k = 0; k < 4; ++k) {           // columns p,q of N
-                double nkp = N[k][p], nkq = N[k][qq];
-                N[k][p] = c * nkp - s * nkq; N[k][qq] = s * nkp + c * nkq;
-            }
-            for (int k = 0; k < 4; ++k) {           // rows p,q of N
-                double npk = N[p][k], nqk = N[qq][k];
-                N[p][k] = c * npk - s * nqk; N[qq][k] = s * npk + c * nqk;
-            }
-            for (int k = 0; k < 4; ++k) {
-                double vkp = V[k][p], vkq = V[k][qq];
-                V[k][p] = c * vkp - s * vkq; V[k][qq] = s * vkp + c * vkq;
-            }
-        }
+        RP_JROT(0, 1) RP_JROT(0, 2) RP_JROT(0, 3) RP_JROT(1, 2) RP_JROT(1, 3) RP_JROT(2, 3)
     }
-    int best = 0;
-    for (int i = 1; i < 4; ++i) if (N[i][i] > N[best][best]) best = i;
-    double nrm = 0.0;
-    for (int i = 0; i < 4; ++i) nrm += V[i][best] * V[i][best];
-    nrm = sqrt(nrm);
-    for (int i = 0; i < 4; ++i) q[i] = V[i][best] / nrm;
+    double best = N[0][0];
+    double v0 = V[0][0], v1 = V[1][0], v2 = V[2][0], v3 = V[3][0];
+    if (N[1][1] > best) { best = N[1][1]; v0 = V[0][1]; v1 = V[1][1]; v2 = V[2][1]; v3 = V[3][1]; }
+    if (N[2][2] > best) { best = N[2][2]; v0 = V[0][2]; v1 = V[1][2]; v2 = V[2][2]; v3 = V[3][2]; }
+    if (N[3][3] > best) { best = N[3][3]; v0 = V[0][3]; v1 = V[1][3]; v2 = V[2][3]; v3 = V[3][3]; }
+    const double nrm = sqrt((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3));
+    q[0] = v0 / nrm; q[1] = v1 / nrm; q[2] = v2 / nrm; q[3] = v3 / nrm;
 }
 
 // Horn '87: rotation from the 3x3 weighted covariance M = sum_k w_k s_k t_k^T (rpmodule.py:43-56).

@@ -35,10 +35,11 @@ constexpr int RS = 224;         // internal resolution (mymodel.py:261)
 
 struct Src {
     const float* x;        // NHWC base (+ channel offset)
-    const float2* ss;      // [G][sstride] {scale, shift} (+ channel offset) or nullptr = identity
+    const float2* ss;      // [G][sstride] {scale, shift} (+ channel offset); identity table for the raw net input
     int cstride;           // floats per pixel
     int C;                 // channels read from this source
     int sstride;           // float2 per group
+    float slope;           // LeakyReLU slope applied after scale/shift (1.0 = no activation)
 };
 
 struct ConvDesc {
@@ -57,29 +58,33 @@ struct ConvDesc {
     int M, K;
 };
 
-__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU * v; }
+__device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, slope * v); }   // slope in (0,1]
 
 // Tile: WM x WN waves (WM*WN = 4), each wave MI x NI MFMA 32x32 blocks.
+// Both tiles are register-staged: the global loads of tile kt+1 (A values, their BatchNorm
+// scale/shift, B weights) are issued BEFORE the MFMAs of tile kt and consumed AFTER them, so their
+// latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
+// keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDesc d) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr int A_IT = BM / 64;                       // float4 slots per thread for the A tile
-    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr int B_IT = (BN + 63) / 64;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
     __shared__ int rowpix[BM];
+    __shared__ int tapoff[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int hw = d.Hp * d.Wp;
 
-    // loader rows of this thread
-    const int kq = tid & 3;
+    const int kq = tid & 3, lrow = tid >> 2;
     int r_img[A_IT], r_y[A_IT], r_x[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int m = m0 + (tid >> 2) + it * 64;
+        const int m = m0 + lrow + it * 64;
         if (m < d.M) {
             const int img = m / hw, rem = m - img * hw;
             const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDesc d) {
         }
         rowpix[tid] = pix;
     }
+    if (tid < 16) tapoff[tid] = ((int)d.offy[tid] << 16) | ((int)d.offx[tid] & 0xffff);
 
     floatx16 acc[MI][NI];
 #pragma unroll
@@ -105,62 +111,72 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDesc d) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_IT], rb[B_IT];
+    // B rows of this thread (BN < 64: rows are clamped, the extra threads re-load row BN-1 and never store)
+    const float* b_src[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int row = min(lrow + it * 64, BN - 1);
+        b_src[it] = d.w + (size_t)(n0 + row) * d.K + kq * 4;
+    }
+
+    float4 ra[A_IT], q0[A_IT], q1[A_IT];
+    float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0;
+    int okm = 0;
+    float slope = 1.f;
     const int nkt = d.K / BK;
     int tap = 0, c0 = 0;
+    __syncthreads();       // tapoff / rowpix visible
 
-    auto load_tile = [&](int kt) {
-        // source + tap of this k-tile (all 16 k's share them: Cin and C0 are multiples of 16)
-        const int s = (d.nsrc > 1 && c0 >= d.src[0].C) ? 1 : 0;
-        const Src& S = d.src[s];
-        const int cc = c0 - (s ? d.src[0].C : 0) + kq * 4;
-        const int oy = d.offy[tap], ox = d.offx[tap];
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int iy = r_y[it] + oy, ix = r_x[it] + ox;
-            if (r_img[it] >= 0 && iy >= 0 && iy < d.Hin && ix >= 0 && ix < d.Win) {
-                const size_t pix = ((size_t)r_img[it] * d.Hin + iy) * d.Win + ix;
-                v = *reinterpret_cast<const float4*>(S.x + pix * S.cstride + cc);
-                if (S.ss) {
-                    const float4* q = reinterpret_cast<const float4*>(S.ss + (size_t)(r_img[it] >> 1) * S.sstride + cc);
-                    const float4 q0 = q[0], q1 = q[1];      // {sc0,sh0,sc1,sh1} {sc2,sh2,sc3,sh3}
-                    v.x = lrelu(v.x * q0.x + q0.y); v.y = lrelu(v.y * q0.z + q0.w);
-                    v.z = lrelu(v.z * q1.x + q1.y); v.w = lrelu(v.w * q1.z + q1.w);
-                }
-            }
-            ra[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int slot = tid + it * 256;
-            const int row = slot >> 2;
-            if (BN * 4 >= 256 || slot < BN * 4)
-                rb[it] = *reinterpret_cast<const float4*>(d.w + (size_t)(n0 + row) * d.K + (size_t)kt * BK + kq * 4);
-        }
-        c0 += BK;
-        if (c0 == d.Cin) { c0 = 0; ++tap; }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it)
-            *reinterpret_cast<float4*>(&As[buf][((tid >> 2) + it * 64) * LDK + kq * 4]) = ra[it];
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int slot = tid + it * 256;
-            if (BN * 4 >= 256 || slot < BN * 4)
-                *reinterpret_cast<float4*>(&Bs[buf][(slot >> 2) * LDK + kq * 4]) = rb[it];
-        }
-    };
+#define RP_ISSUE_LOADS(KT)                                                                                        \
+    {                                                                                                             \
+        const bool s1_ = (d.nsrc > 1) && (c0 >= d.src[0].C);                                                      \
+        const float* sx_ = s1_ ? d.src[1].x : d.src[0].x;                                                         \
+        const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                                     \
+        const int scs_ = s1_ ? d.src[1].cstride : d.src[0].cstride;                                               \
+        const int sst_ = s1_ ? d.src[1].sstride : d.src[0].sstride;                                               \
+        slope = s1_ ? d.src[1].slope : d.src[0].slope;                                                            \
+        const int cc_ = c0 - (s1_ ? d.src[0].C : 0) + kq * 4;                                                     \
+        const int to_ = tapoff[tap];                                                                              \
+        const int oy_ = to_ >> 16, ox_ = (int)(short)(to_ & 0xffff);                                              \
+        okm = 0;                                                                                                  \
+        _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
+            const int iy = r_y[it] + oy_, ix = r_x[it] + ox_;                                                     \
+            const bool ok_ = (r_img[it] >= 0) & (iy >= 0) & (iy < d.Hin) & (ix >= 0) & (ix < d.Win);               \
+            okm |= ok_ ? (1 << it) : 0;                                                                           \
+            const int im_ = ok_ ? r_img[it] : 0;                                                                  \
+            const size_t pix = ok_ ? ((size_t)im_ * d.Hin + iy) * d.Win + ix : 0;                                 \
+            ra[it] = *reinterpret_cast<const float4*>(sx_ + pix * scs_ + cc_);                                    \
+            const float4* q = reinterpret_cast<const float4*>(sss_ + (size_t)(im_ >> 1) * sst_ + cc_);            \
+            q0[it] = q[0]; q1[it] = q[1];                                                                         \
+        }                                                                                                         \
+        rb0 = *reinterpret_cast<const float4*>(b_src[0] + (size_t)(KT) * BK);                                     \
+        if (B_IT > 1) rb1 = *reinterpret_cast<const float4*>(b_src[B_IT - 1] + (size_t)(KT) * BK);                \
+        c0 += BK;                                                                                                 \
+        if (c0 == d.Cin) { c0 = 0; ++tap; }                                                                       \
+    }
 
-    load_tile(0);
-    store_tile(0);
+#define RP_STORE_TILE(BUF)                                                                                        \
+    {                                                                                                             \
+        _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
+            float4 v = ra[it];                                                                                    \
+            v.x = lrelu(v.x * q0[it].x + q0[it].y, slope); v.y = lrelu(v.y * q0[it].z + q0[it].w, slope);         \
+            v.z = lrelu(v.z * q1[it].x + q1[it].y, slope); v.w = lrelu(v.w * q1[it].z + q1[it].w, slope);         \
+            const bool ok_ = (okm >> it) & 1;                                                                     \
+            v.x = ok_ ? v.x : 0.f; v.y = ok_ ? v.y : 0.f; v.z = ok_ ? v.z : 0.f; v.w = ok_ ? v.w : 0.f;           \
+            *reinterpret_cast<float4*>(&As[BUF][(lrow + it * 64) * LDK + kq * 4]) = v;                            \
+        }                                                                                                         \
+        if (BN >= 64 || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb0;               \
+        if (B_IT > 1) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + 64) * LDK + kq * 4]) = rb1;                     \
+    }
+
+    RP_ISSUE_LOADS(0)
+    RP_STORE_TILE(0)
     __syncthreads();
     const int arow = (wm * MI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     const int brow = (wn * NI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             float4 a[MI], b[NI];
@@ -178,11 +194,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDesc d) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        if (kt + 1 < nkt) RP_STORE_TILE(buf ^ 1)
         __syncthreads();
     }
+#undef RP_ISSUE_LOADS
+#undef RP_STORE_TILE
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float bias_v[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * NI * 32 + j * 32 + (lane & 31);
+        bias_v[j] = (d.bias && col < d.Cout) ? d.bias[col] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -195,8 +219,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDesc d) {
             for (int j = 0; j < NI; ++j) {
                 const int col = n0 + wn * NI * 32 + j * 32 + (lane & 31);
                 if (col < d.Cout) {
-                    float v = acc[i][j][r];
-                    if (d.bias) v += d.bias[col];
+                    float v = acc[i][j][r] + bias_v[j];
                     if (d.tanh_out) v = tanhf(v);
                     yo[col] = v;
                 }
@@ -335,6 +358,7 @@ struct RelposeSCNet {
     // device
     float* d_w = nullptr;        // packed weights + biases
     float* d_gb = nullptr;       // gamma/beta per activation buffer [2][C]
+    float2* d_ident = nullptr;   // 16 x {1,0}: scale/shift of the raw network input
     std::map<std::string, Layer> layers;
     std::map<std::string, Buf> bufs;
     size_t per_image_floats = 0, ss_float2_per_group = 0;
@@ -526,7 +550,8 @@ struct Runner {
     Src src(const std::string& b, int choff, int C) {
         const Buf& B = net->bufs[b];
         Src r; r.x = buf(b) + choff; r.cstride = B.C; r.C = C; r.sstride = B.C;
-        r.ss = (b == "X0") ? nullptr : ssb(b) + choff;
+        if (b == "X0") { r.ss = net->d_ident; r.sstride = 0; r.slope = 1.f; }
+        else { r.ss = ssb(b) + choff; r.slope = LRELU; }
         return r;
     }
 
@@ -611,6 +636,7 @@ void relpose_scnet_destroy(RelposeSCNet* net) {
     if (!net) return;
     if (net->d_w) hipFree(net->d_w);
     if (net->d_gb) hipFree(net->d_gb);
+    if (net->d_ident) hipFree(net->d_ident);
     delete net;
 }
 
@@ -667,6 +693,12 @@ int relpose_scnet_finalize(RelposeSCNet* net) {
     RP_HIP(hipMemcpy(net->d_w, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     RP_HIP(hipMalloc((void**)&net->d_gb, gb.size() * sizeof(float)));
     RP_HIP(hipMemcpy(net->d_gb, gb.data(), gb.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!net->d_ident) {
+        float2 id[16];
+        for (int i = 0; i < 16; ++i) id[i] = make_float2(1.f, 0.f);
+        RP_HIP(hipMalloc((void**)&net->d_ident, sizeof(id)));
+        RP_HIP(hipMemcpy(net->d_ident, id, sizeof(id), hipMemcpyHostToDevice));
+    }
     net->finalized = true;
     return 0;
 }
