@@ -25,6 +25,7 @@
 #define RP_MAXK 8
 #define RP_FEAT 32
 #define RP_FIT_THREADS 512
+#define RP_EIG_MAX_ITERS 64
 #define RP_EPS 1e-12
 #define RP_OFFSET 50.0
 
@@ -45,6 +46,7 @@ struct Graph {                 // per-batch device arrays of the pair-compatibil
     double* wv;                // [B, max_edges]
     double* xe;                // [B, max_edges]
     double* state;             // [B, 4, Cmax]  deg, gP, gN, rsum
+    double* geo;               // [B, Cmax, 12]  sp, tp, sn, tn of every correspondence (gathered once per fit)
 };
 
 __device__ __forceinline__ int pair_C(const RelposeKeypoints& kp, const Graph& g, int b) {
@@ -305,25 +307,17 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Gra
 
 // ------------------------------------------------------------------ fit
 struct FitCtx {
-    const double *pc_s, *pc_t, *normal_s, *normal_t;
-    const int32_t* corres_j;
-    int ns_max, nt_max;
-    int b, C, keff, topK;
+    const double* geo;      // [C][12] of this pair
+    int b, C;
     double mu;
     double* deg; double* gP; double* gN; double* rsum;
     double* red;        // LDS reduction scratch
 };
 
 __device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, double* tp, double* sn, double* tn) {
-    int i = c / f.keff, kk = c - i * f.keff;
-    size_t si = (size_t)f.b * f.ns_max + i;
-    int j = f.corres_j[si * f.topK + kk];
-    size_t ti = (size_t)f.b * f.nt_max + j;
+    const double* g = f.geo + (size_t)c * 12;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        sp[a] = f.pc_s[si * 3 + a]; sn[a] = f.normal_s[si * 3 + a];
-        tp[a] = f.pc_t[ti * 3 + a]; tn[a] = f.normal_t[ti * 3 + a];
-    }
+    for (int a = 0; a < 3; ++a) { sp[a] = g[a]; tp[a] = g[3 + a]; sn[a] = g[6 + a]; tn[a] = g[9 + a]; }
 }
 
 // centre with position weights, Horn, residuals; optionally IRLS-reweight (rpmodule.py:236-255).
@@ -413,6 +407,7 @@ __global__ __launch_bounds__(RP_FIT_THREADS) void fit_kernel(RelposeKeypoints kp
     double* y = u + g.Cmax;               // [Cmax]
     double* h = y + g.Cmax;               // [Cmax]
     double* red = h + g.Cmax;             // [9*16 + 16]
+    int* rp = (int*)(red + 9 * 16 + 16);  // [Cmax + 1] CSR row pointers
     __shared__ int flag_s;
     int st = status[b];
     if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
@@ -432,13 +427,29 @@ __global__ __launch_bounds__(RP_FIT_THREADS) void fit_kernel(RelposeKeypoints kp
         return;
     }
     FitCtx f;
-    f.pc_s = kp.pc_s; f.pc_t = kp.pc_t; f.normal_s = kp.normal_s; f.normal_t = kp.normal_t;
-    f.corres_j = g.corres_j; f.ns_max = kp.ns_max; f.nt_max = kp.nt_max; f.b = b; f.C = C; f.keff = g.keff[b]; f.topK = topK; f.mu = kc.mu;
+    f.b = b; f.C = C; f.mu = kc.mu;
     f.deg = g.state + ((size_t)b * 4 + 0) * g.Cmax; f.gP = g.state + ((size_t)b * 4 + 1) * g.Cmax;
     f.gN = g.state + ((size_t)b * 4 + 2) * g.Cmax; f.rsum = g.state + ((size_t)b * 4 + 3) * g.Cmax;
     f.red = red;
+    {   // gather the geometry of every correspondence once (coalesced re-reads in every IRLS pass)
+        double* geo = g.geo + (size_t)b * g.Cmax * 12;
+        const int keff = g.keff[b];
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const int i = c / keff, kk = c - i * keff;
+            const size_t si = (size_t)b * kp.ns_max + i;
+            const int j = g.corres_j[si * topK + kk];
+            const size_t ti = (size_t)b * kp.nt_max + j;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                geo[(size_t)c * 12 + a] = kp.pc_s[si * 3 + a]; geo[(size_t)c * 12 + 3 + a] = kp.pc_t[ti * 3 + a];
+                geo[(size_t)c * 12 + 6 + a] = kp.normal_s[si * 3 + a]; geo[(size_t)c * 12 + 9 + a] = kp.normal_t[ti * 3 + a];
+            }
+        }
+        f.geo = geo;
+    }
     const size_t eoff = (size_t)b * g.max_edges;
-    const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
+    for (int c = threadIdx.x; c <= C; c += blockDim.x) rp[c] = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
+    __syncthreads();
     const int32_t* col = g.col + eoff;
     const double* wv = g.wv + eoff;
     double* xe = g.xe + eoff;
@@ -471,18 +482,39 @@ __global__ __launch_bounds__(RP_FIT_THREADS) void fit_kernel(RelposeKeypoints kp
             __syncthreads();
             const bool use_xe = (method == RELPOSE_FIT_SPECTRAL) && round > 0;
             int iters = 0;
-            for (; iters < 300; ++iters) {
-                for (int c = grp; c < C; c += ngrp) {
-                    double s = 0.0;
-                    const double hc = h[c];
-                    for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) {
-                        const int cc = col[k];
-                        const double base = use_xe ? f.mu * xe[k] : wv[k];
-                        s += (base * (hc + h[cc])) * u[cc];
+            for (; iters < RP_EIG_MAX_ITERS; ++iters) {
+                // y = A u, A[c][cc] = base*(h[c]+h[cc]); 16 lanes per row, 4 rows in flight per group so the
+                // L2 latency of the col/wv reads overlaps (rows are short: ~2M/C = 20-45 entries)
+                for (int cb = grp * 4; cb < C; cb += ngrp * 4) {
+                    int k0[4], k1[4], cc0[4];
+                    double w0[4], sacc[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = min(cb + r, C - 1);
+                        k0[r] = rp[c] + gl; k1[r] = (cb + r < C) ? rp[c + 1] : 0;
+                        sacc[r] = 0.0; cc0[r] = 0; w0[r] = 0.0;
                     }
 #pragma unroll
-                    for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
-                    if (gl == 0) y[c] = s;
+                    for (int r = 0; r < 4; ++r)
+                        if (k0[r] < k1[r]) { cc0[r] = col[k0[r]]; w0[r] = use_xe ? f.mu * xe[k0[r]] : wv[k0[r]]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = min(cb + r, C - 1);
+                        const double hc = h[c];
+                        if (k0[r] < k1[r]) sacc[r] += (w0[r] * (hc + h[cc0[r]])) * u[cc0[r]];
+                        for (int k = k0[r] + 16; k < k1[r]; k += 16) {
+                            const int cc = col[k];
+                            const double base = use_xe ? f.mu * xe[k] : wv[k];
+                            sacc[r] += (base * (hc + h[cc])) * u[cc];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double sv = sacc[r];
+#pragma unroll
+                        for (int m = 8; m >= 1; m >>= 1) sv += rp_shfl_xor_d(sv, m);
+                        if (gl == 0 && cb + r < C) y[cb + r] = sv;
+                    }
                 }
                 __syncthreads();
                 double n2[1] = {0.0};
@@ -571,7 +603,7 @@ int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* w
 }
 
 struct WsLayout {
-    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, total;
+    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, total;
     int32_t Cmax, Wmax;
     int64_t max_edges;
 };
@@ -597,6 +629,7 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.wv = take((size_t)B * L.max_edges * 8);
     L.xe = take((size_t)B * L.max_edges * 8);
     L.state = take((size_t)B * 4 * L.Cmax * 8);
+    L.geo = take((size_t)B * L.Cmax * 12 * 8);
     L.total = o;
     return L;
 }
@@ -631,7 +664,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     if (p->method < 0 || p->method > 3) return RELPOSE_EINVAL;
     const WsLayout L = ws_layout(kp->B, kp->ns_max, p->topK, max_edges);
     if (workspace_bytes < L.total) return RELPOSE_ENOMEM;
-    if ((size_t)L.Cmax * 24 + (9 * 16 + 16) * 8 > 150 * 1024) return RELPOSE_EINVAL;
+    if ((size_t)L.Cmax * 28 + (9 * 16 + 16) * 8 + 16 > 150 * 1024) return RELPOSE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     int32_t* cj = (int32_t*)(ws + L.corres_j);
@@ -643,7 +676,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     g.bitmap = (unsigned long long*)(ws + L.bitmap);
     g.upcnt = (int32_t*)(ws + L.upcnt); g.lowcnt = (int32_t*)(ws + L.lowcnt); g.counters = (int32_t*)(ws + L.counters);
     g.rowptr = (int32_t*)(ws + L.rowptr); g.col = (int32_t*)(ws + L.col);
-    g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state);
+    g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state); g.geo = (double*)(ws + L.geo);
     RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
     int rc = launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
     if (rc) return rc;
@@ -655,7 +688,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     RP_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_fill_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK, status);
     RP_CHECK_LAUNCH();
-    const size_t lds = (size_t)L.Cmax * 24 + (9 * 16 + 16) * 8;
+    const size_t lds = (size_t)L.Cmax * 28 + (9 * 16 + 16) * 8 + 16;
     RP_HIP(hipFuncSetAttribute((const void*)fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fit_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), lds, s, *kp, g, kc, p->topK, p->method, status, pose,
                        dbg ? dbg->trace : nullptr, dbg ? dbg->eig_iters : nullptr, dbg ? dbg->counts : nullptr);
