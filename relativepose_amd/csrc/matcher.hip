@@ -396,171 +396,205 @@ __device__ __forceinline__ void write_pose(double* out, const double R[3][3], co
     }
 }
 
-__global__ __launch_bounds__(RP_FIT_THREADS) void fit_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK, int method,
-                                                              int32_t* __restrict__ status, double* __restrict__ pose,
-                                                              double* __restrict__ trace, int32_t* __restrict__ eig_iters,
-                                                              int32_t* __restrict__ counts_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x;
+// ---- fit as a launch sequence over ALL pairs (no host sync; kernels of finished / failed pairs exit at once)
+//   fit_begin        status finalisation, geometry gather, degrees with the raw pair weights
+//   fit_irls         one workgroup per pair: n x {centre, Horn, residuals[, reweight]}; writes pose / trace
+//   eig_init         h = relu(50 - r), uniform start vector
+//   eig_spmv         y = A u, rows spread over the whole GPU (16 lanes per CSR row), per-block sum of squares
+//   eig_norm         u = y/|y| (fixed-order reduction of the partials), convergence flag
+//   eig_finish       x = relu(u_i u_j) w per edge, new weighted degrees
+// The host enqueues the ~80 spmv/norm launches of a spectral round back to back; each is a few us.
+struct FitState {
+    double* u;        // [B, Cmax] current unit vector
+    double* y;        // [B, Cmax]
+    double* h;        // [B, Cmax]
+    double* part;     // [B, nblk] per-block sum of squares of y
+    int32_t* done;    // [B] eigen iteration converged
+    int32_t* iters;   // [B]
+    int nblk;
+};
+
+__device__ __forceinline__ bool pair_active(const int32_t* status, int b) { return status[b] == RELPOSE_OK; }
+
+__global__ __launch_bounds__(256) void fit_begin_kernel(RelposeKeypoints kp, Graph g, int topK, int32_t* __restrict__ status,
+                                                         double* __restrict__ pose, double* __restrict__ trace,
+                                                         int32_t* __restrict__ counts_out) {
+    const int b = blockIdx.y;
     const int C = pair_C(kp, g, b);
-    double* u = (double*)smem;            // [Cmax]
-    double* y = u + g.Cmax;               // [Cmax]
-    double* h = y + g.Cmax;               // [Cmax]
-    double* red = h + g.Cmax;             // [9*16 + 16]
-    int* rp = (int*)(red + 9 * 16 + 16);  // [Cmax + 1] CSR row pointers
-    __shared__ int flag_s;
-    int st = status[b];
-    if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
+    __shared__ int st_s;
     if (threadIdx.x == 0) {
-        status[b] = st;
-        if (counts_out) {
+        int st = status[b];
+        if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
+        st_s = st;
+    }
+    __syncthreads();
+    const int st = st_s;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && counts_out) {
             counts_out[b * 4 + 0] = g.counters[b * 4 + 0];
             counts_out[b * 4 + 1] = g.counters[b * 4 + 1];
             counts_out[b * 4 + 2] = g.counters[b * 4 + 2] / 2;
             counts_out[b * 4 + 3] = (kp.ns[b] >= 3 && kp.nt[b] >= 3) ? g.keff[b] : 0;
         }
+        if (st != RELPOSE_OK) {                       // identity, like the reference's early returns
+            if (threadIdx.x < 16) pose[(size_t)b * 16 + threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;
+            if (trace && threadIdx.x < 96) trace[(size_t)b * 96 + threadIdx.x] = ((threadIdx.x % 16) % 5 == 0) ? 1.0 : 0.0;
+        }
     }
-    double* P = pose + (size_t)b * 16;
-    if (st != RELPOSE_OK) {
-        if (threadIdx.x < 16) P[threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;
-        if (trace) for (int q = threadIdx.x; q < 96; q += blockDim.x) trace[(size_t)b * 96 + q] = ((q % 16) % 5 == 0) ? 1.0 : 0.0;
-        return;
+    if (st != RELPOSE_OK) return;
+    const int keff = g.keff[b];
+    const size_t eoff = (size_t)b * g.max_edges;
+    const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
+    double* geo = g.geo + (size_t)b * g.Cmax * 12;
+    double* st4 = g.state + (size_t)b * 4 * g.Cmax;
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + grp;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) s += g.wv[eoff + k];
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
+    if (gl == 0) { st4[c] = s; st4[g.Cmax + c] = 1.0; st4[2 * g.Cmax + c] = 1.0; st4[3 * g.Cmax + c] = 0.0; }
+    if (gl < 12) {
+        const int i = c / keff, kk = c - i * keff;
+        const size_t si = (size_t)b * kp.ns_max + i;
+        const int j = g.corres_j[si * topK + kk];
+        const size_t ti = (size_t)b * kp.nt_max + j;
+        const int a = gl % 3, what = gl / 3;
+        const double v = what == 0 ? kp.pc_s[si * 3 + a] : what == 1 ? kp.pc_t[ti * 3 + a] : what == 2 ? kp.normal_s[si * 3 + a]
+                                                                                                            : kp.normal_t[ti * 3 + a];
+        geo[(size_t)c * 12 + gl] = v;
     }
+}
+
+// status is committed separately so that every block of fit_begin sees the same (pre-commit) value
+__global__ void fit_commit_status_kernel(Graph g, int32_t* __restrict__ status, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && status[b] == RELPOSE_OK && g.counters[b * 4 + 2] < 1) status[b] = RELPOSE_ZERO_WEIGHT;
+}
+
+__global__ __launch_bounds__(RP_FIT_THREADS) void fit_irls_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int n_iter, int reweight,
+                                                                   int reset_g, const int32_t* __restrict__ status,
+                                                                   double* __restrict__ pose, double* __restrict__ trace_slot) {
+    __shared__ double red[9 * 16 + 16];
+    const int b = blockIdx.x;
+    if (!pair_active(status, b)) return;
     FitCtx f;
-    f.b = b; f.C = C; f.mu = kc.mu;
+    f.b = b; f.C = pair_C(kp, g, b); f.mu = kc.mu;
     f.deg = g.state + ((size_t)b * 4 + 0) * g.Cmax; f.gP = g.state + ((size_t)b * 4 + 1) * g.Cmax;
     f.gN = g.state + ((size_t)b * 4 + 2) * g.Cmax; f.rsum = g.state + ((size_t)b * 4 + 3) * g.Cmax;
     f.red = red;
-    {   // gather the geometry of every correspondence once (coalesced re-reads in every IRLS pass)
-        double* geo = g.geo + (size_t)b * g.Cmax * 12;
-        const int keff = g.keff[b];
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            const int i = c / keff, kk = c - i * keff;
-            const size_t si = (size_t)b * kp.ns_max + i;
-            const int j = g.corres_j[si * topK + kk];
-            const size_t ti = (size_t)b * kp.nt_max + j;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                geo[(size_t)c * 12 + a] = kp.pc_s[si * 3 + a]; geo[(size_t)c * 12 + 3 + a] = kp.pc_t[ti * 3 + a];
-                geo[(size_t)c * 12 + 6 + a] = kp.normal_s[si * 3 + a]; geo[(size_t)c * 12 + 9 + a] = kp.normal_t[ti * 3 + a];
-            }
-        }
-        f.geo = geo;
+    f.geo = g.geo + (size_t)b * g.Cmax * 12;
+    if (reset_g) {
+        for (int c = threadIdx.x; c < f.C; c += blockDim.x) { f.gP[c] = 1.0; f.gN[c] = 1.0; }
+        __syncthreads();
     }
-    const size_t eoff = (size_t)b * g.max_edges;
-    for (int c = threadIdx.x; c <= C; c += blockDim.x) rp[c] = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
-    __syncthreads();
-    const int32_t* col = g.col + eoff;
-    const double* wv = g.wv + eoff;
-    double* xe = g.xe + eoff;
-    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, ngrp = blockDim.x >> 4;
-
-    // weighted degree with the raw pair weights (allWP = [w, w], rpmodule.py:488)
-    for (int c = grp; c < C; c += ngrp) {
-        double s = 0.0;
-        for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) s += wv[k];
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
-        if (gl == 0) f.deg[c] = s;
-    }
-    for (int c = threadIdx.x; c < C; c += blockDim.x) { f.gP[c] = 1.0; f.gN[c] = 1.0; }
-    __syncthreads();
-
     double R[3][3], t[3];
-    const int n_irls = (method == RELPOSE_FIT_HORN87 || method == RELPOSE_FIT_SPECTRAL) ? 1 : 5;
-    for (int it = 0; it < n_irls; ++it) fit_solve(f, n_irls > 1, R, t);
-    if (trace) write_pose(trace + (size_t)b * 96, R, t);
+    for (int it = 0; it < n_iter; ++it) fit_solve(f, reweight != 0, R, t);
+    write_pose(pose + (size_t)b * 16, R, t);
+    if (trace_slot) write_pose(trace_slot + (size_t)b * 96, R, t);
+}
 
-    if (method == RELPOSE_FIT_IRLS_SM || method == RELPOSE_FIT_SPECTRAL) {
-        for (int round = 0; round < 5; ++round) {
-            // a = base * relu(50 - r), summed over the two halves (rpmodule.py:262-267): base*(h[c1]+h[c2])
-            for (int c = threadIdx.x; c < C; c += blockDim.x) {
-                double v = RP_OFFSET - f.rsum[c];
-                h[c] = v < 0.0 ? 0.0 : v;
-                u[c] = 1.0 / sqrt((double)C);
-            }
-            __syncthreads();
-            const bool use_xe = (method == RELPOSE_FIT_SPECTRAL) && round > 0;
-            int iters = 0;
-            for (; iters < RP_EIG_MAX_ITERS; ++iters) {
-                // y = A u, A[c][cc] = base*(h[c]+h[cc]); 16 lanes per row, 4 rows in flight per group so the
-                // L2 latency of the col/wv reads overlaps (rows are short: ~2M/C = 20-45 entries)
-                for (int cb = grp * 4; cb < C; cb += ngrp * 4) {
-                    int k0[4], k1[4], cc0[4];
-                    double w0[4], sacc[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = min(cb + r, C - 1);
-                        k0[r] = rp[c] + gl; k1[r] = (cb + r < C) ? rp[c + 1] : 0;
-                        sacc[r] = 0.0; cc0[r] = 0; w0[r] = 0.0;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (k0[r] < k1[r]) { cc0[r] = col[k0[r]]; w0[r] = use_xe ? f.mu * xe[k0[r]] : wv[k0[r]]; }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = min(cb + r, C - 1);
-                        const double hc = h[c];
-                        if (k0[r] < k1[r]) sacc[r] += (w0[r] * (hc + h[cc0[r]])) * u[cc0[r]];
-                        for (int k = k0[r] + 16; k < k1[r]; k += 16) {
-                            const int cc = col[k];
-                            const double base = use_xe ? f.mu * xe[k] : wv[k];
-                            sacc[r] += (base * (hc + h[cc])) * u[cc];
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        double sv = sacc[r];
-#pragma unroll
-                        for (int m = 8; m >= 1; m >>= 1) sv += rp_shfl_xor_d(sv, m);
-                        if (gl == 0 && cb + r < C) y[cb + r] = sv;
-                    }
-                }
-                __syncthreads();
-                double n2[1] = {0.0};
-                for (int c = threadIdx.x; c < C; c += blockDim.x) n2[0] += y[c] * y[c];
-                rp_block_sum<1>(n2, red);
-                const double nrm = sqrt(n2[0]);
-                if (!(nrm > 0.0)) break;                 // zero matrix: keep the uniform vector
-                int moved = 0;
-                for (int c = threadIdx.x; c < C; c += blockDim.x) {
-                    const double un = y[c] / nrm;
-                    if (fabs(un - u[c]) > 1e-15) moved = 1;
-                    u[c] = un;
-                }
-                if (threadIdx.x == 0) flag_s = 0;
-                __syncthreads();
-                if (moved) flag_s = 1;
-                __syncthreads();
-                const int any = flag_s;
-                __syncthreads();
-                if (!any) { ++iters; break; }
-            }
-            if (eig_iters && threadIdx.x == 0) eig_iters[b * 5 + round] = iters;
-            // x = relu(u[c1]*u[c2]) * w  (rpmodule.py:277-280); new degrees
-            for (int c = grp; c < C; c += ngrp) {
-                double s = 0.0;
-                const double uc = u[c];
-                for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) {
-                    double x = uc * u[col[k]];
-                    x = (x < 0.0 ? 0.0 : x) * wv[k];
-                    xe[k] = x;
-                    s += x;
-                }
-#pragma unroll
-                for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
-                if (gl == 0) f.deg[c] = s;
-            }
-            for (int c = threadIdx.x; c < C; c += blockDim.x) { f.gP[c] = 1.0; f.gN[c] = 1.0; }
-            __syncthreads();
-            const int n_in = (method == RELPOSE_FIT_SPECTRAL) ? 1 : 5;
-            for (int it = 0; it < n_in; ++it) fit_solve(f, n_in > 1, R, t);
-            if (trace) write_pose(trace + (size_t)b * 96 + (round + 1) * 16, R, t);
+__global__ __launch_bounds__(256) void eig_init_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status) {
+    const int b = blockIdx.y;
+    if (!pair_active(status, b)) return;
+    const int C = pair_C(kp, g, b);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) { fs.done[b] = 0; fs.iters[b] = 0; }
+    if (c >= C) return;
+    const double v = RP_OFFSET - g.state[((size_t)b * 4 + 3) * g.Cmax + c];
+    fs.h[(size_t)b * g.Cmax + c] = v < 0.0 ? 0.0 : v;
+    fs.u[(size_t)b * g.Cmax + c] = 1.0 / sqrt((double)C);
+}
+
+// a = base*(h[c]+h[cc]) (rpmodule.py:262-267 summed over the two halves); base = w, or mu*x for 'spectral' rounds > 0
+__global__ __launch_bounds__(256) void eig_spmv_kernel(RelposeKeypoints kp, Graph g, FitState fs, double mu_xe,
+                                                        const int32_t* __restrict__ status) {
+    __shared__ double wsum[4];
+    const int b = blockIdx.y;
+    if (!pair_active(status, b) || fs.done[b]) return;
+    const int C = pair_C(kp, g, b);
+    if (blockIdx.x * 16 >= C) return;
+    const size_t eoff = (size_t)b * g.max_edges;
+    const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
+    const double* u = fs.u + (size_t)b * g.Cmax;
+    const double* h = fs.h + (size_t)b * g.Cmax;
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + grp;
+    double s = 0.0;
+    if (c < C) {
+        const double hc = h[c];
+        for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) {
+            const int cc = g.col[eoff + k];
+            const double base = mu_xe != 0.0 ? mu_xe * g.xe[eoff + k] : g.wv[eoff + k];
+            s += (base * (hc + h[cc])) * u[cc];
         }
-    } else if (trace) {
-        for (int q = 1; q < 6; ++q) write_pose(trace + (size_t)b * 96 + q * 16, R, t);
     }
-    write_pose(P, R, t);
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
+    if (c < C && gl == 0) fs.y[(size_t)b * g.Cmax + c] = s;
+    // per-block sum of squares (fixed order: 4 rows per wave via lanes 0,16,32,48; then 4 waves)
+    double q = (gl == 0 && c < C) ? s * s : 0.0;
+    q += rp_shfl_xor_d(q, 16); q += rp_shfl_xor_d(q, 32);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) fs.part[(size_t)b * fs.nblk + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(256) void eig_norm_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status) {
+    __shared__ double red[16];
+    __shared__ int flag;
+    const int b = blockIdx.x;
+    if (!pair_active(status, b) || fs.done[b]) return;
+    const int C = pair_C(kp, g, b);
+    const int nb = (C + 15) / 16;
+    double a[1] = {0.0};
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) a[0] += fs.part[(size_t)b * fs.nblk + i];
+    rp_block_sum<1>(a, red);
+    const double nrm = sqrt(a[0]);
+    if (threadIdx.x == 0) flag = 0;
+    __syncthreads();
+    if (!(nrm > 0.0)) {                                  // zero matrix: keep the current vector, stop
+        if (threadIdx.x == 0) fs.done[b] = 1;
+        return;
+    }
+    int moved = 0;
+    double* u = fs.u + (size_t)b * g.Cmax;
+    const double* y = fs.y + (size_t)b * g.Cmax;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double un = y[c] / nrm;
+        if (fabs(un - u[c]) > 1e-15) moved = 1;
+        u[c] = un;
+    }
+    if (moved) flag = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) { fs.iters[b] += 1; if (!flag) fs.done[b] = 1; }
+}
+
+// x = relu(u[c1]*u[c2]) * w  (rpmodule.py:277-280) and the new weighted degrees
+__global__ __launch_bounds__(256) void eig_finish_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status,
+                                                          int32_t* __restrict__ eig_iters_out) {
+    const int b = blockIdx.y;
+    if (!pair_active(status, b)) return;
+    const int C = pair_C(kp, g, b);
+    const size_t eoff = (size_t)b * g.max_edges;
+    const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
+    const double* u = fs.u + (size_t)b * g.Cmax;
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + grp;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && eig_iters_out) *(eig_iters_out + b * 5) = fs.iters[b];
+    if (c >= C) return;
+    const double uc = u[c];
+    double s = 0.0;
+    for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) {
+        double x = uc * u[g.col[eoff + k]];
+        x = (x < 0.0 ? 0.0 : x) * g.wv[eoff + k];
+        g.xe[eoff + k] = x;
+        s += x;
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
+    if (gl == 0) g.state[((size_t)b * 4 + 0) * g.Cmax + c] = s;
 }
 
 RpPairConsts make_consts(const RelposeParams& p) {
@@ -603,7 +637,7 @@ int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* w
 }
 
 struct WsLayout {
-    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, total;
+    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, eig, total;
     int32_t Cmax, Wmax;
     int64_t max_edges;
 };
@@ -630,6 +664,7 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.xe = take((size_t)B * L.max_edges * 8);
     L.state = take((size_t)B * 4 * L.Cmax * 8);
     L.geo = take((size_t)B * L.Cmax * 12 * 8);
+    L.eig = take((size_t)B * (3 * (size_t)L.Cmax + (L.Cmax + 15) / 16) * 8 + (size_t)B * 2 * 4);
     L.total = o;
     return L;
 }
@@ -664,7 +699,6 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     if (p->method < 0 || p->method > 3) return RELPOSE_EINVAL;
     const WsLayout L = ws_layout(kp->B, kp->ns_max, p->topK, max_edges);
     if (workspace_bytes < L.total) return RELPOSE_ENOMEM;
-    if ((size_t)L.Cmax * 28 + (9 * 16 + 16) * 8 + 16 > 150 * 1024) return RELPOSE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     int32_t* cj = (int32_t*)(ws + L.corres_j);
@@ -688,11 +722,42 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     RP_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_fill_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK, status);
     RP_CHECK_LAUNCH();
-    const size_t lds = (size_t)L.Cmax * 28 + (9 * 16 + 16) * 8 + 16;
-    RP_HIP(hipFuncSetAttribute((const void*)fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fit_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), lds, s, *kp, g, kc, p->topK, p->method, status, pose,
-                       dbg ? dbg->trace : nullptr, dbg ? dbg->eig_iters : nullptr, dbg ? dbg->counts : nullptr);
+    // ---- fit: launch sequence (see fit_begin_kernel)
+    FitState fs;
+    fs.nblk = (L.Cmax + 15) / 16;
+    fs.u = (double*)(ws + L.eig); fs.y = fs.u + (size_t)kp->B * L.Cmax; fs.h = fs.y + (size_t)kp->B * L.Cmax;
+    fs.part = fs.h + (size_t)kp->B * L.Cmax;
+    fs.done = (int32_t*)(fs.part + (size_t)kp->B * fs.nblk); fs.iters = fs.done + kp->B;
+    double* trace = dbg ? dbg->trace : nullptr;
+    int32_t* eig_iters = dbg ? dbg->eig_iters : nullptr;
+    dim3 grid16(fs.nblk, kp->B);
+    hipLaunchKernelGGL(fit_begin_kernel, grid16, dim3(256), 0, s, *kp, g, p->topK, status, pose, trace, dbg ? dbg->counts : nullptr);
+    hipLaunchKernelGGL(fit_commit_status_kernel, dim3((kp->B + 63) / 64), dim3(64), 0, s, g, status, kp->B);
     RP_CHECK_LAUNCH();
+    const int m = p->method;
+    const bool irls0 = (m == RELPOSE_FIT_IRLS_SM || m == RELPOSE_FIT_IRLS);
+    hipLaunchKernelGGL(fit_irls_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), 0, s, *kp, g, kc, irls0 ? 5 : 1, irls0 ? 1 : 0, 0, status, pose,
+                       trace);
+    RP_CHECK_LAUNCH();
+    if (m == RELPOSE_FIT_IRLS_SM || m == RELPOSE_FIT_SPECTRAL) {
+        const bool sm = (m == RELPOSE_FIT_IRLS_SM);
+        for (int round = 0; round < 5; ++round) {
+            hipLaunchKernelGGL(eig_init_kernel, dim3((L.Cmax + 255) / 256, kp->B), dim3(256), 0, s, *kp, g, fs, status);
+            const double mu_xe = (!sm && round > 0) ? p->mu : 0.0;
+            for (int it = 0; it < RP_EIG_MAX_ITERS; ++it) {
+                hipLaunchKernelGGL(eig_spmv_kernel, grid16, dim3(256), 0, s, *kp, g, fs, mu_xe, status);
+                hipLaunchKernelGGL(eig_norm_kernel, dim3(kp->B), dim3(256), 0, s, *kp, g, fs, status);
+            }
+            hipLaunchKernelGGL(eig_finish_kernel, grid16, dim3(256), 0, s, *kp, g, fs, status, eig_iters ? eig_iters + round : nullptr);
+            hipLaunchKernelGGL(fit_irls_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), 0, s, *kp, g, kc, sm ? 5 : 1, sm ? 1 : 0, 1, status, pose,
+                               trace ? trace + (round + 1) * 16 : nullptr);
+            RP_CHECK_LAUNCH();
+        }
+    } else if (trace) {
+        for (int q = 1; q < 6; ++q)
+            RP_HIP(hipMemcpy2DAsync(trace + q * 16, 96 * sizeof(double), pose, 16 * sizeof(double), 16 * sizeof(double), kp->B,
+                                    hipMemcpyDeviceToDevice, s));
+    }
     if (dbg && dbg->corres_j)
         RP_HIP(hipMemcpyAsync(dbg->corres_j, cj, (size_t)kp->B * kp->ns_max * p->topK * 4, hipMemcpyDeviceToDevice, s));
     if (dbg && dbg->corres_w)
