@@ -25,7 +25,7 @@
 #define RP_MAXK 8
 #define RP_FEAT 32
 #define RP_FIT_THREADS 512
-#define RP_EIG_MAX_ITERS 64
+#define RP_EIG_MAX_ITERS 40
 #define RP_EPS 1e-12
 #define RP_OFFSET 50.0
 

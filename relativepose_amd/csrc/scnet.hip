@@ -19,6 +19,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -56,6 +57,10 @@ struct ConvDesc {
     const float* bias;     // heads only
     int tanh_out;
     int M, K;
+    int ksplit, kt_per;    // split-K: slices along K and k-tiles per slice (ksplit==1: direct store)
+    int ntiles_n;          // N tiles (grid.y = ntiles_n * ksplit)
+    float* partial;        // [ksplit][M][CoutPad] partial sums when ksplit > 1
+    int cout_pad;
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, slope * v); }   // slope in (0,1]
@@ -66,8 +71,10 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    const ConvDesc d = descs[blockIdx.z];             // block-uniform: scalar loads
+    if ((int)blockIdx.x * BM >= d.M) return;          // groups share a grid; shorter members exit
     constexpr int A_IT = BM / 64;                       // float4 slots per thread for the A tile
     constexpr int B_IT = (BN + 63) / 64;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
@@ -77,7 +84,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ks = blockIdx.y / d.ntiles_n;
+    const int m0 = blockIdx.x * BM, n0 = (blockIdx.y - ks * d.ntiles_n) * BN;
     const int hw = d.Hp * d.Wp;
 
     const int kq = tid & 3, lrow = tid >> 2;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
         }
         rowpix[tid] = pix;
     }
-    if (tid < 16) tapoff[tid] = ((int)d.offy[tid] << 16) | ((int)d.offx[tid] & 0xffff);
+    if (tid < 16) tapoff[tid] = ((int)descs[blockIdx.z].offy[tid] << 16) | ((int)descs[blockIdx.z].offx[tid] & 0xffff);
 
     floatx16 acc[MI][NI];
 #pragma unroll
@@ -123,8 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
     float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0;
     int okm = 0;
     float slope = 1.f;
-    const int nkt = d.K / BK;
-    int tap = 0, c0 = 0;
+    const int kt_begin = ks * d.kt_per;
+    const int nkt = min(d.K / BK, kt_begin + d.kt_per);
+    int tap = (kt_begin * BK) / d.Cin, c0 = kt_begin * BK - tap * d.Cin;
     __syncthreads();       // tapoff / rowpix visible
 
 #define RP_ISSUE_LOADS(KT)                                                                                        \
@@ -169,13 +178,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
         if (B_IT > 1) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + 64) * LDK + kq * 4]) = rb1;                     \
     }
 
-    RP_ISSUE_LOADS(0)
+    RP_ISSUE_LOADS(kt_begin)
     RP_STORE_TILE(0)
     __syncthreads();
     const int arow = (wm * MI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     const int brow = (wn * NI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt_begin; kt < nkt; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
         if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
@@ -201,6 +210,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
 #undef RP_STORE_TILE
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (d.ksplit > 1) {                                // partial sums, reduced in fixed order by splitk_reduce_kernel
+        float* po = d.partial + (size_t)ks * d.M * d.cout_pad;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= d.M) continue;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) po[(size_t)m * d.cout_pad + n0 + wn * NI * 32 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        return;
+    }
     float bias_v[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -225,6 +247,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
                 }
             }
         }
+}
+
+// y[pix(m)][col] = sum over K slices (fixed order) of the partial tiles
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __restrict__ descs) {
+    const ConvDesc d = descs[blockIdx.z];
+    const int q4 = d.cout_pad >> 2;
+    const size_t total = (size_t)d.M * q4;
+    const int hw = d.Hp * d.Wp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / q4), c4 = (int)(idx - (size_t)m * q4) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ks = 0; ks < d.ksplit; ++ks) {
+            const float4 v = *reinterpret_cast<const float4*>(d.partial + ((size_t)ks * d.M + m) * d.cout_pad + c4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        const int img = m / hw, rem = m - img * hw;
+        const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
+        const size_t pix = ((size_t)img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
+        float* yo = d.y + pix * d.ycstride + d.ychoff + c4;
+        if (c4 + 3 < d.Cout) *reinterpret_cast<float4*>(yo) = a;
+        else { if (c4 < d.Cout) yo[0] = a.x; if (c4 + 1 < d.Cout) yo[1] = a.y; if (c4 + 2 < d.Cout) yo[2] = a.z; }
+    }
 }
 
 // ---- BatchNorm batch statistics (per group of 2 images, per channel), float64 ---------------------
@@ -359,6 +403,8 @@ struct RelposeSCNet {
     float* d_w = nullptr;        // packed weights + biases
     float* d_gb = nullptr;       // gamma/beta per activation buffer [2][C]
     float2* d_ident = nullptr;   // 16 x {1,0}: scale/shift of the raw network input
+    ConvDesc* d_descs = nullptr; // device copy of the launch plan's descriptor table
+    void* plan = nullptr;        // Plan* (anonymous namespace type)
     std::map<std::string, Layer> layers;
     std::map<std::string, Buf> bufs;
     size_t per_image_floats = 0, ss_float2_per_group = 0;
@@ -533,93 +579,197 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
     return {};
 }
 
-struct Runner {
-    RelposeSCNet* net; hipStream_t s; int n, G;
-    float* act; float2* ss; double* partial;
+// ---- static launch plan ------------------------------------------------------------------------------
+// Everything about a forward except the in/out pointers is fixed by (n, workspace): the ConvDesc table is
+// built once, uploaded, and the forward replays the op list.  Independent convs of equal tile shape
+// (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
+// merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
+// of a few hundred (wave quantisation); layers with few output tiles are split along K.
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2 };
+struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; };
+
+struct Plan {
+    int n = 0; void* ws = nullptr;
+    std::vector<ConvDesc> descs;
+    std::vector<Op> ops;
+    size_t splitk_floats = 0;
+};
+
+struct Builder {
+    RelposeSCNet* net; int n, G;
+    float* act; float2* ss; float* splitk;   // may be null for a sizing dry run
+    Plan* plan;
     int rc = 0;
+    int group_first = -1;
 
-    float* buf(const std::string& b) { return act + net->bufs[b].off * n; }
-    float2* ssb(const std::string& b) { return ss + net->bufs[b].ss_off * G; }
-
-    void mark(int kind) {
-        if (!net->profiling) return;
-        hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s);
-        net->ev.push_back(e); net->ev_kind.push_back(kind);
-    }
-
-    Src src(const std::string& b, int choff, int C) {
-        const Buf& B = net->bufs[b];
-        Src r; r.x = buf(b) + choff; r.cstride = B.C; r.C = C; r.sstride = B.C;
-        if (b == "X0") { r.ss = net->d_ident; r.sstride = 0; r.slope = 1.f; }
-        else { r.ss = ssb(b) + choff; r.slope = LRELU; }
-        return r;
-    }
-
-    void conv(const std::string& layer, Src s0, const Src* s1, int Hin, const std::string& out, int ochoff) {
-        if (rc) return;
-        const Layer& L = net->layers[layer];
-        const Buf& O = net->bufs[out];
-        const int Hout = O.H;
-        for (const Phase& P : L.phases) {
-            ConvDesc d;
-            memset(&d, 0, sizeof(d));
-            d.src[0] = s0; d.nsrc = 1;
-            if (s1) { d.src[1] = *s1; d.nsrc = 2; }
-            d.Cin = s0.C + (s1 ? s1->C : 0);
-            d.Nimg = n; d.Hin = Hin; d.Win = Hin;
-            if (L.kind == 1) {
-                d.sy = d.sx = 1; d.osy = d.osx = L.stride; d.py = P.py; d.px = P.px;
-                d.Hp = (Hout - P.py + L.stride - 1) / L.stride; d.Wp = (Hout - P.px + L.stride - 1) / L.stride;
-            } else {
-                d.sy = d.sx = L.stride; d.osy = d.osx = 1; d.py = d.px = 0; d.Hp = Hout; d.Wp = Hout;
-            }
-            d.ntaps = P.ntaps;
-            memcpy(d.offy, P.offy, 16); memcpy(d.offx, P.offx, 16);
-            d.w = net->d_w + P.w_off;
-            d.Cout = L.cout;
-            d.y = buf(out); d.Hout = Hout; d.Wout = Hout; d.ycstride = (out == "OUT") ? net->cf : O.C; d.ychoff = ochoff;
-            d.bias = (L.kind == 2) ? net->d_w + L.bias_off : nullptr;
-            d.tanh_out = (L.kind == 2 && layer == "deconv1f" && net->use_tanh) ? 1 : 0;
-            d.M = n * d.Hp * d.Wp; d.K = P.K;
-            if (d.K != d.ntaps * d.Cin || d.Cin % BK || (s1 && s0.C % BK)) { rc = RELPOSE_EINVAL; return; }
-            mark(1);
-            if (L.cout_pad >= 128) {
-                dim3 grid((d.M + 127) / 128, L.cout_pad / 128);
-                hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, d);
-            } else if (L.cout_pad == 64) {
-                dim3 grid((d.M + 255) / 256, 1);
-                hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2>), grid, dim3(256), 0, s, d);
-            } else {
-                dim3 grid((d.M + 255) / 256, 1);
-                hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1>), grid, dim3(256), 0, s, d);
-            }
-            mark(-1);
-            if (hipGetLastError() != hipSuccess) { rc = -1001; return; }
-        }
-    }
-
-    void stats(const std::string& b) {
-        if (rc) return;
-        const Buf& B = net->bufs[b];
-        const int rows = 2 * B.H * B.H;
-        int nch = (2048 + G - 1) / G;
-        if (nch > (rows + 63) / 64) nch = (rows + 63) / 64;
-        if (nch > 64) nch = 64;
-        if (nch < 1) nch = 1;
-        const int chunk_rows = (rows + nch - 1) / nch;
-        nch = (rows + chunk_rows - 1) / chunk_rows;
-        const int q4 = B.C / 4, nrl = 256 / q4;
-        mark(2);
-        hipLaunchKernelGGL(bn_partial_kernel, dim3(nch, G), dim3(256), (size_t)nrl * q4 * 8 * sizeof(double), s, buf(b), rows, B.C,
-                           chunk_rows, partial);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((B.C + 255) / 256, G), dim3(256), 0, s, partial, nch, B.C, rows,
-                           net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssb(b));
-        mark(-2);
-        if (hipGetLastError() != hipSuccess) rc = -1002;
-    }
+    float* buf(const std::string& b);
+    float2* ssb(const std::string& b);
+    Src src(const std::string& b, int choff, int C);
+    void begin_group() { group_first = (int)plan->descs.size(); }
+    void end_group();
+    void conv(const std::string& layer, Src s0, const Src* s1, int Hin, const std::string& out, int ochoff);
+    void stats(const std::string& b) { Op o; o.type = OP_STATS; o.buf = b; o.first = o.count = o.cfg = 0; plan->ops.push_back(o); }
 };
 
 size_t partial_doubles(int G) { return (size_t)G * 64 * 1024 * 2; }
+constexpr int MAX_DESCS = 256;
+
+float* Builder::buf(const std::string& b) { return act ? act + net->bufs[b].off * n : nullptr; }
+float2* Builder::ssb(const std::string& b) { return ss ? ss + net->bufs[b].ss_off * G : nullptr; }
+
+Src Builder::src(const std::string& b, int choff, int C) {
+    const Buf& B = net->bufs[b];
+    Src r; r.x = buf(b) + choff; r.cstride = B.C; r.C = C; r.sstride = B.C;
+    if (b == "X0") { r.ss = net->d_ident; r.sstride = 0; r.slope = 1.f; }
+    else { r.ss = ssb(b) + choff; r.slope = LRELU; }
+    return r;
+}
+
+void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, const std::string& out, int ochoff) {
+    if (rc) return;
+    const Layer& L = net->layers[layer];
+    const Buf& O = net->bufs[out];
+    const int Hout = O.H;
+    for (const Phase& P : L.phases) {
+        ConvDesc d;
+        memset(&d, 0, sizeof(d));
+        d.src[0] = s0; d.nsrc = 1;
+        if (s1) { d.src[1] = *s1; d.nsrc = 2; }
+        d.Cin = s0.C + (s1 ? s1->C : 0);
+        d.Nimg = n; d.Hin = Hin; d.Win = Hin;
+        if (L.kind == 1) {
+            d.sy = d.sx = 1; d.osy = d.osx = L.stride; d.py = P.py; d.px = P.px;
+            d.Hp = (Hout - P.py + L.stride - 1) / L.stride; d.Wp = (Hout - P.px + L.stride - 1) / L.stride;
+        } else {
+            d.sy = d.sx = L.stride; d.osy = d.osx = 1; d.py = d.px = 0; d.Hp = Hout; d.Wp = Hout;
+        }
+        d.ntaps = P.ntaps;
+        memcpy(d.offy, P.offy, 16); memcpy(d.offx, P.offx, 16);
+        d.w = net->d_w + P.w_off;
+        d.Cout = L.cout; d.cout_pad = L.cout_pad;
+        d.y = buf(out); d.Hout = Hout; d.Wout = Hout; d.ycstride = (out == "OUT") ? net->cf : O.C; d.ychoff = ochoff;
+        d.bias = (L.kind == 2) ? net->d_w + L.bias_off : nullptr;
+        d.tanh_out = (L.kind == 2 && layer == "deconv1f" && net->use_tanh) ? 1 : 0;
+        d.M = n * d.Hp * d.Wp; d.K = P.K;
+        d.ksplit = 1; d.kt_per = d.K / BK; d.partial = nullptr;
+        if (d.K != d.ntaps * d.Cin || d.Cin % BK || (s1 && s0.C % BK)) { rc = RELPOSE_EINVAL; return; }
+        plan->descs.push_back(d);
+    }
+}
+
+// close a group: all members share cout_pad (= tile config); choose split-K from the tile count
+void Builder::end_group() {
+    if (rc || group_first < 0) return;
+    const int first = group_first, count = (int)plan->descs.size() - first;
+    group_first = -1;
+    if (count <= 0) return;
+    if ((int)plan->descs.size() > MAX_DESCS) { rc = RELPOSE_EINVAL; return; }
+    const int cp = plan->descs[first].cout_pad;
+    const int cfg = cp >= 128 ? 0 : (cp == 64 ? 1 : 2);
+    const int BMt = cfg == 0 ? 128 : 256, BNt = cfg == 0 ? 128 : cp;
+    int max_mt = 0, min_kt = 1 << 30;
+    long tiles = 0;
+    for (int i = first; i < first + count; ++i) {
+        ConvDesc& d = plan->descs[i];
+        if (d.cout_pad != cp) { rc = RELPOSE_EINVAL; return; }
+        const int mt = (d.M + BMt - 1) / BMt;
+        max_mt = std::max(max_mt, mt);
+        min_kt = std::min(min_kt, d.K / BK);
+        tiles += (long)mt * (cp / BNt);
+    }
+    // split along K until the launch has >= ~3000 tiles (>= 4 waves of resident blocks), keeping >= 8 k-tiles per slice
+    int ksplit = 1;
+    while (tiles * ksplit < 3000 && ksplit < 64 && min_kt / (ksplit * 2) >= 8) ksplit *= 2;
+    size_t pf = 0;
+    for (int i = first; i < first + count; ++i) {
+        ConvDesc& d = plan->descs[i];
+        d.ntiles_n = cp / BNt;
+        d.ksplit = ksplit;
+        d.kt_per = (d.K / BK + ksplit - 1) / ksplit;
+        if (ksplit > 1) { d.partial = splitk ? splitk + pf : nullptr; pf += (size_t)ksplit * d.M * cp; }
+    }
+    plan->splitk_floats = std::max(plan->splitk_floats, pf);
+    Op o; o.type = OP_CONV; o.first = first; o.count = count; o.cfg = cfg;
+    o.grid = dim3(max_mt, (cp / BNt) * ksplit, count);
+    plan->ops.push_back(o);
+    if (ksplit > 1) {
+        Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
+        plan->ops.push_back(r);
+    }
+}
+
+void build_plan(RelposeSCNet* net, int n, Builder& R) {
+    const char* mods[3] = {"rgb", "n", "d"};
+    const char* heads[5] = {"rgb", "n", "d", "s", "f"};
+    auto one = [&](const std::string& layer, Src s0, const Src* s1, int Hin, const std::string& out, int ochoff) {
+        R.begin_group(); R.conv(layer, s0, s1, Hin, out, ochoff); R.end_group();
+    };
+    // encoder, three modalities x two streams in concatenated buffers (mymodel.py:266-291)
+    one("conv1", R.src("X0", 0, 16), nullptr, 224, "A1", 0);
+    R.stats("A1");
+    R.begin_group();
+    for (int q = 0; q < 6; ++q) R.conv(std::string("conv2") + mods[q / 2], R.src("A1", q * 32, 32), nullptr, 224, "A2", q * 64);
+    R.end_group(); R.stats("A2");
+    R.begin_group();
+    for (int q = 0; q < 6; ++q) R.conv(std::string("conv3") + mods[q / 2], R.src("A2", q * 64, 64), nullptr, 112, "A3", q * 128);
+    R.end_group(); R.stats("A3");
+    one("conv4", R.src("A3", 0, 768), nullptr, 56, "A4", 0); R.stats("A4");
+    one("conv5", R.src("A4", 0, 256), nullptr, 28, "A5", 0); R.stats("A5");
+    one("conv6", R.src("A5", 0, 512), nullptr, 14, "A6", 0); R.stats("A6");
+    one("conv7", R.src("A6", 0, 512), nullptr, 7, "A7", 0); R.stats("A7");
+    one("conv8", R.src("A7", 0, 512), nullptr, 3, "A8", 0); R.stats("A8");
+    one("conv9", R.src("A8", 0, 512), nullptr, 3, "A9", 0); R.stats("A9");
+    // decoder with skip concatenations (mymodel.py:302-307)
+    Src sk;
+    one("deconv9", R.src("A9", 0, 1024), nullptr, 1, "D9", 0); R.stats("D9");
+    sk = R.src("A8", 0, 512); one("deconv8", R.src("D9", 0, 512), &sk, 3, "D8", 0); R.stats("D8");
+    sk = R.src("A7", 0, 512); one("deconv7", R.src("D8", 0, 512), &sk, 3, "D7", 0); R.stats("D7");
+    sk = R.src("A6", 0, 512); one("deconv6", R.src("D7", 0, 512), &sk, 7, "D6", 0); R.stats("D6");
+    sk = R.src("A5", 0, 512); one("deconv5", R.src("D6", 0, 512), &sk, 14, "D5", 0); R.stats("D5");
+    sk = R.src("A4", 0, 256); one("deconv4", R.src("D5", 0, 256), &sk, 28, "D4", 0); R.stats("D4");
+    // heads (mymodel.py:309-376): rgb/n/d with skips from the self stream, s/f without
+    R.begin_group();
+    for (int m = 0; m < 5; ++m) {
+        if (m < 3) { sk = R.src("A3", 2 * m * 128, 128); R.conv(std::string("deconv3") + heads[m], R.src("D4", 0, 128), &sk, 56, "D3", m * 64); }
+        else R.conv(std::string("deconv3") + heads[m], R.src("D4", 0, 128), nullptr, 56, "D3", m * 64);
+    }
+    R.end_group(); R.stats("D3");
+    const int d2off[5] = {0, 32, 64, 96, 160};
+    R.begin_group();
+    for (int m = 0; m < 3; ++m) { sk = R.src("A2", 2 * m * 64, 64); R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), &sk, 112, "D2", d2off[m]); }
+    R.end_group();
+    R.begin_group();
+    for (int m = 3; m < 5; ++m) R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), nullptr, 112, "D2", d2off[m]);
+    R.end_group(); R.stats("D2");
+    const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
+    R.begin_group();
+    for (int m = 0; m < 5; ++m) {
+        if (m < 3) { sk = R.src("A1", 2 * m * 32, 32); R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 32), &sk, 224, "OUT", ooff[m]); }
+        else R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 64), nullptr, 224, "OUT", ooff[m]);
+    }
+    R.end_group();
+    (void)n;
+}
+
+void free_plan(RelposeSCNet* net) {
+    if (net->plan) { delete (Plan*)net->plan; net->plan = nullptr; }
+}
+
+struct WsOffsets { size_t act, ss, partial, splitk, total; };
+
+WsOffsets ws_offsets(RelposeSCNet* net, int n) {
+    Plan dry;
+    Builder B; B.net = net; B.n = n; B.G = n / 2; B.act = nullptr; B.ss = nullptr; B.splitk = nullptr; B.plan = &dry;
+    build_plan(net, n, B);
+    WsOffsets o;
+    size_t off = 0;
+    o.act = off; off += rp_align(net->per_image_floats * n * sizeof(float));
+    o.ss = off; off += rp_align(net->ss_float2_per_group * (n / 2) * sizeof(float2));
+    o.partial = off; off += rp_align(partial_doubles(n / 2) * sizeof(double));
+    o.splitk = off; off += rp_align(dry.splitk_floats * sizeof(float));
+    o.total = off;
+    return o;
+}
 
 }  // namespace
 
@@ -637,6 +787,8 @@ void relpose_scnet_destroy(RelposeSCNet* net) {
     if (net->d_w) hipFree(net->d_w);
     if (net->d_gb) hipFree(net->d_gb);
     if (net->d_ident) hipFree(net->d_ident);
+    if (net->d_descs) hipFree(net->d_descs);
+    free_plan(net);
     delete net;
 }
 
@@ -705,70 +857,79 @@ int relpose_scnet_finalize(RelposeSCNet* net) {
 
 size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n, int32_t H, int32_t W) {
     if (!net || !net->finalized || n <= 0 || (n & 1) || H <= 0 || W <= 0) return 0;
-    const int G = n / 2;
-    return rp_align(net->per_image_floats * n * sizeof(float)) + rp_align(net->ss_float2_per_group * G * sizeof(float2)) +
-           rp_align(partial_doubles(G) * sizeof(double));
+    return ws_offsets(const_cast<RelposeSCNet*>(net), n).total;
 }
 
 int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                           size_t workspace_bytes, void* stream) {
     if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0) return RELPOSE_EINVAL;
-    if (workspace_bytes < relpose_scnet_workspace_bytes(net, n, H, W)) return RELPOSE_ENOMEM;
+    Plan* plan = (Plan*)net->plan;
+    const int G = n / 2;
+    if (!plan || plan->n != n || plan->ws != workspace) {
+        const WsOffsets o = ws_offsets(net, n);
+        if (workspace_bytes < o.total) return RELPOSE_ENOMEM;
+        free_plan(net);
+        plan = new Plan();
+        plan->n = n; plan->ws = workspace;
+        char* ws = (char*)workspace;
+        Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan;
+        B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk);
+        build_plan(net, n, B);
+        if (B.rc) { delete plan; return B.rc; }
+        if (!net->d_descs) RP_HIP(hipMalloc((void**)&net->d_descs, MAX_DESCS * sizeof(ConvDesc)));
+        // one-off synchronous upload; the stream may still be executing an older plan
+        RP_HIP(hipStreamSynchronize((hipStream_t)stream));
+        RP_HIP(hipMemcpy(net->d_descs, plan->descs.data(), plan->descs.size() * sizeof(ConvDesc), hipMemcpyHostToDevice));
+        net->plan = plan;
+    }
     net->last_n = n;
-    Runner R;
-    R.net = net; R.s = (hipStream_t)stream; R.n = n; R.G = n / 2;
+    hipStream_t s = (hipStream_t)stream;
+    const WsOffsets o = ws_offsets(net, n);
     char* ws = (char*)workspace;
-    R.act = (float*)ws;
-    R.ss = (float2*)(ws + rp_align(net->per_image_floats * n * sizeof(float)));
-    R.partial = (double*)((char*)R.ss + rp_align(net->ss_float2_per_group * R.G * sizeof(float2)));
-
-    R.mark(3);
-    hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, R.s, x, R.buf("X0"), n, H, W);
-    R.mark(-3);
-    // encoder, three modalities x two streams in concatenated buffers (mymodel.py:266-291)
-    R.conv("conv1", R.src("X0", 0, 16), nullptr, 224, "A1", 0);
-    R.stats("A1");
-    const char* mods[3] = {"rgb", "n", "d"};
-    for (int q = 0; q < 6; ++q) R.conv(std::string("conv2") + mods[q / 2], R.src("A1", q * 32, 32), nullptr, 224, "A2", q * 64);
-    R.stats("A2");
-    for (int q = 0; q < 6; ++q) R.conv(std::string("conv3") + mods[q / 2], R.src("A2", q * 64, 64), nullptr, 112, "A3", q * 128);
-    R.stats("A3");
-    R.conv("conv4", R.src("A3", 0, 768), nullptr, 56, "A4", 0); R.stats("A4");
-    R.conv("conv5", R.src("A4", 0, 256), nullptr, 28, "A5", 0); R.stats("A5");
-    R.conv("conv6", R.src("A5", 0, 512), nullptr, 14, "A6", 0); R.stats("A6");
-    R.conv("conv7", R.src("A6", 0, 512), nullptr, 7, "A7", 0); R.stats("A7");
-    R.conv("conv8", R.src("A7", 0, 512), nullptr, 3, "A8", 0); R.stats("A8");
-    R.conv("conv9", R.src("A8", 0, 512), nullptr, 3, "A9", 0); R.stats("A9");
-    // decoder with skip concatenations (mymodel.py:302-307)
-    Src sk;
-    R.conv("deconv9", R.src("A9", 0, 1024), nullptr, 1, "D9", 0); R.stats("D9");
-    sk = R.src("A8", 0, 512); R.conv("deconv8", R.src("D9", 0, 512), &sk, 3, "D8", 0); R.stats("D8");
-    sk = R.src("A7", 0, 512); R.conv("deconv7", R.src("D8", 0, 512), &sk, 3, "D7", 0); R.stats("D7");
-    sk = R.src("A6", 0, 512); R.conv("deconv6", R.src("D7", 0, 512), &sk, 7, "D6", 0); R.stats("D6");
-    sk = R.src("A5", 0, 512); R.conv("deconv5", R.src("D6", 0, 512), &sk, 14, "D5", 0); R.stats("D5");
-    sk = R.src("A4", 0, 256); R.conv("deconv4", R.src("D5", 0, 256), &sk, 28, "D4", 0); R.stats("D4");
-    // heads (mymodel.py:309-376): rgb/n/d with skips from the self stream, s/f without
-    const char* heads[5] = {"rgb", "n", "d", "s", "f"};
-    for (int m = 0; m < 5; ++m) {
-        if (m < 3) { sk = R.src("A3", 2 * m * 128, 128); R.conv(std::string("deconv3") + heads[m], R.src("D4", 0, 128), &sk, 56, "D3", m * 64); }
-        else R.conv(std::string("deconv3") + heads[m], R.src("D4", 0, 128), nullptr, 56, "D3", m * 64);
+    float* act = (float*)(ws + o.act);
+    float2* ssp = (float2*)(ws + o.ss);
+    double* partial = (double*)(ws + o.partial);
+    auto mark = [&](int kind) {
+        if (!net->profiling) return;
+        hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, s);
+        net->ev.push_back(e); net->ev_kind.push_back(kind);
+    };
+    mark(3);
+    hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, s, x, act + net->bufs["X0"].off * n, n, H, W);
+    mark(-3);
+    for (const Op& op : plan->ops) {
+        if (op.type == OP_CONV) {
+            mark(1);
+            const ConvDesc* dd = net->d_descs + op.first;
+            if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2>), op.grid, dim3(256), 0, s, dd);
+            else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2>), op.grid, dim3(256), 0, s, dd);
+            else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1>), op.grid, dim3(256), 0, s, dd);
+            mark(-1);
+        } else if (op.type == OP_REDUCE) {
+            mark(4);
+            hipLaunchKernelGGL(splitk_reduce_kernel, op.grid, dim3(256), 0, s, net->d_descs + op.first);
+            mark(-4);
+        } else {
+            const Buf& B = net->bufs[op.buf];
+            const int rows = 2 * B.H * B.H;
+            int nch = (2048 + G - 1) / G;
+            if (nch > (rows + 63) / 64) nch = (rows + 63) / 64;
+            if (nch > 64) nch = 64;
+            if (nch < 1) nch = 1;
+            const int chunk_rows = (rows + nch - 1) / nch;
+            nch = (rows + chunk_rows - 1) / chunk_rows;
+            const int q4 = B.C / 4, nrl = 256 / q4;
+            mark(2);
+            hipLaunchKernelGGL(bn_partial_kernel, dim3(nch, G), dim3(256), (size_t)nrl * q4 * 8 * sizeof(double), s, act + B.off * n, rows,
+                               B.C, chunk_rows, partial);
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3((B.C + 255) / 256, G), dim3(256), 0, s, partial, nch, B.C, rows,
+                               net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
+            mark(-2);
+        }
     }
-    R.stats("D3");
-    const int d2off[5] = {0, 32, 64, 96, 160};
-    for (int m = 0; m < 5; ++m) {
-        if (m < 3) { sk = R.src("A2", 2 * m * 64, 64); R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), &sk, 112, "D2", d2off[m]); }
-        else R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), nullptr, 112, "D2", d2off[m]);
-    }
-    R.stats("D2");
-    const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
-    for (int m = 0; m < 5; ++m) {
-        if (m < 3) { sk = R.src("A1", 2 * m * 32, 32); R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 32), &sk, 224, "OUT", ooff[m]); }
-        else R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 64), nullptr, 224, "OUT", ooff[m]);
-    }
-    if (R.rc) return R.rc;
-    R.mark(3);
-    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), 0, R.s, R.buf("OUT"), out, n, net->cf, H, W);
-    R.mark(-3);
+    mark(3);
+    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), 0, s, act + net->bufs["OUT"].off * n, out, n, net->cf, H, W);
+    mark(-3);
     RP_CHECK_LAUNCH();
     return 0;
 }
