@@ -25,7 +25,8 @@
 #define RP_MAXK 8
 #define RP_FEAT 32
 #define RP_FIT_THREADS 512
-#define RP_EIG_MAX_ITERS 40
+#define RP_EIG_MAX_ITERS 64     // SpMV launches per spectral round (upper bound; converged pairs exit early)
+#define RP_EIG_NORM_EVERY 4    // renormalise + test convergence every 4th SpMV (|y| grows by lambda^4 at most: safe in f64)
 #define RP_EPS 1e-12
 #define RP_OFFSET 50.0
 
@@ -406,7 +407,8 @@ __device__ __forceinline__ void write_pose(double* out, const double R[3][3], co
 // The host enqueues the ~80 spmv/norm launches of a spectral round back to back; each is a few us.
 struct FitState {
     double* u;        // [B, Cmax] current unit vector
-    double* y;        // [B, Cmax]
+    double* y;        // [B, Cmax] un-normalised iterate (odd products), read by eig_norm
+    double* y2;       // [B, Cmax] un-normalised iterate (even products)
     double* h;        // [B, Cmax]
     double* part;     // [B, nblk] per-block sum of squares of y
     int32_t* done;    // [B] eigen iteration converged
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(256) void eig_init_kernel(RelposeKeypoints kp, Grap
 
 // a = base*(h[c]+h[cc]) (rpmodule.py:262-267 summed over the two halves); base = w, or mu*x for 'spectral' rounds > 0
 __global__ __launch_bounds__(256) void eig_spmv_kernel(RelposeKeypoints kp, Graph g, FitState fs, double mu_xe,
-                                                        const int32_t* __restrict__ status) {
+                                                        const int32_t* __restrict__ status, int src_sel, int dst_sel, int want_norm) {
     __shared__ double wsum[4];
     const int b = blockIdx.y;
     if (!pair_active(status, b) || fs.done[b]) return;
@@ -517,7 +519,9 @@ __global__ __launch_bounds__(256) void eig_spmv_kernel(RelposeKeypoints kp, Grap
     if (blockIdx.x * 16 >= C) return;
     const size_t eoff = (size_t)b * g.max_edges;
     const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
-    const double* u = fs.u + (size_t)b * g.Cmax;
+    // buffers: 0 = u (unit vector, kept for the convergence test), 1 = y2, 2 = y (the one eig_norm reads)
+    const double* u = (src_sel == 0 ? fs.u : src_sel == 1 ? fs.y2 : fs.y) + (size_t)b * g.Cmax;
+    double* yo = (dst_sel == 1 ? fs.y2 : fs.y) + (size_t)b * g.Cmax;
     const double* h = fs.h + (size_t)b * g.Cmax;
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
     const int c = blockIdx.x * 16 + grp;
@@ -532,7 +536,8 @@ __global__ __launch_bounds__(256) void eig_spmv_kernel(RelposeKeypoints kp, Grap
     }
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
-    if (c < C && gl == 0) fs.y[(size_t)b * g.Cmax + c] = s;
+    if (c < C && gl == 0) yo[c] = s;
+    if (!want_norm) return;
     // per-block sum of squares (fixed order: 4 rows per wave via lanes 0,16,32,48; then 4 waves)
     double q = (gl == 0 && c < C) ? s * s : 0.0;
     q += rp_shfl_xor_d(q, 16); q += rp_shfl_xor_d(q, 32);
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(256) void eig_norm_kernel(RelposeKeypoints kp, Grap
     }
     if (moved) flag = 1;
     __syncthreads();
-    if (threadIdx.x == 0) { fs.iters[b] += 1; if (!flag) fs.done[b] = 1; }
+    if (threadIdx.x == 0) { fs.iters[b] += RP_EIG_NORM_EVERY; if (!flag) fs.done[b] = 1; }
 }
 
 // x = relu(u[c1]*u[c2]) * w  (rpmodule.py:277-280) and the new weighted degrees
@@ -664,7 +669,7 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.xe = take((size_t)B * L.max_edges * 8);
     L.state = take((size_t)B * 4 * L.Cmax * 8);
     L.geo = take((size_t)B * L.Cmax * 12 * 8);
-    L.eig = take((size_t)B * (3 * (size_t)L.Cmax + (L.Cmax + 15) / 16) * 8 + (size_t)B * 2 * 4);
+    L.eig = take((size_t)B * (4 * (size_t)L.Cmax + (L.Cmax + 15) / 16) * 8 + (size_t)B * 2 * 4);
     L.total = o;
     return L;
 }
@@ -725,7 +730,8 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     // ---- fit: launch sequence (see fit_begin_kernel)
     FitState fs;
     fs.nblk = (L.Cmax + 15) / 16;
-    fs.u = (double*)(ws + L.eig); fs.y = fs.u + (size_t)kp->B * L.Cmax; fs.h = fs.y + (size_t)kp->B * L.Cmax;
+    fs.u = (double*)(ws + L.eig); fs.y = fs.u + (size_t)kp->B * L.Cmax; fs.y2 = fs.y + (size_t)kp->B * L.Cmax;
+    fs.h = fs.y2 + (size_t)kp->B * L.Cmax;
     fs.part = fs.h + (size_t)kp->B * L.Cmax;
     fs.done = (int32_t*)(fs.part + (size_t)kp->B * fs.nblk); fs.iters = fs.done + kp->B;
     double* trace = dbg ? dbg->trace : nullptr;
@@ -745,8 +751,12 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
             hipLaunchKernelGGL(eig_init_kernel, dim3((L.Cmax + 255) / 256, kp->B), dim3(256), 0, s, *kp, g, fs, status);
             const double mu_xe = (!sm && round > 0) ? p->mu : 0.0;
             for (int it = 0; it < RP_EIG_MAX_ITERS; ++it) {
-                hipLaunchKernelGGL(eig_spmv_kernel, grid16, dim3(256), 0, s, *kp, g, fs, mu_xe, status);
-                hipLaunchKernelGGL(eig_norm_kernel, dim3(kp->B), dim3(256), 0, s, *kp, g, fs, status);
+                // 4 products per normalisation: u -> y2 -> y -> y2 -> y, then eig_norm: u = y/|y|
+                const int j = it % RP_EIG_NORM_EVERY;
+                const int src = (j == 0) ? 0 : ((j & 1) ? 1 : 2), dst = (j & 1) ? 2 : 1;
+                const bool last = (j == RP_EIG_NORM_EVERY - 1);
+                hipLaunchKernelGGL(eig_spmv_kernel, grid16, dim3(256), 0, s, *kp, g, fs, mu_xe, status, src, dst, last ? 1 : 0);
+                if (last) hipLaunchKernelGGL(eig_norm_kernel, dim3(kp->B), dim3(256), 0, s, *kp, g, fs, status);
             }
             hipLaunchKernelGGL(eig_finish_kernel, grid16, dim3(256), 0, s, *kp, g, fs, status, eig_iters ? eig_iters + round : nullptr);
             hipLaunchKernelGGL(fit_irls_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), 0, s, *kp, g, kc, sm ? 5 : 1, sm ? 1 : 0, 1, status, pose,

@@ -675,7 +675,9 @@ void Builder::end_group() {
         const int mt = (d.M + BMt - 1) / BMt;
         max_mt = std::max(max_mt, mt);
         min_kt = std::min(min_kt, d.K / BK);
-        tiles += (long)mt * (cp / BNt);
+        // the split factor must not depend on the batch size (results are bitwise batch-invariant), so the
+        // tile count is evaluated at a nominal batch of 64 images (32 scan pairs)
+        tiles += (long)((d.M / n * 64 + BMt - 1) / BMt) * (cp / BNt);
     }
     // split along K until the launch has >= ~3000 tiles (>= 4 waves of resident blocks), keeping >= 8 k-tiles per slice
     int ksplit = 1;

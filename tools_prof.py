@@ -36,7 +36,7 @@ if __name__ == "__main__":
 
 
 def conv_layers(rows, n=64, which=3):
-    """Per-layer conv timing of the `which`-th forward in the trace (launch order is fixed, csrc/scnet.hip)."""
+    """Per-group conv timing of the `which`-th forward in the trace (launch order is fixed, csrc/scnet.hip)."""
     seq, on, count = [], False, 0
     for r in rows:
         if 'resize_in' in r[0]:
@@ -46,33 +46,30 @@ def conv_layers(rows, n=64, which=3):
             seq.append(r)
         if 'resize_out' in r[0] and on:
             break
-    L = []
-    add = lambda name, M, K, C: L.append((name, M, K, C))
-    add('conv1', n * 224 * 224, 144, 192)
-    for q in range(6): add('conv2', n * 112 * 112, 16 * 32, 64)
-    for q in range(6): add('conv3', n * 56 * 56, 16 * 64, 128)
-    add('conv4', n * 28 * 28, 16 * 768, 256); add('conv5', n * 14 * 14, 16 * 256, 512); add('conv6', n * 7 * 7, 16 * 512, 512)
-    add('conv7', n * 9, 9 * 512, 512); add('conv8', n * 9, 9 * 512, 512); add('conv9', n * 1, 9 * 512, 1024)
-    add('deconv9', n * 9, 9 * 1024, 512); add('deconv8', n * 9, 9 * 1024, 512)
-    for (hp, wp, t) in ((4, 4, 4), (4, 3, 2), (3, 4, 2), (3, 3, 1)): add('deconv7', n * hp * wp, t * 1024, 512)
-    for ph in range(4): add('deconv6', n * 49, 4 * 1024, 512)
-    for ph in range(4): add('deconv5', n * 196, 4 * 1024, 256)
-    for ph in range(4): add('deconv4', n * 784, 4 * 512, 128)
-    for m in range(5):
-        for ph in range(4): add('deconv3', n * 56 * 56, 4 * (256 if m < 3 else 128), 64)
-    for m in range(5):
-        for ph in range(4): add('deconv2', n * 112 * 112, 4 * (128 if m < 3 else 64), 32 if m < 3 else 64)
-    for m, co in enumerate((3, 3, 1, 15, 32)): add('head', n * 224 * 224, 64, co)
+    P = lambda M, K, C: 2.0 * M * K * C
+    G = [('conv1', P(n * 224 * 224, 144, 192)), ('conv2 x6', 6 * P(n * 112 * 112, 512, 64)), ('conv3 x6', 6 * P(n * 56 * 56, 1024, 128)),
+         ('conv4', P(n * 784, 12288, 256)), ('conv5', P(n * 196, 4096, 512)), ('conv6', P(n * 49, 8192, 512)),
+         ('conv7', P(n * 9, 4608, 512)), ('conv8', P(n * 9, 4608, 512)), ('conv9', P(n, 4608, 1024)),
+         ('deconv9', P(n * 9, 9216, 512)), ('deconv8', P(n * 9, 9216, 512)),
+         ('deconv7', sum(P(n * a * b, t * 1024, 512) for a, b, t in ((4, 4, 4), (4, 3, 2), (3, 4, 2), (3, 3, 1)))),
+         ('deconv6', 4 * P(n * 49, 4096, 512)), ('deconv5', 4 * P(n * 196, 4096, 256)), ('deconv4', 4 * P(n * 784, 2048, 128)),
+         ('deconv3 x5', 4 * (3 * P(n * 3136, 1024, 64) + 2 * P(n * 3136, 512, 64))),
+         ('deconv2 rgb/n/d', 12 * P(n * 12544, 512, 32)), ('deconv2 s/f', 8 * P(n * 12544, 256, 64)),
+         ('heads', sum(P(n * 50176, 64, c) for c in (3, 3, 1, 15, 32)))]
     convs = [r for r in seq if 'conv_igemm' in r[0]]
-    out = [f"{len(convs)} conv launches in forward #{which} (expected {len(L)})"]
-    agg = {}
-    for r, (name, M, K, C) in zip(convs, L):
-        a = agg.setdefault(name, [0.0, 0.0, 0])
-        a[0] += (r[2] - r[1]) / 1e3; a[1] += 2.0 * M * K * C; a[2] += 1
-    tot = sum(a[0] for a in agg.values())
-    for k, a in agg.items():
-        out.append(f"{k:8s} launches={a[2]:2d} time={a[0]:9.1f}us {100*a[0]/tot:5.1f}%  useful TFLOP/s={a[1]/a[0]/1e6:6.1f}")
-    out.append(f"conv total {tot:.1f} us, useful {sum(a[1] for a in agg.values())/tot/1e6:.1f} TFLOP/s; forward wall {(seq[-1][2]-seq[0][1])/1e3:.1f} us")
+    red = sum((r[2] - r[1]) / 1e3 for r in seq if 'splitk_reduce' in r[0])
+    out = [f"{len(convs)} conv launches in forward #{which} (expected {len(G)})"]
+    tot = sum((r[2] - r[1]) / 1e3 for r in convs)
+    for r, (name, fl) in zip(convs, G):
+        d = (r[2] - r[1]) / 1e3
+        out.append(f"{name:16s} grid=({r[3]//256:5d},{r[4]:3d},{r[5]:2d}) time={d:9.1f}us {100*d/tot:5.1f}%  useful TFLOP/s={fl/d/1e6:6.1f}")
+    out.append(f"conv total {tot:.1f} us (+ split-K reduce {red:.1f} us), useful {sum(f for _, f in G)/tot/1e6:.1f} TFLOP/s; "
+               f"forward wall {(seq[-1][2]-seq[0][1])/1e3:.1f} us")
+    oth = {}
+    for r in seq:
+        if 'conv_igemm' not in r[0]:
+            oth[short(r[0])[:24]] = oth.get(short(r[0])[:24], 0) + (r[2] - r[1]) / 1e3
+    out.append("other kernels (us): " + ", ".join(f"{k}={v:.0f}" for k, v in oth.items()))
     return "\n".join(out)
 
 
