@@ -48,6 +48,7 @@ struct Graph {                 // per-batch device arrays of the pair-compatibil
     double* xe;                // [B, max_edges]
     double* state;             // [B, 4, Cmax]  deg, gP, gN, rsum
     double* geo;               // [B, Cmax, 12]  sp, tp, sn, tn of every correspondence (gathered once per fit)
+    int32_t* pairC;            // [B] number of correspondences of a pair whose fit is running, 0 otherwise
 };
 
 __device__ __forceinline__ int pair_C(const RelposeKeypoints& kp, const Graph& g, int b) {
@@ -470,9 +471,11 @@ __global__ __launch_bounds__(256) void fit_begin_kernel(RelposeKeypoints kp, Gra
 }
 
 // status is committed separately so that every block of fit_begin sees the same (pre-commit) value
-__global__ void fit_commit_status_kernel(Graph g, int32_t* __restrict__ status, int B) {
+__global__ void fit_commit_status_kernel(RelposeKeypoints kp, Graph g, int32_t* __restrict__ status, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && status[b] == RELPOSE_OK && g.counters[b * 4 + 2] < 1) status[b] = RELPOSE_ZERO_WEIGHT;
+    if (b >= B) return;
+    if (status[b] == RELPOSE_OK && g.counters[b * 4 + 2] < 1) status[b] = RELPOSE_ZERO_WEIGHT;
+    g.pairC[b] = (status[b] == RELPOSE_OK) ? pair_C(kp, g, b) : 0;      // one load replaces status/ns/nt/keff in the eig kernels
 }
 
 __global__ __launch_bounds__(RP_FIT_THREADS) void fit_irls_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int n_iter, int reweight,
@@ -499,8 +502,8 @@ __global__ __launch_bounds__(RP_FIT_THREADS) void fit_irls_kernel(RelposeKeypoin
 
 __global__ __launch_bounds__(256) void eig_init_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status) {
     const int b = blockIdx.y;
-    if (!pair_active(status, b)) return;
-    const int C = pair_C(kp, g, b);
+    const int C = g.pairC[b];
+    if (C == 0) return;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0) { fs.done[b] = 0; fs.iters[b] = 0; }
     if (c >= C) return;
@@ -514,8 +517,8 @@ __global__ __launch_bounds__(256) void eig_spmv_kernel(RelposeKeypoints kp, Grap
                                                         const int32_t* __restrict__ status, int src_sel, int dst_sel, int want_norm) {
     __shared__ double wsum[4];
     const int b = blockIdx.y;
-    if (!pair_active(status, b) || fs.done[b]) return;
-    const int C = pair_C(kp, g, b);
+    const int C = g.pairC[b];
+    if (C == 0 || fs.done[b]) return;
     if (blockIdx.x * 16 >= C) return;
     const size_t eoff = (size_t)b * g.max_edges;
     const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
@@ -550,8 +553,8 @@ __global__ __launch_bounds__(256) void eig_norm_kernel(RelposeKeypoints kp, Grap
     __shared__ double red[16];
     __shared__ int flag;
     const int b = blockIdx.x;
-    if (!pair_active(status, b) || fs.done[b]) return;
-    const int C = pair_C(kp, g, b);
+    const int C = g.pairC[b];
+    if (C == 0 || fs.done[b]) return;
     const int nb = (C + 15) / 16;
     double a[1] = {0.0};
     for (int i = threadIdx.x; i < nb; i += blockDim.x) a[0] += fs.part[(size_t)b * fs.nblk + i];
@@ -580,8 +583,8 @@ __global__ __launch_bounds__(256) void eig_norm_kernel(RelposeKeypoints kp, Grap
 __global__ __launch_bounds__(256) void eig_finish_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status,
                                                           int32_t* __restrict__ eig_iters_out) {
     const int b = blockIdx.y;
-    if (!pair_active(status, b)) return;
-    const int C = pair_C(kp, g, b);
+    const int C = g.pairC[b];
+    if (C == 0) return;
     const size_t eoff = (size_t)b * g.max_edges;
     const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
     const double* u = fs.u + (size_t)b * g.Cmax;
@@ -642,7 +645,7 @@ int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* w
 }
 
 struct WsLayout {
-    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, eig, total;
+    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, eig, pairC, total;
     int32_t Cmax, Wmax;
     int64_t max_edges;
 };
@@ -669,6 +672,7 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.xe = take((size_t)B * L.max_edges * 8);
     L.state = take((size_t)B * 4 * L.Cmax * 8);
     L.geo = take((size_t)B * L.Cmax * 12 * 8);
+    L.pairC = take((size_t)B * 4);
     L.eig = take((size_t)B * (4 * (size_t)L.Cmax + (L.Cmax + 15) / 16) * 8 + (size_t)B * 2 * 4);
     L.total = o;
     return L;
@@ -715,7 +719,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     g.bitmap = (unsigned long long*)(ws + L.bitmap);
     g.upcnt = (int32_t*)(ws + L.upcnt); g.lowcnt = (int32_t*)(ws + L.lowcnt); g.counters = (int32_t*)(ws + L.counters);
     g.rowptr = (int32_t*)(ws + L.rowptr); g.col = (int32_t*)(ws + L.col);
-    g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state); g.geo = (double*)(ws + L.geo);
+    g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state); g.geo = (double*)(ws + L.geo); g.pairC = (int32_t*)(ws + L.pairC);
     RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
     int rc = launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
     if (rc) return rc;
@@ -738,7 +742,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     int32_t* eig_iters = dbg ? dbg->eig_iters : nullptr;
     dim3 grid16(fs.nblk, kp->B);
     hipLaunchKernelGGL(fit_begin_kernel, grid16, dim3(256), 0, s, *kp, g, p->topK, status, pose, trace, dbg ? dbg->counts : nullptr);
-    hipLaunchKernelGGL(fit_commit_status_kernel, dim3((kp->B + 63) / 64), dim3(64), 0, s, g, status, kp->B);
+    hipLaunchKernelGGL(fit_commit_status_kernel, dim3((kp->B + 63) / 64), dim3(64), 0, s, *kp, g, status, kp->B);
     RP_CHECK_LAUNCH();
     const int m = p->method;
     const bool irls0 = (m == RELPOSE_FIT_IRLS_SM || m == RELPOSE_FIT_IRLS);

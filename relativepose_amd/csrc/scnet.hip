@@ -28,6 +28,9 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+#ifndef RP_ABLATE
+#define RP_ABLATE 0
+#endif
 constexpr int BK = 16;          // K-tile (floats)
 constexpr int LDK = 20;         // LDS row stride in floats (80 B: 16-B aligned, conflict-free b128 reads)
 constexpr float LRELU = 0.1f;
@@ -70,34 +73,48 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // scale/shift, B weights) are issued BEFORE the MFMAs of tile kt and consumed AFTER them, so their
 // latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
-template <int WM, int WN, int MI, int NI>
+template <int WM, int WN, int MI, int NI, bool SSLDS>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     const ConvDesc d = descs[blockIdx.z];             // block-uniform: scalar loads
     if ((int)blockIdx.x * BM >= d.M) return;          // groups share a grid; shorter members exit
     constexpr int A_IT = BM / 64;                       // float4 slots per thread for the A tile
     constexpr int B_IT = (BN + 63) / 64;
+    constexpr int SS_CAP = (WM == 2) ? 1024 : 512;      // float2 entries of the LDS scale/shift table (8 / 4 KB: keeps 3 blocks per CU)
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) float2 sstab[SSLDS ? SS_CAP : 4];
     __shared__ int rowpix[BM];
-    __shared__ int tapoff[16];
+    __shared__ int tapdelta[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ks = blockIdx.y / d.ntiles_n;
     const int m0 = blockIdx.x * BM, n0 = (blockIdx.y - ks * d.ntiles_n) * BN;
     const int hw = d.Hp * d.Wp;
+    const int g0 = (m0 / hw) >> 1;                      // first BatchNorm group touched by this tile
 
+    // Per loader row: pixel index of the (tap 0,0) origin, a 16-bit mask of the taps that fall inside
+    // the image (everything else is zero padding), and the BatchNorm group.  Computed once per block.
     const int kq = tid & 3, lrow = tid >> 2;
-    int r_img[A_IT], r_y[A_IT], r_x[A_IT];
+    int r_base[A_IT], r_mask[A_IT], r_grp[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int m = m0 + lrow + it * 64;
+        r_base[it] = 0; r_mask[it] = 0; r_grp[it] = 0;
         if (m < d.M) {
             const int img = m / hw, rem = m - img * hw;
             const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
-            r_img[it] = img; r_y[it] = yp * d.sy; r_x[it] = xp * d.sx;
-        } else { r_img[it] = -1; r_y[it] = 0; r_x[it] = 0; }
+            const int y0 = yp * d.sy, x0 = xp * d.sx;
+            r_base[it] = (img * d.Hin + y0) * d.Win + x0;
+            r_grp[it] = SSLDS ? ((img >> 1) - g0) * d.Cin : (img >> 1);
+            int msk = 0;
+            for (int t = 0; t < d.ntaps; ++t) {
+                const int iy = y0 + descs[blockIdx.z].offy[t], ix = x0 + descs[blockIdx.z].offx[t];
+                msk |= ((iy >= 0) & (iy < d.Hin) & (ix >= 0) & (ix < d.Win)) ? (1 << t) : 0;
+            }
+            r_mask[it] = msk;
+        }
     }
     if (tid < BM) {
         const int m = m0 + tid;
@@ -109,7 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
         }
         rowpix[tid] = pix;
     }
-    if (tid < 16) tapoff[tid] = ((int)descs[blockIdx.z].offy[tid] << 16) | ((int)descs[blockIdx.z].offx[tid] & 0xffff);
+    if (tid < 16) tapdelta[tid] = (int)descs[blockIdx.z].offy[tid] * d.Win + (int)descs[blockIdx.z].offx[tid];
+    if (SSLDS) {
+        // scale/shift of every (group, input channel) this tile can touch; both sources concatenated
+        const int ng = min(((min(m0 + BM, d.M) - 1) / hw >> 1) - g0 + 1, SS_CAP / d.Cin);
+        for (int idx = tid; idx < ng * d.Cin; idx += 256) {
+            const int g = g0 + idx / d.Cin, c = idx % d.Cin;
+            const bool s1 = c >= d.src[0].C;
+            sstab[idx] = s1 ? d.src[1].ss[(size_t)g * d.src[1].sstride + (c - d.src[0].C)] : d.src[0].ss[(size_t)g * d.src[0].sstride + c];
+        }
+    }
 
     floatx16 acc[MI][NI];
 #pragma unroll
@@ -127,36 +153,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
         b_src[it] = d.w + (size_t)(n0 + row) * d.K + kq * 4;
     }
 
-    float4 ra[A_IT], q0[A_IT], q1[A_IT];
+    float4 ra[A_IT], q0[SSLDS ? 1 : A_IT], q1[SSLDS ? 1 : A_IT];
     float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0;
-    int okm = 0;
-    float slope = 1.f;
+    int okm = 0, cst = 0;
+    const float slope = d.src[0].slope;                 // both sources of a skip concatenation use LeakyReLU(0.1)
     const int kt_begin = ks * d.kt_per;
     const int nkt = min(d.K / BK, kt_begin + d.kt_per);
     int tap = (kt_begin * BK) / d.Cin, c0 = kt_begin * BK - tap * d.Cin;
-    __syncthreads();       // tapoff / rowpix visible
+    __syncthreads();       // tapdelta / rowpix / sstab visible
 
 #define RP_ISSUE_LOADS(KT)                                                                                        \
     {                                                                                                             \
         const bool s1_ = (d.nsrc > 1) && (c0 >= d.src[0].C);                                                      \
         const float* sx_ = s1_ ? d.src[1].x : d.src[0].x;                                                         \
-        const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                                     \
         const int scs_ = s1_ ? d.src[1].cstride : d.src[0].cstride;                                               \
-        const int sst_ = s1_ ? d.src[1].sstride : d.src[0].sstride;                                               \
-        slope = s1_ ? d.src[1].slope : d.src[0].slope;                                                            \
         const int cc_ = c0 - (s1_ ? d.src[0].C : 0) + kq * 4;                                                     \
-        const int to_ = tapoff[tap];                                                                              \
-        const int oy_ = to_ >> 16, ox_ = (int)(short)(to_ & 0xffff);                                              \
-        okm = 0;                                                                                                  \
+        const int td_ = tapdelta[tap];                                                                            \
+        okm = 0; cst = c0 + kq * 4;                                                                               \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
-            const int iy = r_y[it] + oy_, ix = r_x[it] + ox_;                                                     \
-            const bool ok_ = (r_img[it] >= 0) & (iy >= 0) & (iy < d.Hin) & (ix >= 0) & (ix < d.Win);               \
+            const bool ok_ = (r_mask[it] >> tap) & 1;                                                             \
             okm |= ok_ ? (1 << it) : 0;                                                                           \
-            const int im_ = ok_ ? r_img[it] : 0;                                                                  \
-            const size_t pix = ok_ ? ((size_t)im_ * d.Hin + iy) * d.Win + ix : 0;                                 \
-            ra[it] = *reinterpret_cast<const float4*>(sx_ + pix * scs_ + cc_);                                    \
-            const float4* q = reinterpret_cast<const float4*>(sss_ + (size_t)(im_ >> 1) * sst_ + cc_);            \
-            q0[it] = q[0]; q1[it] = q[1];                                                                         \
+            const int pix_ = ok_ ? r_base[it] + td_ : 0;                                                          \
+            ra[it] = *reinterpret_cast<const float4*>(sx_ + (size_t)pix_ * scs_ + cc_);                           \
+            if (!SSLDS) {                                                                                         \
+                const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                             \
+                const int sst_ = s1_ ? d.src[1].sstride : d.src[0].sstride;                                       \
+                const float4* q = reinterpret_cast<const float4*>(sss_ + (size_t)r_grp[it] * sst_ + cc_);         \
+                q0[SSLDS ? 0 : it] = q[0]; q1[SSLDS ? 0 : it] = q[1];                                             \
+            }                                                                                                     \
         }                                                                                                         \
         rb0 = *reinterpret_cast<const float4*>(b_src[0] + (size_t)(KT) * BK);                                     \
         if (B_IT > 1) rb1 = *reinterpret_cast<const float4*>(b_src[B_IT - 1] + (size_t)(KT) * BK);                \
@@ -168,8 +192,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
     {                                                                                                             \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
             float4 v = ra[it];                                                                                    \
-            v.x = lrelu(v.x * q0[it].x + q0[it].y, slope); v.y = lrelu(v.y * q0[it].z + q0[it].w, slope);         \
-            v.z = lrelu(v.z * q1[it].x + q1[it].y, slope); v.w = lrelu(v.w * q1[it].z + q1[it].w, slope);         \
+            float4 s0_, s1v_;                                                                                     \
+            if (SSLDS) {                                                                                          \
+                const float4* q = reinterpret_cast<const float4*>(&sstab[r_grp[it] + cst]);                       \
+                s0_ = q[0]; s1v_ = q[1];                                                                          \
+            } else { s0_ = q0[SSLDS ? 0 : it]; s1v_ = q1[SSLDS ? 0 : it]; }                                       \
+            v.x = lrelu(v.x * s0_.x + s0_.y, slope); v.y = lrelu(v.y * s0_.z + s0_.w, slope);                     \
+            v.z = lrelu(v.z * s1v_.x + s1v_.y, slope); v.w = lrelu(v.w * s1v_.z + s1v_.w, slope);                 \
             const bool ok_ = (okm >> it) & 1;                                                                     \
             v.x = ok_ ? v.x : 0.f; v.y = ok_ ? v.y : 0.f; v.z = ok_ ? v.z : 0.f; v.w = ok_ ? v.w : 0.f;           \
             *reinterpret_cast<float4*>(&As[BUF][(lrow + it * 64) * LDK + kq * 4]) = v;                            \
@@ -185,7 +214,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
     const int brow = (wn * NI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     for (int kt = kt_begin; kt < nkt; ++kt) {
         const int buf = (kt - kt_begin) & 1;
+#if RP_ABLATE != 2
         if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
+#endif
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             float4 a[MI], b[NI];
@@ -197,10 +228,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
+#if RP_ABLATE == 1
+                    acc[i][j][0] += a[i].x * b[j].x + a[i].y * b[j].y + a[i].z * b[j].z + a[i].w * b[j].w;
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+#endif
                 }
         }
         if (kt + 1 < nkt) RP_STORE_TILE(buf ^ 1)
@@ -268,6 +303,70 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __re
         float* yo = d.y + pix * d.ycstride + d.ychoff + c4;
         if (c4 + 3 < d.Cout) *reinterpret_cast<float4*>(yo) = a;
         else { if (c4 < d.Cout) yo[0] = a.x; if (c4 + 1 < d.Cout) yo[1] = a.y; if (c4 + 2 < d.Cout) yo[2] = a.z; }
+    }
+}
+
+// ---- conv1{rgb,n,d} x {self, warped}: direct 3x3 convolution (mymodel.py:151,155,159 / :266-286) ------------
+// Six tiny convs (Cin 4/4/2 -> 32) of the resized 16-channel input.  K is 36 or 18, far too small for an
+// implicit GEMM; one wave handles 64 pixels of one (modality, stream) block so the weights are wave-uniform
+// (scalar loads, SGPR operands) and every lane accumulates its 32 outputs in registers.
+// w1: [6][9 taps][4 ch][32 out] (zero rows for the 2-channel depth block).
+__global__ __launch_bounds__(256) void conv1_direct_kernel(const float* __restrict__ x0, const float* __restrict__ w1,
+                                                            float* __restrict__ a1, int n) {
+    const int q = blockIdx.y;                        // block 2*m + s
+    const int m = q >> 1, sft = (q & 1) * 8;
+    // input channels of this block inside the 16-channel pixel (mymodel.py:264-286)
+    const int c0 = m == 0 ? sft + 0 : (m == 1 ? sft + 3 : sft + 6);
+    const int nch = m == 2 ? 2 : 4;                  // {rgb|n} + mask, or depth + mask
+    const size_t total = (size_t)n * RS * RS;      // multiple of 64: a wave never straddles the end
+    __shared__ __attribute__((aligned(16))) float wl[9 * 4 * 32];      // this block's weights, read as LDS broadcasts
+    __shared__ __attribute__((aligned(16))) float tile[4 * 64 * 36];
+    for (int i = threadIdx.x; i < 9 * 4 * 32; i += 256) wl[i] = w1[(size_t)q * 9 * 4 * 32 + i];
+    __syncthreads();
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % RS), y = (int)((pix / RS) % RS);
+        float acc[32];
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[o] = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            const bool ok = (iy >= 0) & (iy < RS) & (ix >= 0) & (ix < RS);
+            const float* p = x0 + (pix + (ok ? (ptrdiff_t)(t / 3 - 1) * RS + (t % 3 - 1) : 0)) * 16;
+            // the pixel's 16 channels are one 64-byte line: fetch the two quads that hold this block's inputs
+            const float4 qa = *reinterpret_cast<const float4*>(p + (c0 & ~3));
+            const float4 qb = *reinterpret_cast<const float4*>(p + ((c0 & ~3) + 4 > 12 ? 12 : (c0 & ~3) + 4));
+            const float4 qm = *reinterpret_cast<const float4*>(p + sft + 4);        // channels sft+4..sft+7 (mask = .w)
+            float in[4];                                  // block-uniform selection (m is per block)
+            if (m == 0) { in[0] = qa.x; in[1] = qa.y; in[2] = qa.z; in[3] = qm.w; }
+            else if (m == 1) { in[0] = qa.w; in[1] = qb.x; in[2] = qb.y; in[3] = qm.w; }
+            else { in[0] = qa.z; in[1] = qm.w; in[2] = 0.f; in[3] = 0.f; }
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                const float vin = c == 0 ? in[0] : (c == 1 ? in[1] : (c == 2 ? in[2] : in[3]));
+                const float v = ok ? vin : 0.f;
+#pragma unroll
+                for (int o4 = 0; o4 < 8; ++o4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(&wl[(t * 4 + c) * 32 + o4 * 4]);   // wave-uniform address
+                    acc[o4 * 4 + 0] = fmaf(v, wv.x, acc[o4 * 4 + 0]); acc[o4 * 4 + 1] = fmaf(v, wv.y, acc[o4 * 4 + 1]);
+                    acc[o4 * 4 + 2] = fmaf(v, wv.z, acc[o4 * 4 + 2]); acc[o4 * 4 + 3] = fmaf(v, wv.w, acc[o4 * 4 + 3]);
+                }
+            }
+        }
+        // transpose through LDS: lane l first holds pixel l (32 channels); it then writes chunk (l&7) of
+        // pixels (l>>3)+8*k, so every store instruction covers 8 full 128-B lines
+        float* tw = tile + (threadIdx.x >> 6) * 64 * 36;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            *reinterpret_cast<float4*>(tw + lane * 36 + o * 4) = make_float4(acc[4 * o], acc[4 * o + 1], acc[4 * o + 2], acc[4 * o + 3]);
+        const size_t pix0 = pix - lane;                 // first pixel of this wave (a wave's pixels are consecutive)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pl = (lane >> 3) + 8 * k;
+            const float4 v = *reinterpret_cast<const float4*>(tw + pl * 36 + (lane & 7) * 4);
+            if (pix0 + pl < total) *reinterpret_cast<float4*>(a1 + (pix0 + pl) * 192 + q * 32 + (lane & 7) * 4) = v;
+        }
     }
 }
 
@@ -353,22 +452,49 @@ __global__ void resize_in_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
-// x [n,RS,RS,C] NHWC -> y [n,C,H,W] NCHW
-__global__ void resize_out_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C, int H, int W) {
-    const size_t total = (size_t)n * H * W;
+// x [n,RS,RS,C] NHWC -> y [n,C,H,W] NCHW.  One wave = 64 consecutive output pixels of one row.  The <=26
+// source pixels x 2 source rows they interpolate from are first copied to LDS with contiguous 8-byte loads
+// (C = 54/60 floats per pixel: 8-B aligned), then every lane blends its 4 taps from LDS and writes plane by
+// plane (256 contiguous bytes per store instruction).
+#define RO_MAXW 28
+__global__ __launch_bounds__(256) void resize_out_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float smem_ro[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* srow = smem_ro + (size_t)wave * 2 * RO_MAXW * C;
+    const int segs = (W + 63) / 64;
+    const size_t nseg = (size_t)n * H * segs;
     const float shh = (float)RS / H, sww = (float)RS / W;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(idx % W), oy = (int)((idx / W) % H), img = (int)(idx / ((size_t)H * W));
-        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    for (size_t sidx = (size_t)blockIdx.x * 4 + wave; sidx < nseg; sidx += (size_t)gridDim.x * 4) {
+        const int seg = (int)(sidx % segs), oy = (int)((sidx / segs) % H), img = (int)(sidx / ((size_t)segs * H));
+        const int ox_first = seg * 64, ox_last = min(ox_first + 63, W - 1);
+        int y0, y1, xa, xb, xc, xd; float ly0, ly1, t0, t1;
         lin_coef(oy, shh, RS, y0, y1, ly0, ly1);
-        lin_coef(ox, sww, RS, x0, x1, lx0, lx1);
-        const float* p00 = x + (((size_t)img * RS + y0) * RS + x0) * C;
-        const float* p01 = x + (((size_t)img * RS + y0) * RS + x1) * C;
-        const float* p10 = x + (((size_t)img * RS + y1) * RS + x0) * C;
-        const float* p11 = x + (((size_t)img * RS + y1) * RS + x1) * C;
-        float* o = y + (size_t)img * C * H * W + (size_t)oy * W + ox;
-        for (int c = 0; c < C; ++c)
-            o[(size_t)c * H * W] = ly0 * (lx0 * p00[c] + lx1 * p01[c]) + ly1 * (lx0 * p10[c] + lx1 * p11[c]);
+        lin_coef(ox_first, sww, RS, xa, xb, t0, t1);
+        lin_coef(ox_last, sww, RS, xc, xd, t0, t1);
+        const int sx = xa, width = xd - xa + 1;           // <= RO_MAXW for scale <= 0.4 (224/640 = 0.35)
+        const int nf2 = width * C / 2;
+        for (int r = 0; r < 2; ++r) {
+            const float2* src = reinterpret_cast<const float2*>(x + (((size_t)img * RS + (r ? y1 : y0)) * RS + sx) * C);
+            float2* dst = reinterpret_cast<float2*>(srow + r * RO_MAXW * C);
+            for (int i = lane; i < nf2; i += 64) dst[i] = src[i];
+        }
+        // the wave's own LDS region: make the writes visible to all of its lanes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int ox = ox_first + lane;
+        if (ox < W) {
+            int x0, x1; float lx0, lx1;
+            lin_coef(ox, sww, RS, x0, x1, lx0, lx1);
+            const float* a = srow + (x0 - sx) * C;
+            const float* b = srow + (x1 - sx) * C;
+            const float* cc = a + RO_MAXW * C;
+            const float* dd = b + RO_MAXW * C;
+            float* o = y + (size_t)img * C * H * W + (size_t)oy * W + ox;
+            for (int c = 0; c < C; ++c)
+                o[(size_t)c * H * W] = ly0 * (lx0 * a[c] + lx1 * b[c]) + ly1 * (lx0 * cc[c] + lx1 * dd[c]);
+        }
+        __builtin_amdgcn_wave_barrier();                 // LDS region is reused by the next segment
     }
 }
 
@@ -403,6 +529,7 @@ struct RelposeSCNet {
     float* d_w = nullptr;        // packed weights + biases
     float* d_gb = nullptr;       // gamma/beta per activation buffer [2][C]
     float2* d_ident = nullptr;   // 16 x {1,0}: scale/shift of the raw network input
+    size_t w1_off = 0;           // conv1 direct-kernel weights inside d_w
     ConvDesc* d_descs = nullptr; // device copy of the launch plan's descriptor table
     void* plan = nullptr;        // Plan* (anonymous namespace type)
     std::map<std::string, Layer> layers;
@@ -585,8 +712,8 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2 };
-struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3 };
+struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0; };
 
 struct Plan {
     int n = 0; void* ws = nullptr;
@@ -693,6 +820,14 @@ void Builder::end_group() {
     plan->splitk_floats = std::max(plan->splitk_floats, pf);
     Op o; o.type = OP_CONV; o.first = first; o.count = count; o.cfg = cfg;
     o.grid = dim3(max_mt, (cp / BNt) * ksplit, count);
+    // LDS scale/shift table: every member must fit (groups spanned by a tile) x Cin entries in 1024
+    o.sslds = 1;
+    for (int i = first; i < first + count; ++i) {
+        const ConvDesc& d = plan->descs[i];
+        const int hw = d.Hp * d.Wp;
+        const int ng = (BMt - 1) / (2 * hw) + 2;
+        if ((long)ng * d.Cin > (cfg == 0 ? 1024 : 512) || d.src[0].sstride == 0) o.sslds = 0;
+    }
     plan->ops.push_back(o);
     if (ksplit > 1) {
         Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
@@ -707,7 +842,7 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
         R.begin_group(); R.conv(layer, s0, s1, Hin, out, ochoff); R.end_group();
     };
     // encoder, three modalities x two streams in concatenated buffers (mymodel.py:266-291)
-    one("conv1", R.src("X0", 0, 16), nullptr, 224, "A1", 0);
+    { Op o; o.type = OP_CONV1; o.first = o.count = o.cfg = 0; R.plan->ops.push_back(o); }   // direct kernel
     R.stats("A1");
     R.begin_group();
     for (int q = 0; q < 6; ++q) R.conv(std::string("conv2") + mods[q / 2], R.src("A1", q * 32, 32), nullptr, 224, "A2", q * 64);
@@ -816,6 +951,21 @@ int relpose_scnet_finalize(RelposeSCNet* net) {
         int rc = pack_layer(net, sp, blob);
         if (rc) return rc;
     }
+    {   // conv1 direct kernel weights: [6][9][4][32]; depth block: channel 0 = depth, 1 = mask, 2..3 = 0
+        net->w1_off = blob.size();
+        blob.resize(blob.size() + 6 * 9 * 4 * 32, 0.f);
+        float* w1 = blob.data() + net->w1_off;
+        const char* mods[3] = {"rgb", "n", "d"};
+        for (int m = 0; m < 3; ++m) {
+            const int cin_m = m == 2 ? 2 : 4;
+            const float* W = net->params[std::string("conv1") + mods[m] + ".0.weight"].data();
+            for (int s2 = 0; s2 < 2; ++s2)
+                for (int t = 0; t < 9; ++t)
+                    for (int c = 0; c < cin_m; ++c)
+                        for (int o = 0; o < 32; ++o)
+                            w1[(((size_t)(2 * m + s2) * 9 + t) * 4 + c) * 32 + o] = W[((size_t)o * cin_m + c) * 9 + t];
+        }
+    }
     // activation buffers
     net->bufs.clear();
     size_t off = 0, ssoff = 0, gboff = 0;
@@ -903,9 +1053,20 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         if (op.type == OP_CONV) {
             mark(1);
             const ConvDesc* dd = net->d_descs + op.first;
-            if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2>), op.grid, dim3(256), 0, s, dd);
-            else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2>), op.grid, dim3(256), 0, s, dd);
-            else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1>), op.grid, dim3(256), 0, s, dd);
+            if (op.sslds) {
+                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true>), op.grid, dim3(256), 0, s, dd);
+                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true>), op.grid, dim3(256), 0, s, dd);
+                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, true>), op.grid, dim3(256), 0, s, dd);
+            } else {
+                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, false>), op.grid, dim3(256), 0, s, dd);
+                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, false>), op.grid, dim3(256), 0, s, dd);
+                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, false>), op.grid, dim3(256), 0, s, dd);
+            }
+            mark(-1);
+        } else if (op.type == OP_CONV1) {
+            mark(1);
+            hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024, 6), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
+                               act + net->bufs["A1"].off * n, n);
             mark(-1);
         } else if (op.type == OP_REDUCE) {
             mark(4);
@@ -930,7 +1091,8 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         }
     }
     mark(3);
-    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), 0, s, act + net->bufs["OUT"].off * n, out, n, net->cf, H, W);
+    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), (size_t)4 * 2 * RO_MAXW * net->cf * sizeof(float), s,
+                       act + net->bufs["OUT"].off * n, out, n, net->cf, H, W);
     mark(-3);
     RP_CHECK_LAUNCH();
     return 0;

@@ -75,3 +75,18 @@ def conv_layers(rows, n=64, which=3):
 
 if __name__ == "__main__" and len(sys.argv) > 2:
     print(conv_layers(load(sys.argv[1]), int(sys.argv[2])))
+
+
+def pmc(db):
+    """{(dispatch_id, kernel, start, end): {counter: summed value}} from a rocprofv3 --pmc run."""
+    c = sqlite3.connect(db)
+    t = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    T = lambda k: [x for x in t if k in x][0]
+    pe, ip, kd, ks = T('rocpd_pmc_event'), T('rocpd_info_pmc'), T('kernel_dispatch'), T('kernel_symbol')
+    out = {}
+    for name, st, en, did, cname, val in c.execute(
+            f"select s.kernel_name, d.start, d.end, d.id, p.name, e.value from {pe} e join {ip} p on e.pmc_id=p.id "
+            f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id"):
+        d = out.setdefault((did, name, st, en), {})
+        d[cname] = d.get(cname, 0.0) + val
+    return out
