@@ -63,6 +63,7 @@ struct ConvDesc {
     int ksplit, kt_per;    // split-K: slices along K and k-tiles per slice (ksplit==1: direct store)
     int ntiles_n;          // N tiles (grid.y = ntiles_n * ksplit)
     float* partial;        // [ksplit][M][CoutPad] partial sums when ksplit > 1
+    double* stat_part;     // [mtiles][2 group slots][CoutPad][2] per-tile BatchNorm partial sums (or null)
     int cout_pad;
 };
 
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
     __shared__ __attribute__((aligned(16))) float2 sstab[SSLDS ? SS_CAP : 4];
     __shared__ int rowpix[BM];
+    __shared__ signed char rowslot[BM];        // BatchNorm group of the row relative to the tile's first group
     __shared__ int tapdelta[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
             const int img = m / hw, rem = m - img * hw;
             const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
             pix = (img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
-        }
+            rowslot[tid] = (signed char)min((img >> 1) - g0, 1);
+        } else rowslot[tid] = -1;
         rowpix[tid] = pix;
     }
     if (tid < 16) tapdelta[tid] = (int)descs[blockIdx.z].offy[tid] * d.Win + (int)descs[blockIdx.z].offx[tid];
@@ -257,6 +260,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
                 for (int j = 0; j < NI; ++j) po[(size_t)m * d.cout_pad + n0 + wn * NI * 32 + j * 32 + (lane & 31)] = acc[i][j][r];
             }
         return;
+    }
+    if (d.stat_part) {
+        // Fused BatchNorm statistics: float64 sum / sum of squares of this tile's raw outputs per column and
+        // per group slot (a tile spans at most two groups here), reduced in a fixed order:
+        // lane rows -> lane pair (xor 32) -> the WM waves of a column (LDS, in order) -> one record per tile.
+        double* red = reinterpret_cast<double*>(&As[0][0]);       // main loop is over (it ended with a barrier)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            double s0 = 0, q0s = 0, s1 = 0, q1s = 0;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int sl = rowslot[row];
+                    const double v = (double)acc[i][j][r];
+                    if (sl == 0) { s0 += v; q0s += v * v; } else if (sl == 1) { s1 += v; q1s += v * v; }
+                }
+            s0 += rp_shfl_xor_d(s0, 32); q0s += rp_shfl_xor_d(q0s, 32);
+            s1 += rp_shfl_xor_d(s1, 32); q1s += rp_shfl_xor_d(q1s, 32);
+            if (lane < 32) {
+                const int cl = wn * NI * 32 + j * 32 + lane;
+                red[((0 * WM + wm) * BN + cl) * 2 + 0] = s0; red[((0 * WM + wm) * BN + cl) * 2 + 1] = q0s;
+                red[((1 * WM + wm) * BN + cl) * 2 + 0] = s1; red[((1 * WM + wm) * BN + cl) * 2 + 1] = q1s;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += 256) {
+            const int sl = idx / BN, cl = idx - sl * BN;
+            double a = 0, b = 0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { a += red[((sl * WM + w) * BN + cl) * 2]; b += red[((sl * WM + w) * BN + cl) * 2 + 1]; }
+            double* o = d.stat_part + (((size_t)blockIdx.x * 2 + sl) * d.cout_pad + n0 + cl) * 2;
+            o[0] = a; o[1] = b;
+        }
     }
     float bias_v[NI];
 #pragma unroll
@@ -414,6 +452,33 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nchun
     }
     const double mean = s / rows_per_group;
     double var = q / rows_per_group - mean * mean;       // biased variance (training-mode BN)
+    if (var < 0) var = 0;
+    const double sc = (double)gamma[c] / sqrt(var + BN_EPS);
+    ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
+}
+
+// Finalise BatchNorm from the per-tile records written by the conv epilogue.  One thread per (group, channel);
+// the records of every launch member that wrote this channel are added in (member, tile) order.
+__global__ void bn_finalize_fused_kernel(const ConvDesc* __restrict__ descs, int ndesc, int BMt, int C, int rows_per_group,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float2* __restrict__ ss) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int z = 0; z < ndesc; ++z) {
+        const ConvDesc& d = descs[z];
+        const int cl = c - d.ychoff;
+        if (cl < 0 || cl >= d.Cout) continue;
+        const int hw = d.Hp * d.Wp;
+        const int t0 = (2 * g * hw) / BMt, t1 = min(((2 * g + 2) * hw - 1) / BMt, (d.M - 1) / BMt);
+        for (int t = t0; t <= t1; ++t) {
+            const int sl = g - (((t * BMt) / hw) >> 1);
+            if (sl < 0 || sl > 1) continue;
+            const double* p = d.stat_part + (((size_t)t * 2 + sl) * d.cout_pad + cl) * 2;
+            s += p[0]; q += p[1];
+        }
+    }
+    const double mean = s / rows_per_group;
+    double var = q / rows_per_group - mean * mean;
     if (var < 0) var = 0;
     const double sc = (double)gamma[c] / sqrt(var + BN_EPS);
     ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
@@ -712,7 +777,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3 };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4 };
 struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0; };
 
 struct Plan {
@@ -720,11 +785,13 @@ struct Plan {
     std::vector<ConvDesc> descs;
     std::vector<Op> ops;
     size_t splitk_floats = 0;
+    size_t stat_doubles = 0;     // per-tile BatchNorm records of all fused-statistics groups
 };
 
 struct Builder {
     RelposeSCNet* net; int n, G;
-    float* act; float2* ss; float* splitk;   // may be null for a sizing dry run
+    float* act; float2* ss; float* splitk; double* statp;   // may be null for a sizing dry run
+    int pend_first = -1, pend_count = 0, pend_bm = 0; bool pend_ok = true;   // conv groups since the last stats() call
     Plan* plan;
     int rc = 0;
     int group_first = -1;
@@ -735,11 +802,23 @@ struct Builder {
     void begin_group() { group_first = (int)plan->descs.size(); }
     void end_group();
     void conv(const std::string& layer, Src s0, const Src* s1, int Hin, const std::string& out, int ochoff);
-    void stats(const std::string& b) { Op o; o.type = OP_STATS; o.buf = b; o.first = o.count = o.cfg = 0; plan->ops.push_back(o); }
+    void stats(const std::string& b);
 };
 
 size_t partial_doubles(int G) { return (size_t)G * 64 * 1024 * 2; }
 constexpr int MAX_DESCS = 256;
+
+void Builder::stats(const std::string& b) {
+    Op o; o.buf = b; o.cfg = 0;
+    if (pend_first >= 0 && pend_ok) { o.type = OP_STATS_FUSED; o.first = pend_first; o.count = pend_count; o.cfg = pend_bm; }
+    else {
+        o.type = OP_STATS; o.first = o.count = 0;
+        // a mixed / ineligible producer set: drop the per-tile records again (they would be written for nothing)
+        if (pend_first >= 0) for (int i = pend_first; i < pend_first + pend_count; ++i) plan->descs[i].stat_part = nullptr;
+    }
+    plan->ops.push_back(o);
+    pend_first = -1; pend_count = 0;
+}
 
 float* Builder::buf(const std::string& b) { return act ? act + net->bufs[b].off * n : nullptr; }
 float2* Builder::ssb(const std::string& b) { return ss ? ss + net->bufs[b].ss_off * G : nullptr; }
@@ -818,6 +897,20 @@ void Builder::end_group() {
         if (ksplit > 1) { d.partial = splitk ? splitk + pf : nullptr; pf += (size_t)ksplit * d.M * cp; }
     }
     plan->splitk_floats = std::max(plan->splitk_floats, pf);
+    // fused BatchNorm statistics: no split-K and every tile inside <= 2 groups (2*hw >= BM)
+    bool fuse = (ksplit == 1);
+    for (int i = first; i < first + count; ++i) fuse = fuse && (2 * plan->descs[i].Hp * plan->descs[i].Wp >= BMt) && !plan->descs[i].bias;
+    if (pend_first < 0) { pend_first = first; pend_count = 0; pend_bm = BMt; pend_ok = true; }
+    pend_count += count;
+    pend_ok = pend_ok && fuse && (pend_bm == BMt);
+    if (fuse) {
+        for (int i = first; i < first + count; ++i) {
+            ConvDesc& d = plan->descs[i];
+            const size_t nd = (size_t)((d.M + BMt - 1) / BMt) * 2 * cp * 2;
+            d.stat_part = statp ? statp + plan->stat_doubles : (double*)(uintptr_t)8;   // non-null marker in the dry run
+            plan->stat_doubles += nd;
+        }
+    }
     Op o; o.type = OP_CONV; o.first = first; o.count = count; o.cfg = cfg;
     o.grid = dim3(max_mt, (cp / BNt) * ksplit, count);
     // LDS scale/shift table: every member must fit (groups spanned by a tile) x Cin entries in 1024
@@ -892,11 +985,11 @@ void free_plan(RelposeSCNet* net) {
     if (net->plan) { delete (Plan*)net->plan; net->plan = nullptr; }
 }
 
-struct WsOffsets { size_t act, ss, partial, splitk, total; };
+struct WsOffsets { size_t act, ss, partial, splitk, statp, total; };
 
 WsOffsets ws_offsets(RelposeSCNet* net, int n) {
     Plan dry;
-    Builder B; B.net = net; B.n = n; B.G = n / 2; B.act = nullptr; B.ss = nullptr; B.splitk = nullptr; B.plan = &dry;
+    Builder B; B.net = net; B.n = n; B.G = n / 2; B.act = nullptr; B.ss = nullptr; B.splitk = nullptr; B.statp = nullptr; B.plan = &dry;
     build_plan(net, n, B);
     WsOffsets o;
     size_t off = 0;
@@ -904,6 +997,7 @@ WsOffsets ws_offsets(RelposeSCNet* net, int n) {
     o.ss = off; off += rp_align(net->ss_float2_per_group * (n / 2) * sizeof(float2));
     o.partial = off; off += rp_align(partial_doubles(n / 2) * sizeof(double));
     o.splitk = off; off += rp_align(dry.splitk_floats * sizeof(float));
+    o.statp = off; off += rp_align(dry.stat_doubles * sizeof(double));
     o.total = off;
     return o;
 }
@@ -1025,7 +1119,7 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         plan->n = n; plan->ws = workspace;
         char* ws = (char*)workspace;
         Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan;
-        B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk);
+        B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk); B.statp = (double*)(ws + o.statp);
         build_plan(net, n, B);
         if (B.rc) { delete plan; return B.rc; }
         if (!net->d_descs) RP_HIP(hipMalloc((void**)&net->d_descs, MAX_DESCS * sizeof(ConvDesc)));
@@ -1068,6 +1162,12 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024, 6), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                act + net->bufs["A1"].off * n, n);
             mark(-1);
+        } else if (op.type == OP_STATS_FUSED) {
+            const Buf& B = net->bufs[op.buf];
+            mark(2);
+            hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((B.C + 127) / 128, G), dim3(128), 0, s, net->d_descs + op.first, op.count, op.cfg,
+                               B.C, 2 * B.H * B.H, net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
+            mark(-2);
         } else if (op.type == OP_REDUCE) {
             mark(4);
             hipLaunchKernelGGL(splitk_reduce_kernel, op.grid, dim3(256), 0, s, net->d_descs + op.first);

@@ -47,7 +47,7 @@ def conv_layers(rows, n=64, which=3):
         if 'resize_out' in r[0] and on:
             break
     P = lambda M, K, C: 2.0 * M * K * C
-    G = [('conv1', P(n * 224 * 224, 144, 192)), ('conv2 x6', 6 * P(n * 112 * 112, 512, 64)), ('conv3 x6', 6 * P(n * 56 * 56, 1024, 128)),
+    G = [('conv2 x6', 6 * P(n * 112 * 112, 512, 64)), ('conv3 x6', 6 * P(n * 56 * 56, 1024, 128)),
          ('conv4', P(n * 784, 12288, 256)), ('conv5', P(n * 196, 4096, 512)), ('conv6', P(n * 49, 8192, 512)),
          ('conv7', P(n * 9, 4608, 512)), ('conv8', P(n * 9, 4608, 512)), ('conv9', P(n, 4608, 1024)),
          ('deconv9', P(n * 9, 9216, 512)), ('deconv8', P(n * 9, 9216, 512)),
@@ -57,12 +57,17 @@ def conv_layers(rows, n=64, which=3):
          ('deconv2 rgb/n/d', 12 * P(n * 12544, 512, 32)), ('deconv2 s/f', 8 * P(n * 12544, 256, 64)),
          ('heads', sum(P(n * 50176, 64, c) for c in (3, 3, 1, 15, 32)))]
     convs = [r for r in seq if 'conv_igemm' in r[0]]
+    c1 = [r for r in seq if 'conv1_direct' in r[0]]
     red = sum((r[2] - r[1]) / 1e3 for r in seq if 'splitk_reduce' in r[0])
     out = [f"{len(convs)} conv launches in forward #{which} (expected {len(G)})"]
     tot = sum((r[2] - r[1]) / 1e3 for r in convs)
     for r, (name, fl) in zip(convs, G):
         d = (r[2] - r[1]) / 1e3
         out.append(f"{name:16s} grid=({r[3]//256:5d},{r[4]:3d},{r[5]:2d}) time={d:9.1f}us {100*d/tot:5.1f}%  useful TFLOP/s={fl/d/1e6:6.1f}")
+    if c1:
+        d1 = (c1[0][2] - c1[0][1]) / 1e3
+        f1 = 2.0 * n * 224 * 224 * 192 * 36 * (10 / 12)      # 4 blocks with 36 and 2 blocks with 18 real MACs per output
+        out.append(f"{'conv1 (direct)':16s} time={d1:9.1f}us  useful TFLOP/s={f1/d1/1e6:6.1f} (VALU; writes {n*224*224*192*4/1e9:.2f} GB -> {n*224*224*192*4/d1/1e3:.0f} GB/s)")
     out.append(f"conv total {tot:.1f} us (+ split-K reduce {red:.1f} us), useful {sum(f for _, f in G)/tot/1e6:.1f} TFLOP/s; "
                f"forward wall {(seq[-1][2]-seq[0][1])/1e3:.1f} us")
     oth = {}
