@@ -1,0 +1,75 @@
+"""sigma tuning of the pose module: the finite-difference
+objective of the reference's trainRelativePoseModuleRecFD.py:215-298, with every
+objective evaluation done as ONE batched `match_pairs` call on the GPU instead of
+a Python loop over cached primitives.
+
+A cached primitive is the reference's dict (trainRelativePoseModuleRecFD.py:207-208):
+  pc_src/normal_src/feat_src/weight_src, pc_tgt/..., R_gt.
+"""
+import numpy as np
+
+from . import _lib, rpmodule
+
+
+def angular_distance_np(R_hat, R):
+    """util.py:176-187 (degrees)."""
+    R_hat = np.asarray(R_hat).reshape(-1, 3, 3)
+    R = np.asarray(R).reshape(-1, 3, 3)
+    tr = np.matmul(R_hat, R.transpose(0, 2, 1)).reshape(len(R), -1)[:, [0, 4, 8]].sum(1)
+    return np.arccos(((tr - 1) / 2).clip(-1, 1)) / np.pi * 180.0
+
+
+class PrimitiveSet:
+    """Cached primitives resident on the device (uploaded once, reused by every objective call)."""
+
+    def __init__(self, primitives):
+        dev = _lib.require_gpu()
+        cases = [({'pc': p['pc_src'], 'normal': p['normal_src'], 'feat': p['feat_src'], 'weight': p['weight_src']},
+                  {'pc': p['pc_tgt'], 'normal': p['normal_tgt'], 'feat': p['feat_tgt'], 'weight': p['weight_tgt']}) for p in primitives]
+        self.args = rpmodule.pack_keypoints(cases, dev)
+        self.R_gt = np.stack([np.asarray(p['R_gt'], dtype=np.float64) for p in primitives])
+
+    def poses(self, para):
+        return rpmodule.match_pairs(*self.args, para).pose.cpu().numpy()
+
+
+def objective(prims, para):
+    """trainRelativePoseModuleRecFD.py:215-233: (mean squared Frobenius rotation error, mean angular distance)."""
+    if not isinstance(prims, PrimitiveSet):
+        prims = PrimitiveSet(prims)
+    R_hat = prims.poses(para)
+    loss = np.power(R_hat[:, :3, :3] - prims.R_gt[:, :3, :3], 2).sum((1, 2))
+    ad = angular_distance_np(R_hat[:, :3, :3], prims.R_gt[:, :3, :3])
+    return float(loss.sum() / len(loss)), float(ad.sum() / len(ad))
+
+
+def make_para(sig):
+    p = rpmodule.opts()
+    p.sigmaAngle1, p.sigmaAngle2, p.sigmaDist, p.sigmaFeat = [float(v) for v in sig]
+    return p
+
+
+def tune_step(prims, sigmas, rng, n_probe=10, objective_fn=objective):
+    """One outer iteration of trainRelativePoseModuleRecFD.py:245-298: finite-difference gradient from
+    `n_probe` random relative perturbations (least squares), normalised step, halving line search.
+    `rng.uniform(size=4)` replaces the reference's global np.random.uniform.  Returns
+    (new sigmas [4], loss, ad, found_descent)."""
+    if not isinstance(prims, PrimitiveSet) and objective_fn is objective:
+        prims = PrimitiveSet(prims)
+    sig = np.asarray(sigmas, dtype=np.float64)
+    eps = np.zeros((n_probe, 4))
+    losses, ads = np.zeros(n_probe), np.zeros(n_probe)
+    for j in range(n_probe):
+        if j >= 1:
+            eps[j] = (rng.uniform(size=4) - 0.5) / 5
+        losses[j], ads[j] = objective_fn(prims, make_para(sig * (1 + eps[j])))
+    grad = np.linalg.lstsq(eps[1:], losses[1:] - losses[0], rcond=None)[0]
+    grad = grad / max(np.abs(grad / sig))
+    alpha = 1.0
+    for _ in range(10):
+        cand = sig * (1 + -1 * grad * alpha)
+        loss, ad = objective_fn(prims, make_para(cand))
+        if loss < losses[0]:
+            return cand, loss, ad, True
+        alpha /= 2
+    return sig, float(losses[0]), float(ads[0]), False
