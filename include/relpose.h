@@ -143,6 +143,19 @@ int relpose_sample_primitives(const float* f, int32_t cf, int32_t feat_off,
                               double* pc, double* normal, float* feat,
                               int32_t n, int32_t h, int32_t mask_method, int32_t dataset, void* stream);
 
+/* ------------------------------------------------- evaluation-side statistics
+ * util.depth2pc (util.py:468-523) of the observed block of each panorama (the face / kinect crop that
+ * util.parse_data :42-92 feeds it): pc [n, P, 3] f64 in pixel order, valid [n, P] = depth != 0, with
+ * P = relpose_observed_points(h, dataset) (25600 or 66*88 at h = 160). */
+int32_t relpose_observed_points(int32_t h, int32_t dataset);
+int relpose_depth2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, int32_t h, int32_t dataset, void* stream);
+
+/* Nearest-neighbour distances behind util.point_cloud_overlap (util.py:21-40, sklearn KDTree there):
+ * dist[i] = min_j || pose*query_i - ref_j || over valid ref points (pose [12+] row-major 3x4/4x4, or NULL);
+ * invalid query points get -1.  query [nq,3], ref [nr,3] f64. */
+int relpose_nn_dist(const double* query, const uint8_t* query_valid, int32_t nq, const double* ref, const uint8_t* ref_valid,
+                    int32_t nr, const double* pose, double* dist, void* stream);
+
 /* -------------------------------------------------------------------- SCNet
  * Replaces SCNet (model/mymodel.py:141-380; skipLayer=1, batchnorm=1, outputType 'rgbdnsf'). */
 typedef struct RelposeSCNet RelposeSCNet;

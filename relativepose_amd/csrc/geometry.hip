@@ -291,6 +291,68 @@ __global__ void sample_primitives_kernel(const float* __restrict__ f, int cf, in
     }
 }
 
+// ---- evaluation-side statistics: util.parse_data / point_cloud_overlap -----------------------
+// depth2pc (util.py:468-523) of the observed block of each panorama: points in pixel order + validity
+// (depth != 0); the same unprojection the warp uses (warp_point with the identity pose).
+__global__ void depth2pc_kernel(const float* __restrict__ depth, double* __restrict__ pc, uint8_t* __restrict__ valid,
+                                int n, int h, int dataset, WarpSrc s) {
+    const int img = blockIdx.y;
+    const size_t hw = (size_t)h * 4 * h;
+    const float* d = depth + (size_t)img * hw;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < s.npts; p += gridDim.x * blockDim.x) {
+        const int v = p / s.pw, u = p - v * s.pw;
+        const double z = (double)d[(size_t)(s.y0 + v) * 4 * h + s.x0 + u];
+        double X, Y, Z;
+        if (dataset == RELPOSE_SCANNET) {
+            const int ph = s.npts / s.pw;
+            const double xs = ((double)u / s.pw - 0.5) * 2, ys = (0.5 - (double)v / ph) * 2;
+            X = (xs * z) * s.pw / 160; Y = (ys * z) * ph / 160; Z = -z;
+        } else {
+            const double xs = ((double)u / h - 0.5) * 2, ys = (0.5 - (double)v / h) * 2;
+            if (dataset == RELPOSE_SUNCG) face_rot(1, xs * z, ys * z, -z, X, Y, Z);
+            else { X = xs * z; Y = ys * z; Z = -z; }
+        }
+        double* o = pc + ((size_t)img * s.npts + p) * 3;
+        o[0] = X; o[1] = Y; o[2] = Z;
+        valid[(size_t)img * s.npts + p] = (z != 0.0);
+    }
+}
+
+// Nearest-neighbour distance of every (optionally rigidly moved) query point to a reference set: brute force,
+// reference points staged through LDS in tiles of 1024.  Replaces the sklearn KDTree queries of
+// util.point_cloud_overlap (util.py:21-40); distances are sqrt((dx^2+dy^2)+dz^2) like KDTree's metric.
+__global__ __launch_bounds__(256) void nn_dist_kernel(const double* __restrict__ q, const uint8_t* __restrict__ qv, int nq,
+                                                       const double* __restrict__ r, const uint8_t* __restrict__ rv, int nr,
+                                                       const double* __restrict__ T, double* __restrict__ out) {
+    __shared__ double rs[1024 * 3];
+    __shared__ uint8_t rok[1024];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double x = 0, y = 0, z = 0;
+    if (i < nq) {
+        const double a = q[(size_t)i * 3], b = q[(size_t)i * 3 + 1], c = q[(size_t)i * 3 + 2];
+        if (T) {      // np.matmul(R[:3,:3], pc.T) + R[:3,3:4]
+            x = ((T[0] * a + T[1] * b) + T[2] * c) + T[3];
+            y = ((T[4] * a + T[5] * b) + T[6] * c) + T[7];
+            z = ((T[8] * a + T[9] * b) + T[10] * c) + T[11];
+        } else { x = a; y = b; z = c; }
+    }
+    double best = INFINITY;
+    for (int t0 = 0; t0 < nr; t0 += 1024) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 1024 * 3; k += 256) rs[k] = (t0 * 3 + k < nr * 3) ? r[(size_t)t0 * 3 + k] : 0.0;
+        for (int k = threadIdx.x; k < 1024; k += 256) rok[k] = (t0 + k < nr) && (!rv || rv[t0 + k]);
+        __syncthreads();
+        const int lim = min(1024, nr - t0);
+        for (int k = 0; k < lim; ++k) {
+            if (!rok[k]) continue;
+            const double dx = x - rs[k * 3], dy = y - rs[k * 3 + 1], dz = z - rs[k * 3 + 2];
+            const double d2 = (dx * dx + dy * dy) + dz * dz;
+            best = d2 < best ? d2 : best;
+        }
+    }
+    if (i < nq) out[i] = (!qv || qv[i]) ? sqrt(best) : -1.0;
+}
+
 inline int grid_for(size_t total, int block = 256, int cap = 4096) {
     size_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
@@ -356,6 +418,26 @@ int relpose_sample_primitives(const float* f, int32_t cf, int32_t feat_off, cons
         return RELPOSE_EINVAL;
     hipLaunchKernelGGL(sample_primitives_kernel, dim3((npts_max + 63) / 64, n), dim3(64), 0, (hipStream_t)stream, f, cf, feat_off,
                        obs_norm, obs_depth, pts, npts, npts_max, pc, normal, feat, n, h, observed_box(mask_method, h), dataset);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+
+int relpose_depth2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, int32_t h, int32_t dataset, void* stream) {
+    if (!depth || !pc || !valid || n <= 0 || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
+    const WarpSrc src = warp_src(dataset, h);
+    hipLaunchKernelGGL(depth2pc_kernel, dim3((src.npts + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, depth, pc, valid, n, h, dataset, src);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int32_t relpose_observed_points(int32_t h, int32_t dataset) { return (h > 0 && dataset >= 0 && dataset <= 2) ? warp_src(dataset, h).npts : 0; }
+
+int relpose_nn_dist(const double* query, const uint8_t* query_valid, int32_t nq, const double* ref, const uint8_t* ref_valid, int32_t nr,
+                    const double* pose, double* dist, void* stream) {
+    if (!query || !ref || !dist || nq <= 0 || nr <= 0) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(nn_dist_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, query, query_valid, nq, ref, ref_valid, nr,
+                       pose, dist);
     RP_CHECK_LAUNCH();
     return 0;
 }

@@ -138,3 +138,63 @@ def Pano2PointCloud(depth, dataList):
     pc, valid = pano2pc_dev(d, dataList)
     pc, valid = pc[0].cpu().numpy(), valid[0].cpu().numpy().astype(bool)
     return pc[:, valid]
+
+
+# ---- evaluation-side statistics ---------------------------------------------------------------
+
+def depth2pc_dev(depth, dataset):
+    """depth [n,h,4h] f32 CUDA -> (pc [n,P,3] f64, valid [n,P] uint8) of the observed block (util.depth2pc)."""
+    import torch
+    _lib.require_gpu()
+    n, h, w = depth.shape
+    L = _lib.lib()
+    P = L.relpose_observed_points(h, dataset_id(dataset))
+    pc = torch.empty(n, P, 3, dtype=torch.float64, device=depth.device)
+    valid = torch.empty(n, P, dtype=torch.uint8, device=depth.device)
+    _lib.check(L.relpose_depth2pc(_lib.ptr(depth.contiguous()), _lib.ptr(pc), _lib.ptr(valid), n, h, dataset_id(dataset), _lib.stream_ptr()),
+               "relpose_depth2pc")
+    return pc, valid
+
+
+def nn_dist_dev(query, ref, pose=None, query_valid=None, ref_valid=None):
+    """min distance of every (pose-moved) query point [nq,3] to the reference set [nr,3] (f64 CUDA tensors)."""
+    import torch
+    out = torch.empty(query.shape[0], dtype=torch.float64, device=query.device)
+    rc = _lib.lib().relpose_nn_dist(_lib.ptr(query.contiguous()), _lib.ptr(query_valid), query.shape[0], _lib.ptr(ref.contiguous()),
+                                    _lib.ptr(ref_valid), ref.shape[0], _lib.ptr(pose), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(rc, "relpose_nn_dist")
+    return out
+
+
+def point_cloud_overlap(pc_src, pc_tgt, R_gt_44):
+    """util.py:21-40 with the two KDTree queries replaced by brute-force GPU nearest neighbours.
+    numpy in, (overlap_val, cam_dist, pc_dist, pc_nn) out."""
+    import torch
+    dev = _lib.require_gpu()
+    ps = torch.from_numpy(np.ascontiguousarray(pc_src, dtype=np.float64)).to(dev)
+    pt = torch.from_numpy(np.ascontiguousarray(pc_tgt, dtype=np.float64)).to(dev)
+    R = np.ascontiguousarray(R_gt_44, dtype=np.float64)
+    d_s2t = nn_dist_dev(ps, pt, torch.from_numpy(R).to(dev)).cpu().numpy()
+    d_t2s = nn_dist_dev(pt, ps, torch.from_numpy(np.ascontiguousarray(np.linalg.inv(R))).to(dev)).cpu().numpy()
+    ov = max((d_s2t < 0.08).sum() / pc_src.shape[0], (d_t2s < 0.08).sum() / pc_tgt.shape[0])
+    src_trans = np.matmul(R[:3, :3], pc_src.T) + R[:3, 3:4]
+    return ov, np.linalg.norm(R[:3, 3]), np.linalg.norm(src_trans.mean(1) - pc_tgt.T.mean(1)), (d_s2t.min() + d_t2s.min()) / 2
+
+
+def depth2pc(depth, dataList):
+    """util.py:468: depth numpy = one h x h face (suncg / matterport) or the 66x88 kinect crop (scannet)
+    -> (pc [k,3] of the non-zero depths, mask)."""
+    import torch
+    dev = _lib.require_gpu()
+    ds = dataset_id(dataList)
+    hh, ww = depth.shape
+    h = 160 if ds == 2 else hh
+    pano = np.zeros((1, h, 4 * h), np.float32)
+    if ds == 2:
+        assert (hh, ww) == (66, 88), "only the kinect crop of the hot path is supported"
+        pano[0, 47:113, 196:284] = depth
+    else:
+        pano[0, :, h:2 * h] = depth
+    pc, valid = depth2pc_dev(torch.from_numpy(pano).to(dev), dataList)
+    m = valid[0].cpu().numpy().astype(bool)
+    return pc[0].cpu().numpy()[m], m

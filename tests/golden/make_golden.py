@@ -270,9 +270,28 @@ def gen_e2e():
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
 
 
+def gen_stats():
+    """util.parse_data + util.point_cloud_overlap of the reference on synthetic pairs."""
+    R = ref_loader.load()
+    util = R["util"]
+    out = {}
+    for ds, mm, seed in GEOM_CASES:
+        d = synth.make_pairs(1, seed + 40, ds)
+        rgb_u8 = (d["rgb"] * 255).clip(0, 255).astype("uint8")
+        res = util.parse_data(d["depth"], rgb_u8, d["norm"], ds, "ours")
+        pc_src, pc_tgt = res[6], res[7]
+        R_gt = np.matmul(d["R"][0, 1], np.linalg.inv(d["R"][0, 0]))
+        ov = util.point_cloud_overlap(pc_src, pc_tgt, R_gt)
+        out[f"stats_{ds}_n"] = np.array([len(pc_src), len(pc_tgt)])
+        out[f"stats_{ds}_pc_head"] = pc_src[:128]
+        out[f"stats_{ds}_overlap"] = np.array(ov, dtype=np.float64)
+        out[f"stats_{ds}_Rgt"] = R_gt
+    np.savez_compressed(os.path.join(HERE, "stats.npz"), **out)
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
-    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e"]
+    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e", "stats"]
     for g in groups:
         t = time.time()
         globals()["gen_" + g]()

@@ -139,3 +139,15 @@ def test_e2e_loop_matches_reference(ge, gm, ci):
         # random-init features make the fit ill-conditioned: roundoff-level
         # differences (summation order) are amplified to ~1e-6 per step
         assert np.abs(trace[step] - ge[f"e2e_{ci}_R{step}"]).max() < 1e-4, (ci, step)
+
+
+@pytest.mark.parametrize("ds,mm,seed", GEOM_CASES)
+def test_overlap_stats_match_reference(golden_dir, ds, mm, seed):
+    from oracle import stats_oracle as S
+    gst = np.load(os.path.join(golden_dir, "stats.npz"))
+    d = synth.make_pairs(1, seed + 40, ds)
+    pc_src, pc_tgt = S.observed_clouds(d["depth"][0], ds)
+    assert [len(pc_src), len(pc_tgt)] == list(gst[f"stats_{ds}_n"])
+    assert np.array_equal(pc_src[:128], gst[f"stats_{ds}_pc_head"])
+    ov = S.point_cloud_overlap(pc_src, pc_tgt, gst[f"stats_{ds}_Rgt"])
+    assert np.allclose(ov, gst[f"stats_{ds}_overlap"], rtol=1e-12, atol=1e-12)
