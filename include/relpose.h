@@ -156,6 +156,13 @@ int relpose_depth2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, 
 int relpose_nn_dist(const double* query, const uint8_t* query_valid, int32_t nq, const double* ref, const uint8_t* ref_valid,
                     int32_t nr, const double* pose, double* dist, void* stream);
 
+/* ------------------------------------ feature-guided keypoint augmentation
+ * rputil.getKeypoint :182-190: dist [nsel,H,W] f32 = sum_c (query[s][c] - feat[c][y][x])^2
+ * (query [nsel,32] = descriptors of the selected keypoints, feat [32,H,W] the other view's feature map). */
+int relpose_feature_distance_map(const float* query, const float* feat, float* dist, int32_t nsel, int32_t H, int32_t W, void* stream);
+/* rputil.Sampling :355-371 on exp(-dist/2): K x {argmax, suppress a +-window box}; pts [nmaps,K,2] f64 (x,y). */
+int relpose_nms_sampling(const float* dist, double* pts, int32_t nmaps, int32_t H, int32_t W, int32_t K, int32_t window, void* stream);
+
 /* -------------------------------------------------------------------- SCNet
  * Replaces SCNet (model/mymodel.py:141-380; skipLayer=1, batchnorm=1, outputType 'rgbdnsf'). */
 typedef struct RelposeSCNet RelposeSCNet;

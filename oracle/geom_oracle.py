@@ -209,3 +209,26 @@ def get_pixel(depth, normal, pts, dataset):
         z = val[i]
         pc[i] = np.matmul(face_R(dataset, slot), np.array([xstp * z, ystp * z, -z]))
     return pc.T, nn
+
+
+def feature_distance_map(fs_sel, featt):
+    """rputil.py:186 (torch float32): fs_sel [32,n] descriptors, featt [32,H,W] -> dist [n,H,W]."""
+    import torch
+    a = torch.from_numpy(np.ascontiguousarray(fs_sel, dtype=np.float32))
+    b = torch.from_numpy(np.ascontiguousarray(featt, dtype=np.float32))
+    C, H, W = b.shape
+    return (a.unsqueeze(2) - b.view(C, 1, -1)).pow(2).sum(0).view(a.shape[1], H, W).numpy()
+
+
+def sampling(dist, K, window=15):
+    """rputil.Sampling :355-371: heat = exp(-dist/2); K x {argmax, suppress [y-15,y+15) x [x-15,x+15) with the min}."""
+    heat = np.exp(-dist / 2)
+    n, h, w = heat.shape
+    pt = np.zeros([n, K, 2])
+    for i in range(n):
+        for j in range(K):
+            idx = np.argmax(heat[i])
+            y, x = np.unravel_index(idx, heat[i].shape)
+            pt[i, j] = (x, y)
+            heat[i][max(0, y - window):min(h - 1, y + window), max(0, x - window):min(w - 1, x + window)] = heat[i].min()
+    return pt

@@ -49,6 +49,8 @@ SIGNATURES = {
     "relpose_observed_points": (c_int, [c_int, c_int]),
     "relpose_depth2pc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "relpose_nn_dist": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "relpose_feature_distance_map": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "relpose_nms_sampling": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "relpose_scnet_create": (c_void_p, [c_int, c_int]),
     "relpose_scnet_destroy": (None, [c_void_p]),
     "relpose_scnet_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),

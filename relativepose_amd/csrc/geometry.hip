@@ -10,6 +10,7 @@
 // descriptor gather must round like numpy / torch (no FMA fusion).
 #include "common.h"
 #include "rp_math.h"
+#include <limits.h>
 
 namespace {
 
@@ -353,6 +354,71 @@ __global__ __launch_bounds__(256) void nn_dist_kernel(const double* __restrict__
     if (i < nq) out[i] = (!qv || qv[i]) ? sqrt(best) : -1.0;
 }
 
+// ---- feature-guided keypoint augmentation: rputil.getKeypoint :182-190, Sampling :355-371 -----
+// dist[s, p] = sum_c (q[s][c] - feat[c][p])^2, float32, for n_sel query descriptors over the H*W map.
+// HBM-bound: every thread owns one pixel, reads its 32 channels once (coalesced per channel plane) and
+// produces all n_sel distances (queries in LDS).
+__global__ __launch_bounds__(256) void feature_distance_kernel(const float* __restrict__ q, const float* __restrict__ feat,
+                                                                float* __restrict__ dist, int nsel, int hw) {
+    extern __shared__ float qs[];                 // [nsel][32]
+    for (int i = threadIdx.x; i < nsel * 32; i += 256) qs[i] = q[i];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    float f[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) f[c] = feat[(size_t)c * hw + p];
+    for (int s = 0; s < nsel; ++s) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { const float d = qs[s * 32 + c] - f[c]; acc = acc + d * d; }
+        dist[(size_t)s * hw + p] = acc;
+    }
+}
+
+// Sampling: per map, K times {argmax of exp(-dist/2) (first index on ties), suppress the window around it with the
+// map's minimum}.  One workgroup per map; the heat map is evaluated on the fly, suppression is a list of windows.
+__global__ __launch_bounds__(1024) void nms_sampling_kernel(const float* __restrict__ dist, double* __restrict__ pts, int H, int W, int K,
+                                                             int win) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ int wy0[8], wy1[8], wx0[8], wx1[8];
+    const int map = blockIdx.x, hw = H * W;
+    const float* dm = dist + (size_t)map * hw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < K; ++k) {
+        float best = -1.f;                         // heat values are in (0, 1]
+        int bidx = INT_MAX;
+        for (int p = threadIdx.x; p < hw; p += blockDim.x) {
+            const int y = p / W, x = p - y * W;
+            bool sup = false;
+            for (int j = 0; j < k; ++j) sup = sup || (y >= wy0[j] && y < wy1[j] && x >= wx0[j] && x < wx1[j]);
+            // suppressed pixels hold the map minimum, which can only win if the whole map is suppressed
+            const float v = sup ? -0.5f : expf(-dm[p] / 2);
+            if (v > best) { best = v; bidx = p; }  // p increases per thread: first index kept on ties
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(bidx, m, 64);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float b = bv[0]; int id = bi[0];
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (bv[w] > b || (bv[w] == b && bi[w] < id)) { b = bv[w]; id = bi[w]; }
+            const int y = id / W, x = id - y * W;
+            pts[((size_t)map * K + k) * 2 + 0] = x;
+            pts[((size_t)map * K + k) * 2 + 1] = y;
+            // heatmap[i][topl[1]:botr[1], topl[0]:botr[0]] = min   (rputil.py:368-370; end exclusive)
+            wy0[k] = max(0, y - win); wy1[k] = min(H - 1, y + win);
+            wx0[k] = max(0, x - win); wx1[k] = min(W - 1, x + win);
+        }
+        __syncthreads();
+    }
+}
+
 inline int grid_for(size_t total, int block = 256, int cap = 4096) {
     size_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
@@ -438,6 +504,23 @@ int relpose_nn_dist(const double* query, const uint8_t* query_valid, int32_t nq,
     if (!query || !ref || !dist || nq <= 0 || nr <= 0) return RELPOSE_EINVAL;
     hipLaunchKernelGGL(nn_dist_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, query, query_valid, nq, ref, ref_valid, nr,
                        pose, dist);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+
+int relpose_feature_distance_map(const float* query, const float* feat, float* dist, int32_t nsel, int32_t H, int32_t W, void* stream) {
+    if (!query || !feat || !dist || nsel <= 0 || nsel > 256 || H <= 0 || W <= 0) return RELPOSE_EINVAL;
+    const int hw = H * W;
+    hipLaunchKernelGGL(feature_distance_kernel, dim3((hw + 255) / 256), dim3(256), (size_t)nsel * 32 * sizeof(float), (hipStream_t)stream,
+                       query, feat, dist, nsel, hw);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int relpose_nms_sampling(const float* dist, double* pts, int32_t nmaps, int32_t H, int32_t W, int32_t K, int32_t window, void* stream) {
+    if (!dist || !pts || nmaps <= 0 || H <= 0 || W <= 0 || K < 1 || K > 8 || window < 0) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(nms_sampling_kernel, dim3(nmaps), dim3(1024), 0, (hipStream_t)stream, dist, pts, H, W, K, window);
     RP_CHECK_LAUNCH();
     return 0;
 }

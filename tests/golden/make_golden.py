@@ -270,6 +270,24 @@ def gen_e2e():
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
 
 
+def gen_keypoints():
+    """rputil.Sampling of the reference on distance maps built like getKeypoint :182-190."""
+    import torch
+    R = ref_loader.load()
+    ru = R["rputil"]
+    rs = np.random.RandomState(77)
+    out = {}
+    for tag, n in (("a", 12), ("b", 30)):
+        featt = torch.from_numpy(np.tanh(rs.randn(32, 160, 640)).astype(np.float32))
+        fs = torch.from_numpy(np.tanh(rs.randn(32, n)).astype(np.float32))
+        dist = (fs.unsqueeze(2) - featt.view(32, 1, -1)).pow(2).sum(0).view(n, 160, 640)
+        pts = ru.Sampling(dist.numpy().copy(), 2)
+        out[f"kp_{tag}_pts"] = pts
+        idx = sample_idx(dist.numel(), 4096, 5)
+        out[f"kp_{tag}_dist_idx"], out[f"kp_{tag}_dist_val"] = idx, dist.reshape(-1)[idx].numpy()
+    np.savez_compressed(os.path.join(HERE, "keypoints.npz"), **out)
+
+
 def gen_stats():
     """util.parse_data + util.point_cloud_overlap of the reference on synthetic pairs."""
     R = ref_loader.load()
@@ -291,7 +309,7 @@ def gen_stats():
 
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
-    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e", "stats"]
+    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e", "stats", "keypoints"]
     for g in groups:
         t = time.time()
         globals()["gen_" + g]()

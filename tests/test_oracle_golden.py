@@ -151,3 +151,19 @@ def test_overlap_stats_match_reference(golden_dir, ds, mm, seed):
     assert np.array_equal(pc_src[:128], gst[f"stats_{ds}_pc_head"])
     ov = S.point_cloud_overlap(pc_src, pc_tgt, gst[f"stats_{ds}_Rgt"])
     assert np.allclose(ov, gst[f"stats_{ds}_overlap"], rtol=1e-12, atol=1e-12)
+
+
+def _kp_inputs(n_list=(("a", 12), ("b", 30))):
+    rs = np.random.RandomState(77)
+    for tag, n in n_list:
+        featt = np.tanh(rs.randn(32, 160, 640)).astype(np.float32)
+        fs = np.tanh(rs.randn(32, n)).astype(np.float32)
+        yield tag, fs, featt
+
+
+def test_keypoint_sampling_matches_reference(golden_dir):
+    gk = np.load(os.path.join(golden_dir, "keypoints.npz"))
+    for tag, fs, featt in _kp_inputs():
+        dist = G.feature_distance_map(fs, featt)
+        assert np.array_equal(dist.reshape(-1)[gk[f"kp_{tag}_dist_idx"]], gk[f"kp_{tag}_dist_val"])
+        assert np.array_equal(G.sampling(dist.copy(), 2), gk[f"kp_{tag}_pts"])
