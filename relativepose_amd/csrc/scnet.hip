@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -75,10 +76,22 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI, bool SSLDS>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-    const ConvDesc d = descs[blockIdx.z];             // block-uniform: scalar loads
-    if ((int)blockIdx.x * BM >= d.M) return;          // groups share a grid; shorter members exit
+    // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
+    // ninner == 4 (the sub-pixel phases of one transposed conv, which gather from the SAME input tile):
+    // the 4 phases of a spatial tile run back to back on the SAME XCD (blocks are dealt round-robin to the
+    // 8 XCDs), so the tile is fetched from HBM once and re-used from that XCD's L2 by the other phases.
+    int zmem, mtile;
+    if (ninner == 1) { zmem = blockIdx.x / mt_max; mtile = blockIdx.x - zmem * mt_max; }
+    else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, t8 = (mt_max + 7) >> 3;
+        const int inner = slot % ninner, rest = slot / ninner;
+        zmem = (rest / t8) * ninner + inner;
+        mtile = (rest % t8) * 8 + xcd;
+    }
+    const ConvDesc d = descs[zmem];                   // block-uniform: scalar loads
+    if (mtile * BM >= d.M) return;                    // groups share a grid; shorter members exit
     constexpr int A_IT = BM / 64;                       // float4 slots per thread for the A tile
     constexpr int B_IT = (BN + 63) / 64;
     constexpr int SS_CAP = (WM == 2) ? 1024 : 512;      // float2 entries of the LDS scale/shift table (8 / 4 KB: keeps 3 blocks per CU)
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ks = blockIdx.y / d.ntiles_n;
-    const int m0 = blockIdx.x * BM, n0 = (blockIdx.y - ks * d.ntiles_n) * BN;
+    const int m0 = mtile * BM, n0 = (blockIdx.y - ks * d.ntiles_n) * BN;
     const int hw = d.Hp * d.Wp;
     const int g0 = (m0 / hw) >> 1;                      // first BatchNorm group touched by this tile
 
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
             r_grp[it] = SSLDS ? ((img >> 1) - g0) * d.Cin : (img >> 1);
             int msk = 0;
             for (int t = 0; t < d.ntaps; ++t) {
-                const int iy = y0 + descs[blockIdx.z].offy[t], ix = x0 + descs[blockIdx.z].offx[t];
+                const int iy = y0 + descs[zmem].offy[t], ix = x0 + descs[zmem].offx[t];
                 msk |= ((iy >= 0) & (iy < d.Hin) & (ix >= 0) & (ix < d.Win)) ? (1 << t) : 0;
             }
             r_mask[it] = msk;
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
         } else rowslot[tid] = -1;
         rowpix[tid] = pix;
     }
-    if (tid < 16) tapdelta[tid] = (int)descs[blockIdx.z].offy[tid] * d.Win + (int)descs[blockIdx.z].offx[tid];
+    if (tid < 16) tapdelta[tid] = (int)descs[zmem].offy[tid] * d.Win + (int)descs[zmem].offx[tid];
     if (SSLDS) {
         // scale/shift of every (group, input channel) this tile can touch; both sources concatenated
         const int ng = min(((min(m0 + BM, d.M) - 1) / hw >> 1) - g0 + 1, SS_CAP / d.Cin);
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
             double a = 0, b = 0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { a += red[((sl * WM + w) * BN + cl) * 2]; b += red[((sl * WM + w) * BN + cl) * 2 + 1]; }
-            double* o = d.stat_part + (((size_t)blockIdx.x * 2 + sl) * d.cout_pad + n0 + cl) * 2;
+            double* o = d.stat_part + (((size_t)mtile * 2 + sl) * d.cout_pad + n0 + cl) * 2;
             o[0] = a; o[1] = b;
         }
     }
@@ -459,10 +472,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nchun
 
 // Finalise BatchNorm from the per-tile records written by the conv epilogue.  One thread per (group, channel);
 // the records of every launch member that wrote this channel are added in (member, tile) order.
-__global__ void bn_finalize_fused_kernel(const ConvDesc* __restrict__ descs, int ndesc, int BMt, int C, int rows_per_group,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta, float2* __restrict__ ss) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
-    if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_finalize_fused_kernel(const ConvDesc* __restrict__ descs, int ndesc, int BMt, int C,
+                                                                int rows_per_group, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float2* __restrict__ ss) {
+    const int c = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;      // one wave per (channel, group)
     double s = 0, q = 0;
     for (int z = 0; z < ndesc; ++z) {
         const ConvDesc& d = descs[z];
@@ -470,13 +483,15 @@ __global__ void bn_finalize_fused_kernel(const ConvDesc* __restrict__ descs, int
         if (cl < 0 || cl >= d.Cout) continue;
         const int hw = d.Hp * d.Wp;
         const int t0 = (2 * g * hw) / BMt, t1 = min(((2 * g + 2) * hw - 1) / BMt, (d.M - 1) / BMt);
-        for (int t = t0; t <= t1; ++t) {
+        for (int t = t0 + lane; t <= t1; t += 64) {
             const int sl = g - (((t * BMt) / hw) >> 1);
             if (sl < 0 || sl > 1) continue;
             const double* p = d.stat_part + (((size_t)t * 2 + sl) * d.cout_pad + cl) * 2;
             s += p[0]; q += p[1];
         }
     }
+    s = rp_wave_sum(s); q = rp_wave_sum(q);          // fixed butterfly order: deterministic
+    if (lane) return;
     const double mean = s / rows_per_group;
     double var = q / rows_per_group - mean * mean;
     if (var < 0) var = 0;
@@ -778,7 +793,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
 enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4 };
-struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0; };
+struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
     int n = 0; void* ws = nullptr;
@@ -912,7 +927,19 @@ void Builder::end_group() {
         }
     }
     Op o; o.type = OP_CONV; o.first = first; o.count = count; o.cfg = cfg;
-    o.grid = dim3(max_mt, (cp / BNt) * ksplit, count);
+    // runs of 4 consecutive members that are the phases of one stride-2 transposed conv share their input tile
+    o.ninner = 1; o.mt_max = max_mt;
+    if (count % 4 == 0) {
+        bool ph = true;
+        for (int i = first; i < first + count; i += 4)
+            for (int k = 1; k < 4; ++k)
+                ph = ph && plan->descs[i + k].src[0].x == plan->descs[i].src[0].x && plan->descs[i + k].osy == 2 && plan->descs[i].osy == 2;
+        // measured neutral on deconv2/deconv3 (their re-reads are already served on-chip) and slightly negative on
+        // the small layers (grid padded to 8 tiles), so phase interleaving stays off: profiles/r01_*.txt
+        if (ph && getenv("RELPOSE_PHASE_INTERLEAVE")) o.ninner = 4;
+    }
+    o.grid = (o.ninner == 1) ? dim3(max_mt * count, (cp / BNt) * ksplit, 1)
+                             : dim3(((max_mt + 7) / 8) * 8 * count, (cp / BNt) * ksplit, 1);
     // LDS scale/shift table: every member must fit (groups spanned by a tile) x Cin entries in 1024
     o.sslds = 1;
     for (int i = first; i < first + count; ++i) {
@@ -1148,13 +1175,13 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             mark(1);
             const ConvDesc* dd = net->d_descs + op.first;
             if (op.sslds) {
-                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true>), op.grid, dim3(256), 0, s, dd);
-                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true>), op.grid, dim3(256), 0, s, dd);
-                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, true>), op.grid, dim3(256), 0, s, dd);
+                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
             } else {
-                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, false>), op.grid, dim3(256), 0, s, dd);
-                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, false>), op.grid, dim3(256), 0, s, dd);
-                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, false>), op.grid, dim3(256), 0, s, dd);
+                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
             }
             mark(-1);
         } else if (op.type == OP_CONV1) {
@@ -1165,7 +1192,7 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         } else if (op.type == OP_STATS_FUSED) {
             const Buf& B = net->bufs[op.buf];
             mark(2);
-            hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((B.C + 127) / 128, G), dim3(128), 0, s, net->d_descs + op.first, op.count, op.cfg,
+            hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(B.C, G), dim3(64), 0, s, net->d_descs + op.first, op.count, op.cfg,
                                B.C, 2 * B.H * B.H, net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
             mark(-2);
         } else if (op.type == OP_REDUCE) {
