@@ -93,3 +93,35 @@ def test_pipeline_batch_equals_single_and_is_deterministic():
         st1 = pipe.prepare(d["rgb"][b:b + 1], d["norm"][b:b + 1], d["depth"][b:b + 1], pts[b:b + 1], ptw[b:b + 1], dev)
         p1, _, _ = pipe.run(st1)
         assert torch.equal(p1[0], pose[b]), b
+
+
+@pytest.mark.parametrize("ds,mm", [("suncg", "second"), ("scannet", "kinect")])
+def test_pipeline_320x1280_vs_parameterised_oracle(ds, mm):
+    """BASELINE config 5 geometry (h=320): the reference asserts 160x640, so the oracle here is the build's own
+    parameterised restatement (validated against the reference at h=160 only -- parity unpinned at this size)."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    h, S, tanh, N = 320, 15, 1, 48
+    d = synth.make_pairs(1, 5100, ds, h=h)
+    pts, ptw = synth.make_keypoints(1, N, 5100, mm, h=h)
+    sd = weights.make_state_dict(11, S)
+    rs = np.random.RandomState(1)
+    forced = [np.eye(4), synth.random_rigid(rs, 0.8, 0.5)]
+    det = []
+    _, otrace = P.run_pair(SCNetOracle(sd, S, tanh), d["rgb"][0], d["norm"][0], d["depth"][0], pts[0], ptw[0], np.tile([[0.26, 0.26, 0.04, 0.01]], (2, 1)),
+                           ds, mm, S, alter_steps=2, detail=det, R_forced=forced)
+    dev = torch.device("cuda:0")
+    from relativepose_amd.model import SCNet
+    net = SCNet(SimpleNamespace(batchnorm=1, useTanh=tanh, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+    net.load_state_dict(sd)
+    pipe = RelativePosePipeline(net, ds, mm, np.tile([[0.26, 0.26, 0.04, 0.01]], (2, 1)), alter_steps=2)
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    keep = []
+    pipe.run(st, R_forced=[torch.from_numpy(f[None]).to(dev) for f in forced], keep=keep)
+    for step in range(2):
+        nbad = int((keep[step]["x"].cpu().numpy() != det[step]["x"]).any(1).sum())
+        f_err = np.abs(keep[step]["f"].cpu().numpy() - det[step]["f"]).max()
+        pc_err = max(np.abs(keep[step]["pc"][0, v].cpu().numpy() - det[step]["prim"][v]["pc"]).max() for v in range(2))
+        ft_err = max(np.abs(keep[step]["ft"][0, v].cpu().numpy() - det[step]["prim"][v]["feat"]).max() for v in range(2))
+        log("pipeline_320", ds=ds, step=step, net_input_pixels_differ=nbad, net_out_abs_err=f_err, pc_err=pc_err, feat_err=ft_err)
+        assert nbad <= 8 and f_err < 1e-3 and pc_err < 1e-3 and ft_err < 1e-3
