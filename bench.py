@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="scan pairs per GPU")
     ap.add_argument("--keypoints", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="split the per-GPU batch over this many HIP streams (matcher/SCNet overlap)")
     args = ap.parse_args()
 
     import torch
@@ -88,10 +89,18 @@ def main():
     net.load_state_dict(weights.make_state_dict(7, S))
     Cc = N * 5
     pipe = RelativePosePipeline(net, "suncg", "second", SUNCG_SIGMAS, max_edges=min(Cc * (Cc - 1), 1 << 20))
-    st = pipe.prepare(data["rgb"], data["norm"], data["depth"], pts, ptw, dev)
+    nloc = hi - lo
+    ns_ = max(1, min(args.streams, nloc))
+    cuts = [nloc * i // ns_ for i in range(ns_ + 1)]
+    states = [pipe.prepare(data["rgb"][a:b], data["norm"][a:b], data["depth"][a:b], pts[a:b], ptw[a:b], dev)
+              for a, b in zip(cuts[:-1], cuts[1:])]
 
     def step():
-        pose, status, _ = pipe.run(st)
+        if len(states) == 1:
+            pose, status, _ = pipe.run(states[0])
+        else:
+            res = pipe.run_interleaved(states)
+            pose, status = torch.cat([r[0] for r in res]), torch.cat([r[1] for r in res])
         return D.gather_poses(pose, status, total, world)
 
     for _ in range(args.warmup):
@@ -112,7 +121,8 @@ def main():
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic (seeded box-room RGB-D panoramas, injected keypoints, random-init weights)",
                "config": {"workload": "SUNCG 160x640, N=200 keypoints, batch=32 pairs per GPU, alterStep=3 (BASELINE configs[1])",
-                          "pairs_per_gpu": B, "keypoints": N, "recurrent_levels": 3, "parallelism": f"pairs sharded x{world}"},
+                          "pairs_per_gpu": B, "keypoints": N, "recurrent_levels": 3, "parallelism": f"pairs sharded x{world}",
+                          "streams_per_gpu": len(states)},
                "status_ok_fraction": float((status == 0).double().mean().item())}
         # --- roofline of the dominant kernel: implicit-GEMM conv, HIP events on the launch stream
         x = torch.randn(2 * B, 16, 160, 640, device=dev)

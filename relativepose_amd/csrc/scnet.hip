@@ -610,8 +610,7 @@ struct RelposeSCNet {
     float* d_gb = nullptr;       // gamma/beta per activation buffer [2][C]
     float2* d_ident = nullptr;   // 16 x {1,0}: scale/shift of the raw network input
     size_t w1_off = 0;           // conv1 direct-kernel weights inside d_w
-    ConvDesc* d_descs = nullptr; // device copy of the launch plan's descriptor table
-    void* plan = nullptr;        // Plan* (anonymous namespace type)
+    std::map<std::pair<void*, int>, void*> plans;   // (workspace, n) -> Plan* (each with its own device descriptor table)
     std::map<std::string, Layer> layers;
     std::map<std::string, Buf> bufs;
     size_t per_image_floats = 0, ss_float2_per_group = 0;
@@ -801,6 +800,7 @@ struct Plan {
     std::vector<Op> ops;
     size_t splitk_floats = 0;
     size_t stat_doubles = 0;     // per-tile BatchNorm records of all fused-statistics groups
+    ConvDesc* d_descs = nullptr; // device copy of `descs`
 };
 
 struct Builder {
@@ -1009,7 +1009,12 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
 }
 
 void free_plan(RelposeSCNet* net) {
-    if (net->plan) { delete (Plan*)net->plan; net->plan = nullptr; }
+    for (auto& kv : net->plans) {
+        Plan* p = (Plan*)kv.second;
+        if (p->d_descs) (void)hipFree(p->d_descs);
+        delete p;
+    }
+    net->plans.clear();
 }
 
 struct WsOffsets { size_t act, ss, partial, splitk, statp, total; };
@@ -1045,7 +1050,6 @@ void relpose_scnet_destroy(RelposeSCNet* net) {
     if (net->d_w) hipFree(net->d_w);
     if (net->d_gb) hipFree(net->d_gb);
     if (net->d_ident) hipFree(net->d_ident);
-    if (net->d_descs) hipFree(net->d_descs);
     free_plan(net);
     delete net;
 }
@@ -1136,12 +1140,16 @@ size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n, int32_t
 int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                           size_t workspace_bytes, void* stream) {
     if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0) return RELPOSE_EINVAL;
-    Plan* plan = (Plan*)net->plan;
     const int G = n / 2;
-    if (!plan || plan->n != n || plan->ws != workspace) {
+    Plan* plan = nullptr;
+    {
+        auto it = net->plans.find(std::make_pair(workspace, (int)n));
+        if (it != net->plans.end()) plan = (Plan*)it->second;
+    }
+    if (!plan) {
         const WsOffsets o = ws_offsets(net, n);
         if (workspace_bytes < o.total) return RELPOSE_ENOMEM;
-        free_plan(net);
+        if (net->plans.size() >= 16) free_plan(net);      // callers keep a few long-lived workspaces; bound the cache
         plan = new Plan();
         plan->n = n; plan->ws = workspace;
         char* ws = (char*)workspace;
@@ -1149,11 +1157,9 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk); B.statp = (double*)(ws + o.statp);
         build_plan(net, n, B);
         if (B.rc) { delete plan; return B.rc; }
-        if (!net->d_descs) RP_HIP(hipMalloc((void**)&net->d_descs, MAX_DESCS * sizeof(ConvDesc)));
-        // one-off synchronous upload; the stream may still be executing an older plan
-        RP_HIP(hipStreamSynchronize((hipStream_t)stream));
-        RP_HIP(hipMemcpy(net->d_descs, plan->descs.data(), plan->descs.size() * sizeof(ConvDesc), hipMemcpyHostToDevice));
-        net->plan = plan;
+        RP_HIP(hipMalloc((void**)&plan->d_descs, MAX_DESCS * sizeof(ConvDesc)));
+        RP_HIP(hipMemcpy(plan->d_descs, plan->descs.data(), plan->descs.size() * sizeof(ConvDesc), hipMemcpyHostToDevice));
+        net->plans[std::make_pair(workspace, (int)n)] = plan;
     }
     net->last_n = n;
     hipStream_t s = (hipStream_t)stream;
@@ -1173,7 +1179,7 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
     for (const Op& op : plan->ops) {
         if (op.type == OP_CONV) {
             mark(1);
-            const ConvDesc* dd = net->d_descs + op.first;
+            const ConvDesc* dd = plan->d_descs + op.first;
             if (op.sslds) {
                 if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
                 else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
@@ -1192,12 +1198,12 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         } else if (op.type == OP_STATS_FUSED) {
             const Buf& B = net->bufs[op.buf];
             mark(2);
-            hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(B.C, G), dim3(64), 0, s, net->d_descs + op.first, op.count, op.cfg,
+            hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(B.C, G), dim3(64), 0, s, plan->d_descs + op.first, op.count, op.cfg,
                                B.C, 2 * B.H * B.H, net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
             mark(-2);
         } else if (op.type == OP_REDUCE) {
             mark(4);
-            hipLaunchKernelGGL(splitk_reduce_kernel, op.grid, dim3(256), 0, s, net->d_descs + op.first);
+            hipLaunchKernelGGL(splitk_reduce_kernel, op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             mark(-4);
         } else {
             const Buf& B = net->bufs[op.buf];

@@ -34,6 +34,7 @@ class SCNet:
         self._h = _lib.lib().relpose_scnet_create(self.snumclass, self.useTanh)
         if not self._h:
             raise RuntimeError("relpose_scnet_create failed")
+        self._wss = {}          # one workspace (and launch plan) per (stream, n): streams must not share scratch
         self._ws = None
         self._loaded = False
 
@@ -77,10 +78,15 @@ class SCNet:
         nbytes = _lib.lib().relpose_scnet_workspace_bytes(self._h, n, H, W)
         if nbytes == 0:
             raise RuntimeError("relpose_scnet_workspace_bytes: invalid shape (n must be even) or weights not loaded")
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
-            self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        return self._ws
+        key = (torch.cuda.current_stream().cuda_stream, n, dev.index)
+        ws = self._wss.get(key)
+        if ws is None or ws.numel() < nbytes:
+            if len(self._wss) >= 8:
+                self._wss.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._wss[key] = ws
+        self._ws = ws
+        return ws
 
     def forward(self, x, out=None):
         import torch

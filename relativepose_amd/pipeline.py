@@ -62,6 +62,55 @@ class RelativePosePipeline:
         st["eye"] = torch.eye(4, dtype=torch.float64, device=device).repeat(B, 1, 1).contiguous()
         return st
 
+    def run_interleaved(self, states):
+        """Several prepared batches advanced in lock step, each on its own HIP stream: the launch-bound matcher
+        phase of one batch (hundreds of few-microsecond kernels) overlaps the MFMA-bound SCNet phase of the
+        others.  Per-pair results are identical to `run` (same kernels, same data).  Returns [(pose, status)]."""
+        import torch
+        cur = torch.cuda.current_stream()
+        for st in states:
+            if "stream" not in st:
+                st["stream"] = torch.cuda.Stream()
+            st["stream"].wait_stream(cur)
+        gens = [self._run_gen(st) for st in states]
+        out = [None] * len(states)
+        live = list(range(len(states)))
+        while live:
+            for i in list(live):
+                with torch.cuda.stream(states[i]["stream"]):
+                    try:
+                        next(gens[i])
+                    except StopIteration as e:
+                        out[i] = e.value
+                        live.remove(i)
+        for st in states:
+            cur.wait_stream(st["stream"])
+        return [(o[0], o[1]) for o in out]
+
+    def _run_gen(self, st):
+        """`run` as a generator that yields after the SCNet phase and after the matcher phase of every level."""
+        import torch
+        B, h, N = st["B"], st["h"], st["N"]
+        view = util.build_view_dev(st["rgb"], st["norm"], st["depth"], self.mask_method)
+        R_hat, status = st["eye"], None
+        for step in range(self.alter_steps):
+            inv = util.pose_inverse_dev(R_hat)
+            poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
+            other = view.view(B, 2, 8, h, 4 * h).flip(1).reshape(2 * B, 8, h, 4 * h).contiguous()
+            warped = util.warping_dev(other, poses, self.dataset)
+            f = self.net(torch.cat((view, warped), 1))
+            yield
+            pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
+                                                    self.mask_method, self.dataset)
+            pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
+            para = rpmodule.opts(*self.sigmas[min(step, len(self.sigmas) - 1)])
+            res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), st["w_s"],
+                                       pc[:, 1].contiguous(), nn[:, 1].contiguous(), ft[:, 1].contiguous(), st["w_t"],
+                                       st["ns"], st["nt"], para, max_edges=self.max_edges)
+            R_hat, status = res.pose, res.status
+            yield
+        return R_hat, status, None
+
     def run(self, st, R_forced=None, keep=None):
         """One pass of the hot path over the prepared batch.  Returns (pose [B,4,4] f64, status [B] i32,
         [pose after each step]).  R_forced: optional list of [B,4,4] tensors (teacher forcing, tests)."""

@@ -54,7 +54,7 @@ _ws_cache = {}
 
 def _workspace(nbytes, dev):
     import torch
-    key = (dev.index,)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)      # streams must not share scratch
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)

@@ -56,7 +56,7 @@ def warping_dev(view, pose, dataset, out=None):
     assert c == 8 and w == 4 * h and view.is_contiguous() and pose.is_contiguous() and pose.dtype == torch.float64
     L = _lib.lib()
     nbytes = L.relpose_warp_workspace_bytes(n, h)
-    key = view.device.index
+    key = (view.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _warp_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=view.device)

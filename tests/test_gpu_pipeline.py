@@ -125,3 +125,24 @@ def test_pipeline_320x1280_vs_parameterised_oracle(ds, mm):
         ft_err = max(np.abs(keep[step]["ft"][0, v].cpu().numpy() - det[step]["prim"][v]["feat"]).max() for v in range(2))
         log("pipeline_320", ds=ds, step=step, net_input_pixels_differ=nbad, net_out_abs_err=f_err, pc_err=pc_err, feat_err=ft_err)
         assert nbad <= 8 and f_err < 1e-3 and pc_err < 1e-3 and ft_err < 1e-3
+
+
+def test_pipeline_interleaved_streams_equal_single_stream():
+    """Two half-batches on two HIP streams (matcher of one overlapping SCNet of the other) give bitwise the same
+    poses as the plain single-stream run."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, mm, S, tanh = "suncg", "second", 15, 1
+    net = _gpu_net(S, tanh, E2E_WEIGHT_SEED)
+    d = synth.make_pairs(4, 1200, ds)
+    pts, ptw = synth.make_keypoints(4, 60, 1200, mm)
+    pipe = RelativePosePipeline(net, ds, mm)
+    full = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    pose, status, _ = pipe.run(full)
+    halves = [pipe.prepare(d["rgb"][a:b], d["norm"][a:b], d["depth"][a:b], pts[a:b], ptw[a:b], dev) for a, b in ((0, 2), (2, 4))]
+    for _ in range(2):
+        res = pipe.run_interleaved(halves)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat([r[0] for r in res]), pose)
+        assert torch.equal(torch.cat([r[1] for r in res]), status)
