@@ -76,7 +76,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI, bool SSLDS>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
     // ninner == 4 (the sub-pixel phases of one transposed conv, which gather from the SAME input tile):
@@ -92,9 +92,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
     }
     const ConvDesc d = descs[zmem];                   // block-uniform: scalar loads
     if (mtile * BM >= d.M) return;                    // groups share a grid; shorter members exit
-    constexpr int A_IT = BM / 64;                       // float4 slots per thread for the A tile
-    constexpr int B_IT = (BN + 63) / 64;
-    constexpr int SS_CAP = (WM == 2) ? 1024 : 512;      // float2 entries of the LDS scale/shift table (8 / 4 KB: keeps 3 blocks per CU)
+    constexpr int NT = WM * WN * 64;                    // threads per block (4 or 8 waves)
+    constexpr int RPI = NT / 4;                         // tile rows covered per loader iteration
+    constexpr int A_IT = BM / RPI;                      // float4 slots per thread for the A tile
+    constexpr int B_IT = (BN + RPI - 1) / RPI;
+    constexpr int SS_CAP = (WN == 2) ? 1024 : 512;      // float2 entries of the LDS scale/shift table (8 / 4 KB: keeps 3 blocks per CU)
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
     __shared__ __attribute__((aligned(16))) float2 sstab[SSLDS ? SS_CAP : 4];
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
     int r_base[A_IT], r_mask[A_IT], r_grp[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int m = m0 + lrow + it * 64;
+        const int m = m0 + lrow + it * RPI;
         r_base[it] = 0; r_mask[it] = 0; r_grp[it] = 0;
         if (m < d.M) {
             const int img = m / hw, rem = m - img * hw;
@@ -131,22 +133,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
             r_mask[it] = msk;
         }
     }
-    if (tid < BM) {
-        const int m = m0 + tid;
+    for (int row_ = tid; row_ < BM; row_ += NT) {
+        const int m = m0 + row_;
         int pix = -1;
         if (m < d.M) {
             const int img = m / hw, rem = m - img * hw;
             const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
             pix = (img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
-            rowslot[tid] = (signed char)min((img >> 1) - g0, 1);
-        } else rowslot[tid] = -1;
-        rowpix[tid] = pix;
+            rowslot[row_] = (signed char)min((img >> 1) - g0, 1);
+        } else rowslot[row_] = -1;
+        rowpix[row_] = pix;
     }
     if (tid < 16) tapdelta[tid] = (int)descs[zmem].offy[tid] * d.Win + (int)descs[zmem].offx[tid];
     if (SSLDS) {
         // scale/shift of every (group, input channel) this tile can touch; both sources concatenated
         const int ng = min(((min(m0 + BM, d.M) - 1) / hw >> 1) - g0 + 1, SS_CAP / d.Cin);
-        for (int idx = tid; idx < ng * d.Cin; idx += 256) {
+        for (int idx = tid; idx < ng * d.Cin; idx += NT) {
             const int g = g0 + idx / d.Cin, c = idx % d.Cin;
             const bool s1 = c >= d.src[0].C;
             sstab[idx] = s1 ? d.src[1].ss[(size_t)g * d.src[1].sstride + (c - d.src[0].C)] : d.src[0].ss[(size_t)g * d.src[0].sstride + c];
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
     const float* b_src[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int row = min(lrow + it * 64, BN - 1);
+        const int row = min(lrow + it * RPI, BN - 1);
         b_src[it] = d.w + (size_t)(n0 + row) * d.K + kq * 4;
     }
 
@@ -217,10 +219,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
             v.z = lrelu(v.z * s1v_.x + s1v_.y, slope); v.w = lrelu(v.w * s1v_.z + s1v_.w, slope);                 \
             const bool ok_ = (okm >> it) & 1;                                                                     \
             v.x = ok_ ? v.x : 0.f; v.y = ok_ ? v.y : 0.f; v.z = ok_ ? v.z : 0.f; v.w = ok_ ? v.w : 0.f;           \
-            *reinterpret_cast<float4*>(&As[BUF][(lrow + it * 64) * LDK + kq * 4]) = v;                            \
+            *reinterpret_cast<float4*>(&As[BUF][(lrow + it * RPI) * LDK + kq * 4]) = v;                            \
         }                                                                                                         \
-        if (BN >= 64 || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb0;               \
-        if (B_IT > 1) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + 64) * LDK + kq * 4]) = rb1;                     \
+        if (BN >= RPI || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb0;              \
+        if (B_IT > 1) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + RPI) * LDK + kq * 4]) = rb1;                     \
     }
 
     RP_ISSUE_LOADS(kt_begin)
@@ -230,16 +232,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
     const int brow = (wn * NI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     for (int kt = kt_begin; kt < nkt; ++kt) {
         const int buf = (kt - kt_begin) & 1;
-#if RP_ABLATE != 2
+#if RP_ABLATE != 2 && RP_ABLATE != 5
         if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
 #endif
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             float4 a[MI], b[NI];
+#if RP_ABLATE == 3 || RP_ABLATE == 5
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = make_float4(1.f + kt, 2.f, 3.f, 4.f + lane);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = make_float4(0.5f, 0.25f + kt, 0.125f, 1.f);
+#else
 #pragma unroll
             for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][arow + i * 32 * LDK + kc * 8]);
 #pragma unroll
             for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[buf][brow + j * 32 * LDK + kc * 8]);
+#endif
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -254,8 +263,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
 #endif
                 }
         }
+#if RP_ABLATE != 5
         if (kt + 1 < nkt) RP_STORE_TILE(buf ^ 1)
+#endif
+#if RP_ABLATE != 4 && RP_ABLATE != 5
         __syncthreads();
+#endif
     }
 #undef RP_ISSUE_LOADS
 #undef RP_STORE_TILE
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc* __re
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < 2 * BN; idx += 256) {
+        for (int idx = tid; idx < 2 * BN; idx += NT) {
             const int sl = idx / BN, cl = idx - sl * BN;
             double a = 0, b = 0;
 #pragma unroll
@@ -886,8 +899,12 @@ void Builder::end_group() {
     if (count <= 0) return;
     if ((int)plan->descs.size() > MAX_DESCS) { rc = RELPOSE_EINVAL; return; }
     const int cp = plan->descs[first].cout_pad;
-    const int cfg = cp >= 128 ? 0 : (cp == 64 ? 1 : 2);
-    const int BMt = cfg == 0 ? 128 : 256, BNt = cfg == 0 ? 128 : cp;
+    int big_m = 0;
+    for (int i = first; i < first + count; ++i) big_m = std::max(big_m, plan->descs[i].M / n * 64);   // at the nominal batch
+    // tile configs: 0 = 128x128 (4 waves), 3 = 256x128 (8 waves, 4 waves/SIMD at 2 blocks/CU), 1 = 256x64, 2 = 256x32
+    // (3 measured within 1 % of 0 on conv3/conv4/deconv4-6 but needs twice the split-K: off unless RELPOSE_8WAVE is set)
+    const int cfg = cp >= 128 ? ((big_m >= 8192 && getenv("RELPOSE_8WAVE")) ? 3 : 0) : (cp == 64 ? 1 : 2);
+    const int BMt = cfg == 0 ? 128 : 256, BNt = (cfg == 0 || cfg == 3) ? 128 : cp;
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
     for (int i = first; i < first + count; ++i) {
@@ -946,7 +963,7 @@ void Builder::end_group() {
         const ConvDesc& d = plan->descs[i];
         const int hw = d.Hp * d.Wp;
         const int ng = (BMt - 1) / (2 * hw) + 2;
-        if ((long)ng * d.Cin > (cfg == 0 ? 1024 : 512) || d.src[0].sstride == 0) o.sslds = 0;
+        if ((long)ng * d.Cin > ((cfg == 0 || cfg == 3) ? 1024 : 512) || d.src[0].sstride == 0) o.sslds = 0;
     }
     plan->ops.push_back(o);
     if (ksplit > 1) {
@@ -1180,7 +1197,10 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         if (op.type == OP_CONV) {
             mark(1);
             const ConvDesc* dd = plan->d_descs + op.first;
-            if (op.sslds) {
+            if (op.cfg == 3) {
+                if (op.sslds) hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, true>), op.grid, dim3(512), 0, s, dd, op.ninner, op.mt_max);
+                else hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, false>), op.grid, dim3(512), 0, s, dd, op.ninner, op.mt_max);
+            } else if (op.sslds) {
                 if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
                 else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
                 else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
