@@ -434,6 +434,93 @@ __global__ __launch_bounds__(256) void conv1_direct_kernel(const float* __restri
     }
 }
 
+// ---- the five 1x1 heads deconv1{rgb,n,d,s,f} (mymodel.py:188,196,204,220,228 / :312-376) in one pass ---------
+// HBM-bound: every pixel reads its 224 D2 channels (+ the 3x32 skip channels of A1) exactly once, applies
+// BatchNorm + LeakyReLU, and feeds the five small matrix-vector products (3+3+1+S+32 outputs, 64 inputs each).
+// One lane per pixel; weights are wave-uniform LDS broadcasts (ds_read_b128 of 4 output weights).
+// Weight image (pack_heads): per input channel a row of padded output weights --
+//   [0,768)      rgb/n/d rows (D2[0:96] then the A1 skip blocks), 4 floats per row
+//   [768,2304)   s rows  (D2[96:160]),  24 floats per row
+//   [2304,4352)  f rows  (D2[160:224]), 32 floats per row
+struct HeadsDesc {
+    const float* d2; const float* a1; const float2* ss_d2; const float2* ss_a1;
+    const float* w; const float* bias; float* out;
+    int n, S, cf, use_tanh;
+};
+constexpr int HEADS_W = 4352;
+
+template <int S>
+__global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
+    __shared__ __attribute__((aligned(16))) float wl[HEADS_W];
+    __shared__ float2 ssl[320];                        // scale/shift of this block's BatchNorm group
+    constexpr int cf = 7 + S + 32;
+    const size_t pix0 = (size_t)blockIdx.x * 256;      // 256 consecutive pixels: one image, one BatchNorm group
+    const int g = (int)(pix0 / ((size_t)RS * RS)) >> 1;
+    for (int i = threadIdx.x; i < HEADS_W; i += 256) wl[i] = hd.w[i];
+    for (int i = threadIdx.x; i < 320; i += 256) {
+        // A1 skip blocks: channels [0:32] (rgb self), [64:96] (n self), [128:160] (d self) of the 192-channel buffer
+        ssl[i] = i < 224 ? hd.ss_d2[(size_t)g * 224 + i] : hd.ss_a1[(size_t)g * 192 + ((i - 224) >> 5) * 64 + ((i - 224) & 31)];
+    }
+    __syncthreads();
+    const size_t pix = pix0 + threadIdx.x;
+    const float* pd = hd.d2 + pix * 224;
+    const float* pa = hd.a1 + pix * 192;
+    float a3[12], as_[24], af[32];                     // rgb 0:3 | n 4:7 | d 8:11 (padded quads), s, f
+#pragma unroll
+    for (int o = 0; o < 12; ++o) a3[o] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 24; ++o) as_[o] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) af[o] = 0.f;
+    // One 128-byte line (32 channels) of a pixel at a time: all 8 loads are issued back to back so the line is
+    // fetched once (a wave touches 64 lines per load instruction; interleaving compute between the loads of a
+    // line let other waves evict it from the 32 KB L1 first).  Then BN + LeakyReLU and
+    // acc[4j+t'] += v * w[row][4j+t'] over the row's NQ4 weight quads.
+#define RP_HEAD_LINE(PTR, SSROW, WOFF, WSTRIDE, NQ4, ACC, OBASE)                                          \
+    {                                                                                                    \
+        float4 x8[8];                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) x8[q] = reinterpret_cast<const float4*>(PTR)[q];   \
+        _Pragma("unroll 1") for (int q = 0; q < 8; ++q) {                                                \
+            const float4 x4 = x8[0];                                                                     \
+            _Pragma("unroll") for (int z = 0; z < 7; ++z) x8[z] = x8[z + 1];                             \
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w};                                                \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                              \
+                const float2 sc = ssl[(SSROW) + q * 4 + t];                                              \
+                const float v = lrelu(xv[t] * sc.x + sc.y, LRELU);                                       \
+                _Pragma("unroll") for (int j = 0; j < (NQ4); ++j) {                                      \
+                    const float4 w4 = *reinterpret_cast<const float4*>(&wl[(WOFF) + (q * 4 + t) * (WSTRIDE) + j * 4]); \
+                    ACC[(OBASE) + j * 4 + 0] = fmaf(v, w4.x, ACC[(OBASE) + j * 4 + 0]);                  \
+                    ACC[(OBASE) + j * 4 + 1] = fmaf(v, w4.y, ACC[(OBASE) + j * 4 + 1]);                  \
+                    ACC[(OBASE) + j * 4 + 2] = fmaf(v, w4.z, ACC[(OBASE) + j * 4 + 2]);                  \
+                    ACC[(OBASE) + j * 4 + 3] = fmaf(v, w4.w, ACC[(OBASE) + j * 4 + 3]);                  \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {                      // rgb, n, d: 32 channels of D2 + 32 skip channels of A1
+        RP_HEAD_LINE(pd + m * 32, m * 32, (m * 32) * 4, 4, 1, a3, m * 4)
+        RP_HEAD_LINE(pa + m * 64, 224 + m * 32, (96 + m * 32) * 4, 4, 1, a3, m * 4)
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) RP_HEAD_LINE(pd + 96 + l * 32, 96 + l * 32, 768 + l * 32 * 24, 24, 6, as_, 0)           // s
+#pragma unroll
+    for (int l = 0; l < 2; ++l) RP_HEAD_LINE(pd + 160 + l * 32, 160 + l * 32, 2304 + l * 32 * 32, 32, 8, af, 0)         // f
+#undef RP_HEAD_LINE
+    // bias, tanh, store (cf is even: 8-byte stores; a lane's cf floats are contiguous in the NHWC output)
+    float r[cf + 1];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { r[o] = a3[o] + hd.bias[o]; r[3 + o] = a3[4 + o] + hd.bias[3 + o]; }
+    r[6] = a3[8] + hd.bias[6];
+#pragma unroll
+    for (int o = 0; o < S; ++o) r[7 + o] = as_[o] + hd.bias[7 + o];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const float v = af[k] + hd.bias[7 + S + k]; r[7 + S + k] = hd.use_tanh ? tanhf(v) : v; }
+    float* o = hd.out + pix * cf;
+#pragma unroll
+    for (int k = 0; k < cf / 2; ++k) *reinterpret_cast<float2*>(o + 2 * k) = make_float2(r[2 * k], r[2 * k + 1]);
+}
+
 // ---- BatchNorm batch statistics (per group of 2 images, per channel), float64 ---------------------
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int rows_per_group, int C, int chunk_rows,
                                                           double* __restrict__ partial) {
@@ -623,6 +710,7 @@ struct RelposeSCNet {
     float* d_gb = nullptr;       // gamma/beta per activation buffer [2][C]
     float2* d_ident = nullptr;   // 16 x {1,0}: scale/shift of the raw network input
     size_t w1_off = 0;           // conv1 direct-kernel weights inside d_w
+    size_t wh_off = 0, bh_off = 0;   // fused-heads weight image and bias vector inside d_w
     std::map<std::pair<void*, int>, void*> plans;   // (workspace, n) -> Plan* (each with its own device descriptor table)
     std::map<std::string, Layer> layers;
     std::map<std::string, Buf> bufs;
@@ -804,7 +892,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4 };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5 };
 struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
@@ -1015,13 +1103,15 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     R.begin_group();
     for (int m = 3; m < 5; ++m) R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), nullptr, 112, "D2", d2off[m]);
     R.end_group(); R.stats("D2");
-    const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
-    R.begin_group();
-    for (int m = 0; m < 5; ++m) {
-        if (m < 3) { sk = R.src("A1", 2 * m * 32, 32); R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 32), &sk, 224, "OUT", ooff[m]); }
-        else R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 64), nullptr, 224, "OUT", ooff[m]);
-    }
-    R.end_group();
+    if (getenv("RELPOSE_GEMM_HEADS") || (net->S != 15 && net->S != 21)) {   // generic implicit-GEMM path (5 members)
+        const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
+        R.begin_group();
+        for (int m = 0; m < 5; ++m) {
+            if (m < 3) { sk = R.src("A1", 2 * m * 32, 32); R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 32), &sk, 224, "OUT", ooff[m]); }
+            else R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 64), nullptr, 224, "OUT", ooff[m]);
+        }
+        R.end_group();
+    } else { Op o; o.type = OP_HEADS; o.first = o.count = o.cfg = 0; R.plan->ops.push_back(o); }
     (void)n;
 }
 
@@ -1106,6 +1196,33 @@ int relpose_scnet_finalize(RelposeSCNet* net) {
                     for (int c = 0; c < cin_m; ++c)
                         for (int o = 0; o < 32; ++o)
                             w1[(((size_t)(2 * m + s2) * 9 + t) * 4 + c) * 32 + o] = W[((size_t)o * cin_m + c) * 9 + t];
+        }
+    }
+    {   // fused heads: weight image (see heads_kernel) + bias in output-channel order
+        net->wh_off = blob.size();
+        blob.resize(blob.size() + HEADS_W, 0.f);
+        net->bh_off = blob.size();
+        blob.resize(blob.size() + 64, 0.f);
+        float* wh = blob.data() + net->wh_off;
+        float* bh = blob.data() + net->bh_off;
+        const char* hn[5] = {"rgb", "n", "d", "s", "f"};
+        const int hc[5] = {3, 3, 1, net->S, 32};
+        if (net->S > 24) return RELPOSE_EINVAL;
+        int ob = 0;
+        for (int m = 0; m < 5; ++m) {
+            const float* W = net->params[std::string("deconv1") + hn[m] + ".weight"].data();     // [Cout][64]
+            const float* Bv = net->params[std::string("deconv1") + hn[m] + ".bias"].data();
+            for (int o = 0; o < hc[m]; ++o) {
+                bh[ob + o] = Bv[o];
+                for (int ci = 0; ci < 64; ++ci) {
+                    size_t idx;
+                    if (m < 3) idx = (size_t)((ci < 32 ? m * 32 + ci : 96 + m * 32 + (ci - 32)) * 4 + o);
+                    else if (m == 3) idx = 768 + (size_t)ci * 24 + o;
+                    else idx = 2304 + (size_t)ci * 32 + o;
+                    wh[idx] = W[(size_t)o * 64 + ci];
+                }
+            }
+            ob += hc[m];
         }
     }
     // activation buffers
@@ -1221,6 +1338,16 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(B.C, G), dim3(64), 0, s, plan->d_descs + op.first, op.count, op.cfg,
                                B.C, 2 * B.H * B.H, net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
             mark(-2);
+        } else if (op.type == OP_HEADS) {
+            HeadsDesc hd;
+            hd.d2 = act + net->bufs["D2"].off * n; hd.a1 = act + net->bufs["A1"].off * n;
+            hd.ss_d2 = ssp + net->bufs["D2"].ss_off * G; hd.ss_a1 = ssp + net->bufs["A1"].ss_off * G;
+            hd.w = net->d_w + net->wh_off; hd.bias = net->d_w + net->bh_off; hd.out = act + net->bufs["OUT"].off * n;
+            hd.n = n; hd.S = net->S; hd.cf = net->cf; hd.use_tanh = net->use_tanh;
+            mark(1);
+            if (net->S == 15) hipLaunchKernelGGL(heads_kernel<15>, dim3((unsigned)((size_t)n * RS * RS / 256)), dim3(256), 0, s, hd);
+            else hipLaunchKernelGGL(heads_kernel<21>, dim3((unsigned)((size_t)n * RS * RS / 256)), dim3(256), 0, s, hd);
+            mark(-1);
         } else if (op.type == OP_REDUCE) {
             mark(4);
             hipLaunchKernelGGL(splitk_reduce_kernel, op.grid, dim3(256), 0, s, plan->d_descs + op.first);

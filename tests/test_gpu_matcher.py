@@ -142,3 +142,21 @@ def test_matcher_recovers_known_rotation(gm, dev):
         e = np.linalg.norm(pose[:3, :3] - G[:3, :3])
         log("matcher_known_rotation", N=N, rot_err=e)
         assert e < 2e-2 and np.abs(pose[:3, 3] - G[:3, 3]).max() < 2e-2
+
+
+def test_matcher_empty_and_maximum_sizes(gm, dev):
+    """Edge cases: no keypoints at all (identity, status 1) and the largest keypoint count the affinity kernel's
+    LDS tile admits (N=1000: 5000 correspondences, 12.5 M candidate pairs) as a size-independent property test."""
+    from relativepose_amd import rpmodule
+    para, _ = _params(gm, "suncg", 0)
+    empty = {'pc': np.zeros((0, 3)), 'normal': np.zeros((0, 3)), 'feat': np.zeros((0, 32), np.float32), 'weight': np.zeros(0)}
+    S, T, _ = synth.make_match_case(40, 1)
+    res = rpmodule.match_pairs(*rpmodule.pack_keypoints([(empty, empty), (S, T), (S, empty)], dev), para)
+    st = res.status.cpu().numpy()
+    assert st[0] == 1 and st[2] == 1 and st[1] == 0
+    assert np.array_equal(res.pose[0].cpu().numpy(), np.eye(4)) and np.array_equal(res.pose[2].cpu().numpy(), np.eye(4))
+    S, T, G = synth.make_match_case(1000, 77, inlier=0.8, noise=0.002)
+    pose = rpmodule.RelativePoseEstimation_helper(S, T, para)
+    e = np.linalg.norm(pose[:3, :3] - G[:3, :3])
+    log("matcher_max_size", N=1000, rot_err_vs_ground_truth=e)
+    assert e < 2e-2
