@@ -32,7 +32,8 @@ def build(force=False, verbose=True):
             continue
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _newer(s, o) or any(_newer(h, o) for h in headers):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o] + extra
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o] + extra + \
+                  os.environ.get("RELPOSE_HIPCC_FLAGS", "").split()       # experiments only (e.g. -DRP_ABLATE=3)
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -32,8 +33,13 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef RP_ABLATE
 #define RP_ABLATE 0
 #endif
-constexpr int BK = 16;          // K-tile (floats)
-constexpr int LDK = 20;         // LDS row stride in floats (80 B: 16-B aligned, conflict-free b128 reads)
+#ifndef RP_BK
+#define RP_BK 32
+#endif
+constexpr int BK = RP_BK;       // K-tile (floats): 16 (double-buffered LDS) or 32 (whole 128-B lines per row, single LDS buffer)
+constexpr int LDK = BK + 4;     // LDS row stride in floats (80 / 144 B: 16-B aligned, conflict-free b128 reads)
+constexpr int KQ = BK / 4;      // float4 slots per tile row
+constexpr int NBUF = (BK == 16) ? 2 : 1;
 constexpr float LRELU = 0.1f;
 constexpr double BN_EPS = 1e-5;
 constexpr int RS = 224;         // internal resolution (mymodel.py:261)
@@ -75,7 +81,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // scale/shift, B weights) are issued BEFORE the MFMAs of tile kt and consumed AFTER them, so their
 // latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
-template <int WM, int WN, int MI, int NI, bool SSLDS>
+template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
@@ -93,12 +99,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     const ConvDesc d = descs[zmem];                   // block-uniform: scalar loads
     if (mtile * BM >= d.M) return;                    // groups share a grid; shorter members exit
     constexpr int NT = WM * WN * 64;                    // threads per block (4 or 8 waves)
-    constexpr int RPI = NT / 4;                         // tile rows covered per loader iteration
+    constexpr int RPI = NT / KQ;                        // tile rows covered per loader iteration
     constexpr int A_IT = BM / RPI;                      // float4 slots per thread for the A tile
     constexpr int B_IT = (BN + RPI - 1) / RPI;
     constexpr int SS_CAP = (WN == 2) ? 1024 : 512;      // float2 entries of the LDS scale/shift table (8 / 4 KB: keeps 3 blocks per CU)
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDK];
     __shared__ __attribute__((aligned(16))) float2 sstab[SSLDS ? SS_CAP : 4];
     __shared__ int rowpix[BM];
     __shared__ signed char rowslot[BM];        // BatchNorm group of the row relative to the tile's first group
@@ -111,38 +117,30 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     const int hw = d.Hp * d.Wp;
     const int g0 = (m0 / hw) >> 1;                      // first BatchNorm group touched by this tile
 
-    // Per loader row: pixel index of the (tap 0,0) origin, a 16-bit mask of the taps that fall inside
-    // the image (everything else is zero padding), and the BatchNorm group.  Computed once per block.
-    const int kq = tid & 3, lrow = tid >> 2;
-    int r_base[A_IT], r_mask[A_IT], r_grp[A_IT];
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int m = m0 + lrow + it * RPI;
-        r_base[it] = 0; r_mask[it] = 0; r_grp[it] = 0;
+    // Per tile row (computed once, by one thread per row): pixel index of the (tap 0,0) origin, a 16-bit mask
+    // of the taps that fall inside the image (everything else is zero padding) packed with the BatchNorm
+    // group, the output pixel and the group slot.  The loader table lives in the (not yet used) A buffer.
+    const int kq = tid % KQ, lrow = tid / KQ;
+    int* rtab = reinterpret_cast<int*>(&As[0][0]);      // [BM][2] {base, mask | grp << 16}
+    for (int row_ = tid; row_ < BM; row_ += NT) {
+        const int m = m0 + row_;
+        int pix = -1, base = 0, mg = 0, slot = -1;
         if (m < d.M) {
             const int img = m / hw, rem = m - img * hw;
             const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
+            pix = (img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
+            slot = min((img >> 1) - g0, 1);
             const int y0 = yp * d.sy, x0 = xp * d.sx;
-            r_base[it] = (img * d.Hin + y0) * d.Win + x0;
-            r_grp[it] = SSLDS ? ((img >> 1) - g0) * d.Cin : (img >> 1);
+            base = (img * d.Hin + y0) * d.Win + x0;
             int msk = 0;
             for (int t = 0; t < d.ntaps; ++t) {
                 const int iy = y0 + descs[zmem].offy[t], ix = x0 + descs[zmem].offx[t];
                 msk |= ((iy >= 0) & (iy < d.Hin) & (ix >= 0) & (ix < d.Win)) ? (1 << t) : 0;
             }
-            r_mask[it] = msk;
+            mg = msk | ((SSLDS ? ((img >> 1) - g0) * d.Cin : (img >> 1)) << 16);
         }
-    }
-    for (int row_ = tid; row_ < BM; row_ += NT) {
-        const int m = m0 + row_;
-        int pix = -1;
-        if (m < d.M) {
-            const int img = m / hw, rem = m - img * hw;
-            const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
-            pix = (img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
-            rowslot[row_] = (signed char)min((img >> 1) - g0, 1);
-        } else rowslot[row_] = -1;
-        rowpix[row_] = pix;
+        rowpix[row_] = pix; rowslot[row_] = (signed char)slot;
+        rtab[2 * row_] = base; rtab[2 * row_ + 1] = mg;
     }
     if (tid < 16) tapdelta[tid] = (int)descs[zmem].offy[tid] * d.Win + (int)descs[zmem].offx[tid];
     if (SSLDS) {
@@ -171,14 +169,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
         b_src[it] = d.w + (size_t)(n0 + row) * d.K + kq * 4;
     }
 
+    int r_base[A_IT], r_mg[A_IT];
     float4 ra[A_IT], q0[SSLDS ? 1 : A_IT], q1[SSLDS ? 1 : A_IT];
-    float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0;
+    float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
+    static_assert(B_IT <= 4 && (B_IT <= 2 || BN % RPI == 0), "B loader layout");
     int okm = 0, cst = 0;
     const float slope = d.src[0].slope;                 // both sources of a skip concatenation use LeakyReLU(0.1)
     const int kt_begin = ks * d.kt_per;
     const int nkt = min(d.K / BK, kt_begin + d.kt_per);
     int tap = (kt_begin * BK) / d.Cin, c0 = kt_begin * BK - tap * d.Cin;
-    __syncthreads();       // tapdelta / rowpix / sstab visible
+    __syncthreads();       // tapdelta / rowpix / sstab / rtab visible
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int2 e = *reinterpret_cast<const int2*>(&rtab[2 * (lrow + it * RPI)]);
+        r_base[it] = e.x; r_mg[it] = e.y;
+    }
 
 #define RP_ISSUE_LOADS(KT)                                                                                        \
     {                                                                                                             \
@@ -189,30 +194,44 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
         const int td_ = tapdelta[tap];                                                                            \
         okm = 0; cst = c0 + kq * 4;                                                                               \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
-            const bool ok_ = (r_mask[it] >> tap) & 1;                                                             \
+            const bool ok_ = (r_mg[it] >> tap) & 1;                                                               \
             okm |= ok_ ? (1 << it) : 0;                                                                           \
             const int pix_ = ok_ ? r_base[it] + td_ : 0;                                                          \
             ra[it] = *reinterpret_cast<const float4*>(sx_ + (size_t)pix_ * scs_ + cc_);                           \
-            if (!SSLDS) {                                                                                         \
+            if (!SSLDS && !UNI) {                                                                                 \
                 const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                             \
                 const int sst_ = s1_ ? d.src[1].sstride : d.src[0].sstride;                                       \
-                const float4* q = reinterpret_cast<const float4*>(sss_ + (size_t)r_grp[it] * sst_ + cc_);         \
+                const float4* q = reinterpret_cast<const float4*>(sss_ + (size_t)(r_mg[it] >> 16) * sst_ + cc_);    \
                 q0[SSLDS ? 0 : it] = q[0]; q1[SSLDS ? 0 : it] = q[1];                                             \
             }                                                                                                     \
         }                                                                                                         \
+        if (!SSLDS && UNI) {                                                                                      \
+            const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                                 \
+            const int sst_ = s1_ ? d.src[1].sstride : d.src[0].sstride;                                           \
+            const float4* q = reinterpret_cast<const float4*>(sss_ + (size_t)g0 * sst_ + cc_);                    \
+            qu0 = q[0]; qu1 = q[1];                                                                               \
+        }                                                                                                         \
         rb0 = *reinterpret_cast<const float4*>(b_src[0] + (size_t)(KT) * BK);                                     \
-        if (B_IT > 1) rb1 = *reinterpret_cast<const float4*>(b_src[B_IT - 1] + (size_t)(KT) * BK);                \
+        if (B_IT > 1) rb1 = *reinterpret_cast<const float4*>(b_src[B_IT > 1 ? 1 : 0] + (size_t)(KT) * BK);          \
+        if (B_IT > 2) rb2 = *reinterpret_cast<const float4*>(b_src[B_IT > 2 ? 2 : 0] + (size_t)(KT) * BK);          \
+        if (B_IT > 3) rb3 = *reinterpret_cast<const float4*>(b_src[B_IT > 3 ? 3 : 0] + (size_t)(KT) * BK);          \
         c0 += BK;                                                                                                 \
         if (c0 == d.Cin) { c0 = 0; ++tap; }                                                                       \
     }
 
 #define RP_STORE_TILE(BUF)                                                                                        \
     {                                                                                                             \
+        float4 u0_ = qu0, u1_ = qu1;                                                                              \
+        if (SSLDS && UNI) {                                                                                       \
+            const float4* q = reinterpret_cast<const float4*>(&sstab[cst]);                                       \
+            u0_ = q[0]; u1_ = q[1];                                                                               \
+        }                                                                                                         \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
             float4 v = ra[it];                                                                                    \
             float4 s0_, s1v_;                                                                                     \
-            if (SSLDS) {                                                                                          \
-                const float4* q = reinterpret_cast<const float4*>(&sstab[r_grp[it] + cst]);                       \
+            if (UNI) { s0_ = u0_; s1v_ = u1_; }                                                                   \
+            else if (SSLDS) {                                                                                     \
+                const float4* q = reinterpret_cast<const float4*>(&sstab[(r_mg[it] >> 16) + cst]);                \
                 s0_ = q[0]; s1v_ = q[1];                                                                          \
             } else { s0_ = q0[SSLDS ? 0 : it]; s1v_ = q1[SSLDS ? 0 : it]; }                                       \
             v.x = lrelu(v.x * s0_.x + s0_.y, slope); v.y = lrelu(v.y * s0_.z + s0_.w, slope);                     \
@@ -223,15 +242,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
         }                                                                                                         \
         if (BN >= RPI || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb0;              \
         if (B_IT > 1) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + RPI) * LDK + kq * 4]) = rb1;                     \
+        if (B_IT > 2) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + 2 * RPI) * LDK + kq * 4]) = rb2;                 \
+        if (B_IT > 3) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + 3 * RPI) * LDK + kq * 4]) = rb3;                 \
     }
 
+    // UNI (chosen by the host when the rows of a BatchNorm group are a multiple of BM, i.e. no tile of the
+    // launch straddles two groups): the scale/shift of a k-tile is read ONCE per thread instead of per A slot.
+    float4 qu0 = make_float4(0.f, 0.f, 0.f, 0.f), qu1 = qu0;
     RP_ISSUE_LOADS(kt_begin)
+    __syncthreads();       // every thread has its rtab rows in registers: the A buffer may be overwritten
     RP_STORE_TILE(0)
     __syncthreads();
     const int arow = (wm * MI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     const int brow = (wn * NI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     for (int kt = kt_begin; kt < nkt; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
+        const int buf = (NBUF == 2) ? ((kt - kt_begin) & 1) : 0;
 #if RP_ABLATE != 2 && RP_ABLATE != 5
         if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
 #endif
@@ -264,7 +289,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
                 }
         }
 #if RP_ABLATE != 5
-        if (kt + 1 < nkt) RP_STORE_TILE(buf ^ 1)
+        if (NBUF == 1) __syncthreads();                 // single buffer: every wave is done reading tile kt
+        if (kt + 1 < nkt) RP_STORE_TILE(NBUF == 2 ? (buf ^ 1) : 0)
 #endif
 #if RP_ABLATE != 4 && RP_ABLATE != 5
         __syncthreads();
@@ -893,7 +919,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
 enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5 };
-struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0; int ninner = 1, mt_max = 1; };
+struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
     int n = 0; void* ws = nullptr;
@@ -1046,13 +1072,15 @@ void Builder::end_group() {
     o.grid = (o.ninner == 1) ? dim3(max_mt * count, (cp / BNt) * ksplit, 1)
                              : dim3(((max_mt + 7) / 8) * 8 * count, (cp / BNt) * ksplit, 1);
     // LDS scale/shift table: every member must fit (groups spanned by a tile) x Cin entries in 1024
-    o.sslds = 1;
+    o.sslds = 1; o.uni = (cfg != 3);
     for (int i = first; i < first + count; ++i) {
         const ConvDesc& d = plan->descs[i];
         const int hw = d.Hp * d.Wp;
         const int ng = (BMt - 1) / (2 * hw) + 2;
         if ((long)ng * d.Cin > ((cfg == 0 || cfg == 3) ? 1024 : 512) || d.src[0].sstride == 0) o.sslds = 0;
+        if ((2 * hw) % BMt) o.uni = 0;             // some tile would straddle two BatchNorm groups
     }
+    if (!o.sslds) o.uni = 0;
     plan->ops.push_back(o);
     if (ksplit > 1) {
         Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
@@ -1317,6 +1345,10 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             if (op.cfg == 3) {
                 if (op.sslds) hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, true>), op.grid, dim3(512), 0, s, dd, op.ninner, op.mt_max);
                 else hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, false>), op.grid, dim3(512), 0, s, dd, op.ninner, op.mt_max);
+            } else if (op.uni) {
+                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
             } else if (op.sslds) {
                 if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
                 else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
