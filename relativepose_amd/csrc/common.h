@@ -18,6 +18,22 @@
         if (e__ != hipSuccess) return -(1000 + (int)e__);   \
     } while (0)
 
+// Global-address-space accessors.  Pointers that reach a kernel through a descriptor struct in memory are
+// "generic" to the compiler, which then emits FLAT loads/stores; FLAT ops also count against lgkmcnt, so every
+// wait for an LDS read would drain the outstanding global loads as well.  These casts give plain
+// global_load / global_store (vmcnt only).
+typedef float rp_v4f __attribute__((ext_vector_type(4)));
+typedef float rp_v2f __attribute__((ext_vector_type(2)));
+#define RP_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ float4 rp_ldg4(const float* p) { const rp_v4f v = *(RP_GLOBAL const rp_v4f*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float2 rp_ldg2(const float* p) { const rp_v2f v = *(RP_GLOBAL const rp_v2f*)p; return make_float2(v.x, v.y); }
+__device__ __forceinline__ float rp_ldg(const float* p) { return *(RP_GLOBAL const float*)p; }
+__device__ __forceinline__ double rp_ldg(const double* p) { return *(RP_GLOBAL const double*)p; }
+__device__ __forceinline__ void rp_stg4(float* p, float4 v) { const rp_v4f w = {v.x, v.y, v.z, v.w}; *(RP_GLOBAL rp_v4f*)p = w; }
+__device__ __forceinline__ void rp_stg2(float* p, float2 v) { const rp_v2f w = {v.x, v.y}; *(RP_GLOBAL rp_v2f*)p = w; }
+__device__ __forceinline__ void rp_stg(float* p, float v) { *(RP_GLOBAL float*)p = v; }
+__device__ __forceinline__ void rp_stg(double* p, double v) { *(RP_GLOBAL double*)p = v; }
+
 __device__ __forceinline__ int rp_lane() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ double rp_shfl_xor_d(double v, int m) {

@@ -82,7 +82,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (SSLDS ? 3 : 2)) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
     // ninner == 4 (the sub-pixel phases of one transposed conv, which gather from the SAME input tile):
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDK];
     __shared__ __attribute__((aligned(16))) float2 sstab[SSLDS ? SS_CAP : 4];
-    __shared__ int rowpix[BM];
+    __shared__ __attribute__((aligned(16))) int rowpix[BM];
     __shared__ signed char rowslot[BM];        // BatchNorm group of the row relative to the tile's first group
     __shared__ int tapdelta[16];
 
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
         for (int idx = tid; idx < ng * d.Cin; idx += NT) {
             const int g = g0 + idx / d.Cin, c = idx % d.Cin;
             const bool s1 = c >= d.src[0].C;
-            sstab[idx] = s1 ? d.src[1].ss[(size_t)g * d.src[1].sstride + (c - d.src[0].C)] : d.src[0].ss[(size_t)g * d.src[0].sstride + c];
+            sstab[idx] = rp_ldg2(reinterpret_cast<const float*>(s1 ? d.src[1].ss + (size_t)g * d.src[1].sstride + (c - d.src[0].C)
+                                                                    : d.src[0].ss + (size_t)g * d.src[0].sstride + c));
         }
     }
 
@@ -197,24 +198,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
             const bool ok_ = (r_mg[it] >> tap) & 1;                                                               \
             okm |= ok_ ? (1 << it) : 0;                                                                           \
             const int pix_ = ok_ ? r_base[it] + td_ : 0;                                                          \
-            ra[it] = *reinterpret_cast<const float4*>(sx_ + (size_t)pix_ * scs_ + cc_);                           \
+            ra[it] = rp_ldg4(sx_ + (size_t)pix_ * scs_ + cc_);                                                    \
             if (!SSLDS && !UNI) {                                                                                 \
                 const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                             \
                 const int sst_ = s1_ ? d.src[1].sstride : d.src[0].sstride;                                       \
-                const float4* q = reinterpret_cast<const float4*>(sss_ + (size_t)(r_mg[it] >> 16) * sst_ + cc_);    \
-                q0[SSLDS ? 0 : it] = q[0]; q1[SSLDS ? 0 : it] = q[1];                                             \
+                const float* q = reinterpret_cast<const float*>(sss_ + (size_t)(r_mg[it] >> 16) * sst_ + cc_);      \
+                q0[SSLDS ? 0 : it] = rp_ldg4(q); q1[SSLDS ? 0 : it] = rp_ldg4(q + 4);                             \
             }                                                                                                     \
         }                                                                                                         \
         if (!SSLDS && UNI) {                                                                                      \
             const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                                 \
             const int sst_ = s1_ ? d.src[1].sstride : d.src[0].sstride;                                           \
-            const float4* q = reinterpret_cast<const float4*>(sss_ + (size_t)g0 * sst_ + cc_);                    \
-            qu0 = q[0]; qu1 = q[1];                                                                               \
+            const float* q = reinterpret_cast<const float*>(sss_ + (size_t)g0 * sst_ + cc_);                      \
+            qu0 = rp_ldg4(q); qu1 = rp_ldg4(q + 4);                                                               \
         }                                                                                                         \
-        rb0 = *reinterpret_cast<const float4*>(b_src[0] + (size_t)(KT) * BK);                                     \
-        if (B_IT > 1) rb1 = *reinterpret_cast<const float4*>(b_src[B_IT > 1 ? 1 : 0] + (size_t)(KT) * BK);          \
-        if (B_IT > 2) rb2 = *reinterpret_cast<const float4*>(b_src[B_IT > 2 ? 2 : 0] + (size_t)(KT) * BK);          \
-        if (B_IT > 3) rb3 = *reinterpret_cast<const float4*>(b_src[B_IT > 3 ? 3 : 0] + (size_t)(KT) * BK);          \
+        rb0 = rp_ldg4(b_src[0] + (size_t)(KT) * BK);                                                              \
+        if (B_IT > 1) rb1 = rp_ldg4(b_src[B_IT > 1 ? 1 : 0] + (size_t)(KT) * BK);                                   \
+        if (B_IT > 2) rb2 = rp_ldg4(b_src[B_IT > 2 ? 2 : 0] + (size_t)(KT) * BK);                                   \
+        if (B_IT > 3) rb3 = rp_ldg4(b_src[B_IT > 3 ? 3 : 0] + (size_t)(KT) * BK);                                   \
         c0 += BK;                                                                                                 \
         if (c0 == d.Cin) { c0 = 0; ++tap; }                                                                       \
     }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
                 const int m = m0 + wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= d.M) continue;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) po[(size_t)m * d.cout_pad + n0 + wn * NI * 32 + j * 32 + (lane & 31)] = acc[i][j][r];
+                for (int j = 0; j < NI; ++j) rp_stg(po + (size_t)m * d.cout_pad + n0 + wn * NI * 32 + j * 32 + (lane & 31), acc[i][j][r]);
             }
         return;
     }
@@ -318,24 +319,33 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
         // per group slot (a tile spans at most two groups here), reduced in a fixed order:
         // lane rows -> lane pair (xor 32) -> the WM waves of a column (LDS, in order) -> one record per tile.
         double* red = reinterpret_cast<double*>(&As[0][0]);       // main loop is over (it ended with a barrier)
+        double s0[NI], q0s[NI], s1[NI], q1s[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { s0[j] = 0; q0s[j] = 0; s1[j] = 0; q1s[j] = 0; }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // UNI: every row of the tile is in slot 0 (rows past M hold exact zeros: their A rows are masked)
+                const int sl = UNI ? 0 : rowslot[wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const double v = (double)acc[i][j][r];
+                    if (UNI) { s0[j] += v; q0s[j] += v * v; }
+                    else {                                  // branch-free: the other slot adds +0
+                        const double v0 = sl == 0 ? v : 0.0, v1 = sl == 1 ? v : 0.0;
+                        s0[j] += v0; q0s[j] += v0 * v0; s1[j] += v1; q1s[j] += v1 * v1;
+                    }
+                }
+            }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            double s0 = 0, q0s = 0, s1 = 0, q1s = 0;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int sl = rowslot[row];
-                    const double v = (double)acc[i][j][r];
-                    if (sl == 0) { s0 += v; q0s += v * v; } else if (sl == 1) { s1 += v; q1s += v * v; }
-                }
-            s0 += rp_shfl_xor_d(s0, 32); q0s += rp_shfl_xor_d(q0s, 32);
-            s1 += rp_shfl_xor_d(s1, 32); q1s += rp_shfl_xor_d(q1s, 32);
+            s0[j] += rp_shfl_xor_d(s0[j], 32); q0s[j] += rp_shfl_xor_d(q0s[j], 32);
+            if (!UNI) { s1[j] += rp_shfl_xor_d(s1[j], 32); q1s[j] += rp_shfl_xor_d(q1s[j], 32); }
             if (lane < 32) {
                 const int cl = wn * NI * 32 + j * 32 + lane;
-                red[((0 * WM + wm) * BN + cl) * 2 + 0] = s0; red[((0 * WM + wm) * BN + cl) * 2 + 1] = q0s;
-                red[((1 * WM + wm) * BN + cl) * 2 + 0] = s1; red[((1 * WM + wm) * BN + cl) * 2 + 1] = q1s;
+                red[((0 * WM + wm) * BN + cl) * 2 + 0] = s0[j]; red[((0 * WM + wm) * BN + cl) * 2 + 1] = q0s[j];
+                red[((1 * WM + wm) * BN + cl) * 2 + 0] = s1[j]; red[((1 * WM + wm) * BN + cl) * 2 + 1] = q1s[j];
             }
         }
         __syncthreads();
@@ -345,32 +355,46 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : 2) void conv_ige
 #pragma unroll
             for (int w = 0; w < WM; ++w) { a += red[((sl * WM + w) * BN + cl) * 2]; b += red[((sl * WM + w) * BN + cl) * 2 + 1]; }
             double* o = d.stat_part + (((size_t)mtile * 2 + sl) * d.cout_pad + n0 + cl) * 2;
-            o[0] = a; o[1] = b;
+            rp_stg(o, a); rp_stg(o + 1, b);
         }
+    }
+    // output rows of this lane come in runs of 4 (r & 3): one 16-byte LDS read of their pixel indices per run
+    const int col0 = n0 + wn * NI * 32 + (lane & 31);
+    if (!d.bias && !d.tanh_out) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int4 px = *reinterpret_cast<const int4*>(&rowpix[wm * MI * 32 + i * 32 + 8 * r4 + 4 * (lane >> 5)]);
+                const int pxs[4] = {px.x, px.y, px.z, px.w};
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    if (pxs[rr] < 0) continue;
+                    float* yo = d.y + (size_t)pxs[rr] * d.ycstride + d.ychoff + col0;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        if (col0 + j * 32 < d.Cout) rp_stg(yo + j * 32, acc[i][j][r4 * 4 + rr]);
+                }
+            }
+        return;
     }
     float bias_v[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int col = n0 + wn * NI * 32 + j * 32 + (lane & 31);
-        bias_v[j] = (d.bias && col < d.Cout) ? d.bias[col] : 0.f;
-    }
+    for (int j = 0; j < NI; ++j) bias_v[j] = (d.bias && col0 + j * 32 < d.Cout) ? rp_ldg(d.bias + col0 + j * 32) : 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int pix = rowpix[row];
+            const int pix = rowpix[wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
             if (pix < 0) continue;
-            float* yo = d.y + (size_t)pix * d.ycstride + d.ychoff;
+            float* yo = d.y + (size_t)pix * d.ycstride + d.ychoff + col0;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int col = n0 + wn * NI * 32 + j * 32 + (lane & 31);
-                if (col < d.Cout) {
+            for (int j = 0; j < NI; ++j)
+                if (col0 + j * 32 < d.Cout) {
                     float v = acc[i][j][r] + bias_v[j];
                     if (d.tanh_out) v = tanhf(v);
-                    yo[col] = v;
+                    rp_stg(yo + j * 32, v);
                 }
-            }
         }
 }
 
@@ -384,15 +408,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __re
         const int m = (int)(idx / q4), c4 = (int)(idx - (size_t)m * q4) * 4;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ks = 0; ks < d.ksplit; ++ks) {
-            const float4 v = *reinterpret_cast<const float4*>(d.partial + ((size_t)ks * d.M + m) * d.cout_pad + c4);
+            const float4 v = rp_ldg4(d.partial + ((size_t)ks * d.M + m) * d.cout_pad + c4);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         const int img = m / hw, rem = m - img * hw;
         const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
         const size_t pix = ((size_t)img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
         float* yo = d.y + pix * d.ycstride + d.ychoff + c4;
-        if (c4 + 3 < d.Cout) *reinterpret_cast<float4*>(yo) = a;
-        else { if (c4 < d.Cout) yo[0] = a.x; if (c4 + 1 < d.Cout) yo[1] = a.y; if (c4 + 2 < d.Cout) yo[2] = a.z; }
+        if (c4 + 3 < d.Cout) rp_stg4(yo, a);
+        else { if (c4 < d.Cout) rp_stg(yo, a.x); if (c4 + 1 < d.Cout) rp_stg(yo + 1, a.y); if (c4 + 2 < d.Cout) rp_stg(yo + 2, a.z); }
     }
 }
 

@@ -17,6 +17,9 @@ from . import rpmodule, util
 
 
 class RelativePosePipeline:
+    _net_token = None
+    _chain_nets = False
+
     def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0):
         self.net = net
         self.dataset = dataset
@@ -63,11 +66,15 @@ class RelativePosePipeline:
         return st
 
     def run_interleaved(self, states):
-        """Several prepared batches advanced in lock step, each on its own HIP stream: the launch-bound matcher
-        phase of one batch (hundreds of few-microsecond kernels) overlaps the MFMA-bound SCNet phase of the
-        others.  Per-pair results are identical to `run` (same kernels, same data).  Returns [(pose, status)]."""
+        """Several prepared batches software-pipelined on their own HIP streams: the SCNet forwards are chained
+        by events (one at a time, each owning the whole GPU: A0 B0 A1 B1 ...), so the launch-bound matcher phase
+        of one batch (hundreds of few-microsecond kernels) always runs UNDER the MFMA-bound SCNet phase of the
+        next one instead of next to another matcher.  Per-pair results are identical to `run` (same kernels,
+        same data).  Returns [(pose, status)]."""
         import torch
         cur = torch.cuda.current_stream()
+        self._net_token = None
+        self._chain_nets = len(states) > 1
         for st in states:
             if "stream" not in st:
                 st["stream"] = torch.cuda.Stream()
@@ -85,6 +92,7 @@ class RelativePosePipeline:
                         live.remove(i)
         for st in states:
             cur.wait_stream(st["stream"])
+        self._net_token, self._chain_nets = None, False
         return [(o[0], o[1]) for o in out]
 
     def _run_gen(self, st):
@@ -98,7 +106,15 @@ class RelativePosePipeline:
             poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
             other = view.view(B, 2, 8, h, 4 * h).flip(1).reshape(2 * B, 8, h, 4 * h).contiguous()
             warped = util.warping_dev(other, poses, self.dataset)
-            f = self.net(torch.cat((view, warped), 1))
+            x = torch.cat((view, warped), 1)
+            if self._chain_nets:
+                if self._net_token is not None:
+                    torch.cuda.current_stream().wait_event(self._net_token)
+                f = self.net(x)
+                self._net_token = torch.cuda.Event()
+                self._net_token.record()
+            else:
+                f = self.net(x)
             yield
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
                                                     self.mask_method, self.dataset)
