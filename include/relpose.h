@@ -127,6 +127,13 @@ size_t relpose_warp_workspace_bytes(int32_t n, int32_t h);
 int relpose_warp(const float* view, const double* pose, float* out, void* workspace,
                  int32_t n, int32_t h, int32_t dataset, void* stream);
 
+/* The warp of evaluation.py:221-222,235-236 for a batch of pairs, in place on the network input
+ * x [n,16,h,4h] (n even; images 2b, 2b+1 are a pair): channels 0:8 of every image hold its own view
+ * (caller-filled, only read here); channels 8:16 of image i receive the view of its partner (image i^1)
+ * warped by pose[i] -- i.e. torch.cat((view, warping(other, pose)), 1) without materialising `other`
+ * or the concatenation.  Same workspace as relpose_warp. */
+int relpose_warp_pairs(float* x, const double* pose, void* workspace, int32_t n, int32_t h, int32_t dataset, void* stream);
+
 /* np.linalg.inv of n 4x4 poses (evaluation.py:235). */
 int relpose_pose_inverse(const double* pose, double* inv, int32_t n, void* stream);
 

@@ -164,13 +164,15 @@ __device__ __forceinline__ bool pose_is_identity(const double* T) {
 
 // pass 1: every source point claims its target pixel in each face with atomicMax(point index + 1):
 // numpy fancy assignment = the last point in point order wins (util.py:603-608).
+// The source view of output image `img` is image (img ^ swap) of `view`, whose images are `vstride` floats apart
+// (swap = 1, vstride = 16*hw: the partner's own-view channels of the in-place network input, relpose_warp_pairs).
 __global__ void warp_scatter_kernel(const float* __restrict__ view, const double* __restrict__ pose, int* __restrict__ keys,
-                                    int n, int h, int dataset, WarpSrc s) {
+                                    int n, int h, int dataset, WarpSrc s, size_t vstride, int swap) {
     const int img = blockIdx.y;
     const double* T = pose + (size_t)img * 16;
     if (pose_is_identity(T)) return;
     const size_t hw = (size_t)h * 4 * h;
-    const float* vw = view + (size_t)img * 8 * hw;
+    const float* vw = view + (size_t)(img ^ swap) * vstride;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < s.npts; p += gridDim.x * blockDim.x) {
         double q[3]; int py, px;
         if (!warp_point(vw, T, h, dataset, s, p, q, py, px)) continue;
@@ -184,14 +186,14 @@ __global__ void warp_scatter_kernel(const float* __restrict__ view, const double
 }
 
 // pass 2: every output pixel gathers from the winning point.
-__global__ void warp_gather_kernel(const float* __restrict__ view, const double* __restrict__ pose, const int* __restrict__ keys,
-                                   float* __restrict__ out, int n, int h, int dataset, WarpSrc s) {
+__global__ void warp_gather_kernel(const float* view, const double* __restrict__ pose, const int* __restrict__ keys,
+                                   float* out, int n, int h, int dataset, WarpSrc s, size_t vstride, int swap, size_t ostride) {
     const int img = blockIdx.y;
     const double* T = pose + (size_t)img * 16;
     const bool ident = pose_is_identity(T);
     const size_t hw = (size_t)h * 4 * h;
-    const float* vw = view + (size_t)img * 8 * hw;
-    float* o = out + (size_t)img * 8 * hw;
+    const float* vw = view + (size_t)(img ^ swap) * vstride;
+    float* o = out + (size_t)img * ostride;
     for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < (int)hw; pix += gridDim.x * blockDim.x) {
         float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int key = ident ? 0 : keys[(size_t)img * hw + pix];
@@ -455,18 +457,31 @@ int relpose_pano2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, i
 
 size_t relpose_warp_workspace_bytes(int32_t n, int32_t h) { return (n <= 0 || h <= 0) ? 0 : rp_align((size_t)n * h * 4 * h * 4); }
 
-int relpose_warp(const float* view, const double* pose, float* out, void* workspace, int32_t n, int32_t h, int32_t dataset, void* stream) {
-    if (!view || !pose || !out || !workspace || n <= 0 || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+static int launch_warp(const float* view, size_t vstride, int swap, const double* pose, float* out, size_t ostride, void* workspace,
+                       int32_t n, int32_t h, int32_t dataset, hipStream_t s) {
     const size_t hw = (size_t)h * 4 * h;
     int* keys = (int*)workspace;
     RP_HIP(hipMemsetAsync(keys, 0, (size_t)n * hw * 4, s));
     const WarpSrc src = warp_src(dataset, h);
-    hipLaunchKernelGGL(warp_scatter_kernel, dim3((src.npts + 255) / 256, n), dim3(256), 0, s, view, pose, keys, n, h, dataset, src);
+    hipLaunchKernelGGL(warp_scatter_kernel, dim3((src.npts + 255) / 256, n), dim3(256), 0, s, view, pose, keys, n, h, dataset, src, vstride,
+                       swap);
     RP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(warp_gather_kernel, dim3((int)((hw + 255) / 256), n), dim3(256), 0, s, view, pose, keys, out, n, h, dataset, src);
+    hipLaunchKernelGGL(warp_gather_kernel, dim3((int)((hw + 255) / 256), n), dim3(256), 0, s, view, pose, keys, out, n, h, dataset, src,
+                       vstride, swap, ostride);
     RP_CHECK_LAUNCH();
     return 0;
+}
+
+int relpose_warp(const float* view, const double* pose, float* out, void* workspace, int32_t n, int32_t h, int32_t dataset, void* stream) {
+    if (!view || !pose || !out || !workspace || n <= 0 || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
+    const size_t hw = (size_t)h * 4 * h;
+    return launch_warp(view, 8 * hw, 0, pose, out, 8 * hw, workspace, n, h, dataset, (hipStream_t)stream);
+}
+
+int relpose_warp_pairs(float* x, const double* pose, void* workspace, int32_t n, int32_t h, int32_t dataset, void* stream) {
+    if (!x || !pose || !workspace || n <= 0 || (n & 1) || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
+    const size_t hw = (size_t)h * 4 * h;
+    return launch_warp(x, 16 * hw, 1, pose, x + 8 * hw, 16 * hw, workspace, n, h, dataset, (hipStream_t)stream);
 }
 
 int relpose_pose_inverse(const double* pose, double* inv, int32_t n, void* stream) {

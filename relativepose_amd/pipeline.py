@@ -95,18 +95,28 @@ class RelativePosePipeline:
         self._net_token, self._chain_nets = None, False
         return [(o[0], o[1]) for o in out]
 
+    def _net_input(self, st):
+        """The network input [2B,16,h,4h] of a prepared batch (kept across calls): channels 0:8 = the masked own
+        view of every image (util.apply_mask layout), channels 8:16 are rewritten by every level's warp."""
+        import torch
+        B, h = st["B"], st["h"]
+        view = util.build_view_dev(st["rgb"], st["norm"], st["depth"], self.mask_method)      # [2B,8,h,4h]
+        x = st.get("x")
+        if x is None:
+            x = st["x"] = torch.empty(2 * B, 16, h, 4 * h, dtype=torch.float32, device=view.device)
+        x[:, :8].copy_(view)
+        return x
+
     def _run_gen(self, st):
         """`run` as a generator that yields after the SCNet phase and after the matcher phase of every level."""
         import torch
         B, h, N = st["B"], st["h"], st["N"]
-        view = util.build_view_dev(st["rgb"], st["norm"], st["depth"], self.mask_method)
+        x = self._net_input(st)
         R_hat, status = st["eye"], None
         for step in range(self.alter_steps):
             inv = util.pose_inverse_dev(R_hat)
             poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
-            other = view.view(B, 2, 8, h, 4 * h).flip(1).reshape(2 * B, 8, h, 4 * h).contiguous()
-            warped = util.warping_dev(other, poses, self.dataset)
-            x = torch.cat((view, warped), 1)
+            util.warp_pairs_dev(x, poses, self.dataset)       # x[:, 8:] = partner view warped by the pose estimate
             if self._chain_nets:
                 if self._net_token is not None:
                     torch.cuda.current_stream().wait_event(self._net_token)
@@ -132,7 +142,7 @@ class RelativePosePipeline:
         [pose after each step]).  R_forced: optional list of [B,4,4] tensors (teacher forcing, tests)."""
         import torch
         B, h, N = st["B"], st["h"], st["N"]
-        view = util.build_view_dev(st["rgb"], st["norm"], st["depth"], self.mask_method)      # [2B,8,h,4h]
+        x = self._net_input(st)                                                               # [2B,16,h,4h]
         R_hat = st["eye"]
         trace = []
         status = None
@@ -142,9 +152,7 @@ class RelativePosePipeline:
             # image 2b (source) gets target warped by inv(R), image 2b+1 (target) gets source warped by R
             inv = util.pose_inverse_dev(R_hat)
             poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
-            other = view.view(B, 2, 8, h, 4 * h).flip(1).reshape(2 * B, 8, h, 4 * h).contiguous()
-            warped = util.warping_dev(other, poses, self.dataset)
-            x = torch.cat((view, warped), 1)
+            util.warp_pairs_dev(x, poses, self.dataset)       # x[:, 8:] = partner view warped by the pose estimate
             f = self.net(x)
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
                                                     self.mask_method, self.dataset)
@@ -156,5 +164,5 @@ class RelativePosePipeline:
             R_hat, status = res.pose, res.status
             trace.append(R_hat)
             if keep is not None:
-                keep.append({"x": x, "f": f, "pc": pc, "nn": nn, "ft": ft})
+                keep.append({"x": x.clone(), "f": f, "pc": pc, "nn": nn, "ft": ft})
         return R_hat, status, trace

@@ -68,6 +68,24 @@ def warping_dev(view, pose, dataset, out=None):
     return out
 
 
+def warp_pairs_dev(x, pose, dataset):
+    """In place on the network input x [n,16,h,4h]: x[i, 8:16] = warping(x[i^1, 0:8], pose[i]) (relpose_warp_pairs)."""
+    import torch
+    _lib.require_gpu()
+    n, c, h, w = x.shape
+    assert c == 16 and w == 4 * h and n % 2 == 0 and x.is_contiguous() and pose.is_contiguous() and pose.dtype == torch.float64
+    L = _lib.lib()
+    nbytes = L.relpose_warp_workspace_bytes(n, h)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _warp_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _warp_ws[key] = ws
+    rc = L.relpose_warp_pairs(_lib.ptr(x), _lib.ptr(pose), _lib.ptr(ws), n, h, dataset_id(dataset), _lib.stream_ptr())
+    _lib.check(rc, "relpose_warp_pairs")
+    return x
+
+
 def pose_inverse_dev(pose):
     import torch
     out = torch.empty_like(pose)

@@ -89,6 +89,32 @@ def test_warp_batched_and_inverse(dev):
     assert np.allclose(inv, np.linalg.inv(T), atol=1e-14)
 
 
+@pytest.mark.parametrize("ds", ["suncg", "matterport", "scannet"])
+def test_warp_pairs_in_place_equals_cat_of_warp(dev, ds):
+    """relpose_warp_pairs on x [n,16,h,4h] == torch.cat((view, warping(partner view, pose)), 1), bit for bit."""
+    import torch
+    from relativepose_amd import util
+    d = synth.make_pairs(2, 91, ds)
+    mm = "second" if ds == "suncg" else ("kinect" if ds == "scannet" else "second")
+    rgb = torch.from_numpy(d["rgb"].reshape(4, 3, 160, 640)).to(dev)
+    nrm = torch.from_numpy(d["norm"].reshape(4, 3, 160, 640)).to(dev)
+    dep = torch.from_numpy(d["depth"].reshape(4, 160, 640)).to(dev)
+    view = util.build_view_dev(rgb, nrm, dep, mm)
+    rs = np.random.RandomState(9)
+    T = np.stack([synth.random_rigid(rs, 1.0, 0.5) for _ in range(4)])
+    T[1] = np.eye(4)
+    Td = torch.from_numpy(T).to(dev)
+    other = view.view(2, 2, 8, 160, 640).flip(1).reshape(4, 8, 160, 640).contiguous()
+    want = torch.cat((view, util.warping_dev(other, Td, ds)), 1)
+    x = torch.full((4, 16, 160, 640), float("nan"), device=dev)
+    x[:, :8].copy_(view)
+    util.warp_pairs_dev(x, Td, ds)
+    assert torch.equal(x, want)
+    util.warp_pairs_dev(x, Td, ds)                        # idempotent: the own-view half is never written
+    assert torch.equal(x, want)
+    assert float(x[1, 8:].abs().max()) == 0.0             # identity pose -> zeros (util.py:96)
+
+
 @pytest.mark.parametrize("ds,mm,seed", GEOM_CASES)
 def test_sample_primitives(gg, dev, ds, mm, seed):
     """compose + getPixel + interpolate: f = a synthetic 'network output' (54 channels)."""
