@@ -33,6 +33,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifndef RP_ABLATE
 #define RP_ABLATE 0
 #endif
+#ifndef RP_C1_ABLATE
+#define RP_C1_ABLATE 0
+#endif
 #ifndef RP_BK
 #define RP_BK 32
 #endif
@@ -425,61 +428,89 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __re
 // implicit GEMM; one wave handles 64 pixels of one (modality, stream) block so the weights are wave-uniform
 // (scalar loads, SGPR operands) and every lane accumulates its 32 outputs in registers.
 // w1: [6][9 taps][4 ch][32 out] (zero rows for the 2-channel depth block).
-__global__ __launch_bounds__(256) void conv1_direct_kernel(const float* __restrict__ x0, const float* __restrict__ w1,
+__global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __restrict__ x0, const float* __restrict__ w1,
                                                             float* __restrict__ a1, int n) {
     const int q = blockIdx.y;                        // block 2*m + s
     const int m = q >> 1, sft = (q & 1) * 8;
     // input channels of this block inside the 16-channel pixel (mymodel.py:264-286)
     const int c0 = m == 0 ? sft + 0 : (m == 1 ? sft + 3 : sft + 6);
     const int nch = m == 2 ? 2 : 4;                  // {rgb|n} + mask, or depth + mask
-    const size_t total = (size_t)n * RS * RS;      // multiple of 64: a wave never straddles the end
+    const size_t total = (size_t)n * RS * RS;      // multiple of 256 (224*224 = 196*256): a wave's pass never straddles the end
     __shared__ __attribute__((aligned(16))) float wl[9 * 4 * 32];      // this block's weights, read as LDS broadcasts
     __shared__ __attribute__((aligned(16))) float tile[4 * 64 * 36];
     for (int i = threadIdx.x; i < 9 * 4 * 32; i += 256) wl[i] = w1[(size_t)q * 9 * 4 * 32 + i];
     __syncthreads();
-    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+    // A wave takes 256 consecutive pixels per pass, lane l the 4 horizontal neighbours base + 4l .. 4l+3 (224 is a
+    // multiple of 4: they share a row).  Per kernel row the lane fetches its 6 input columns ONCE (the 3x3 windows
+    // of the 4 pixels overlap) and only the channel quads this block needs; every weight quad read from LDS (a
+    // broadcast, but still 1 KB of register writes) feeds 4 pixels; the 32 outputs of a pixel are 16 pairs
+    // accumulated with packed FMAs (v_pk_fma_f32: two fp32 FMAs per lane per issue).
+    constexpr int PX = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* tw = tile + wave * 64 * 36;
+    // quads of the 16-channel pixel that hold this block's inputs: A (first data quad) and B (second / mask quad)
+    const int qA = (m == 2 ? sft + 4 : sft), qB = sft + 4;
+    for (size_t base = ((size_t)blockIdx.x * 4 + wave) * (64 * PX); base < total; base += (size_t)gridDim.x * 4 * (64 * PX)) {
+        rp_v2f acc[PX][16];
+#pragma unroll
+        for (int k = 0; k < PX; ++k)
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[k][o] = (rp_v2f){0.f, 0.f};
+        const size_t pix = base + lane * PX;             // first of the lane's 4 pixels
         const int x = (int)(pix % RS), y = (int)((pix / RS) % RS);
-        float acc[32];
-#pragma unroll
-        for (int o = 0; o < 32; ++o) acc[o] = 0.f;
 #pragma unroll 1
-        for (int t = 0; t < 9; ++t) {
-            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-            const bool ok = (iy >= 0) & (iy < RS) & (ix >= 0) & (ix < RS);
-            const float* p = x0 + (pix + (ok ? (ptrdiff_t)(t / 3 - 1) * RS + (t % 3 - 1) : 0)) * 16;
-            // the pixel's 16 channels are one 64-byte line: fetch the two quads that hold this block's inputs
-            const float4 qa = *reinterpret_cast<const float4*>(p + (c0 & ~3));
-            const float4 qb = *reinterpret_cast<const float4*>(p + ((c0 & ~3) + 4 > 12 ? 12 : (c0 & ~3) + 4));
-            const float4 qm = *reinterpret_cast<const float4*>(p + sft + 4);        // channels sft+4..sft+7 (mask = .w)
-            float in[4];                                  // block-uniform selection (m is per block)
-            if (m == 0) { in[0] = qa.x; in[1] = qa.y; in[2] = qa.z; in[3] = qm.w; }
-            else if (m == 1) { in[0] = qa.w; in[1] = qb.x; in[2] = qb.y; in[3] = qm.w; }
-            else { in[0] = qa.z; in[1] = qm.w; in[2] = 0.f; in[3] = 0.f; }
-#pragma unroll 1
-            for (int c = 0; c < 4; ++c) {
-                const float vin = c == 0 ? in[0] : (c == 1 ? in[1] : (c == 2 ? in[2] : in[3]));
-                const float v = ok ? vin : 0.f;
+        for (int ty = 0; ty < 3; ++ty) {
+            const int iy = y + ty - 1;
+            const bool oky = (iy >= 0) & (iy < RS);
+            float in[PX + 2][4];
 #pragma unroll
-                for (int o4 = 0; o4 < 8; ++o4) {
-                    const float4 wv = *reinterpret_cast<const float4*>(&wl[(t * 4 + c) * 32 + o4 * 4]);   // wave-uniform address
-                    acc[o4 * 4 + 0] = fmaf(v, wv.x, acc[o4 * 4 + 0]); acc[o4 * 4 + 1] = fmaf(v, wv.y, acc[o4 * 4 + 1]);
-                    acc[o4 * 4 + 2] = fmaf(v, wv.z, acc[o4 * 4 + 2]); acc[o4 * 4 + 3] = fmaf(v, wv.w, acc[o4 * 4 + 3]);
-                }
+            for (int cx = 0; cx < PX + 2; ++cx) {
+                const int ix = x + cx - 1;
+                const bool ok = oky & (ix >= 0) & (ix < RS);
+                const float* p = x0 + (pix + (ok ? (ptrdiff_t)(ty - 1) * RS + (cx - 1) : 0)) * 16;
+                const float4 a = *reinterpret_cast<const float4*>(p + qA);
+                float4 b = a;
+                if (m != 2) b = *reinterpret_cast<const float4*>(p + qB);        // block-uniform
+                // block-uniform channel selection (mymodel.py:264-286): {rgb|n} + mask, or depth + mask
+                if (m == 0) { in[cx][0] = a.x; in[cx][1] = a.y; in[cx][2] = a.z; in[cx][3] = b.w; }
+                else if (m == 1) { in[cx][0] = a.w; in[cx][1] = b.x; in[cx][2] = b.y; in[cx][3] = b.w; }
+                else { in[cx][0] = a.z; in[cx][1] = a.w; in[cx][2] = 0.f; in[cx][3] = 0.f; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) in[cx][c] = ok ? in[cx][c] : 0.f;       // zero padding
             }
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    rp_v2f vv[PX];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) vv[k] = (rp_v2f){in[k + tx][c], in[k + tx][c]};
+                    const float* wrow = &wl[((ty * 3 + tx) * 4 + c) * 32];
+#pragma unroll
+                    for (int o4 = 0; o4 < 8; ++o4) {
+                        const float4 wv = *reinterpret_cast<const float4*>(wrow + o4 * 4);   // wave-uniform address
+                        const rp_v2f w01 = {wv.x, wv.y}, w23 = {wv.z, wv.w};
+#pragma unroll
+                        for (int k = 0; k < PX; ++k) {
+                            acc[k][o4 * 2 + 0] = vv[k] * w01 + acc[k][o4 * 2 + 0];
+                            acc[k][o4 * 2 + 1] = vv[k] * w23 + acc[k][o4 * 2 + 1];
+                        }
+                    }
+                }
         }
-        // transpose through LDS: lane l first holds pixel l (32 channels); it then writes chunk (l&7) of
-        // pixels (l>>3)+8*k, so every store instruction covers 8 full 128-B lines
-        float* tw = tile + (threadIdx.x >> 6) * 64 * 36;
-        const int lane = threadIdx.x & 63;
+        // transpose through LDS: lane l first holds pixel 4l+k (32 channels); it then writes chunk (l&7) of the
+        // pixels 4*((l>>3)+8j)+k, so every store instruction covers 8 full 128-B lines
 #pragma unroll
-        for (int o = 0; o < 8; ++o)
-            *reinterpret_cast<float4*>(tw + lane * 36 + o * 4) = make_float4(acc[4 * o], acc[4 * o + 1], acc[4 * o + 2], acc[4 * o + 3]);
-        const size_t pix0 = pix - lane;                 // first pixel of this wave (a wave's pixels are consecutive)
+        for (int k = 0; k < PX; ++k) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int pl = (lane >> 3) + 8 * k;
-            const float4 v = *reinterpret_cast<const float4*>(tw + pl * 36 + (lane & 7) * 4);
-            if (pix0 + pl < total) *reinterpret_cast<float4*>(a1 + (pix0 + pl) * 192 + q * 32 + (lane & 7) * 4) = v;
+            for (int o = 0; o < 8; ++o)
+                *reinterpret_cast<float4*>(tw + lane * 36 + o * 4) = make_float4(acc[k][2 * o].x, acc[k][2 * o].y, acc[k][2 * o + 1].x, acc[k][2 * o + 1].y);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int pl = (lane >> 3) + 8 * jj;
+                const float4 v = *reinterpret_cast<const float4*>(tw + pl * 36 + (lane & 7) * 4);
+                *reinterpret_cast<float4*>(a1 + (base + (size_t)pl * PX + k) * 192 + q * 32 + (lane & 7) * 4) = v;
+            }
         }
     }
 }
