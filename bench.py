@@ -65,7 +65,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="scan pairs per GPU")
     ap.add_argument("--keypoints", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="split the per-GPU batch over this many HIP streams (matcher/SCNet overlap)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
+    ap.add_argument("--streams", type=int, default=1, help="with --inflight 1: split the batch over this many HIP streams instead")
     args = ap.parse_args()
 
     import torch
@@ -85,15 +87,23 @@ def main():
     # synthetic inputs + random-init weights (no dataset / checkpoint ships with the reference)
     data = synth.make_pairs(hi - lo, 2000 + lo, "suncg")      # seed = 1000*config + pair index
     pts, ptw = synth.make_keypoints(hi - lo, N, 2000 + lo, "second")
+    depth = max(1, args.inflight)
     net = SCNet(SimpleNamespace(batchnorm=1, useTanh=1, skipLayer=1, outputType="rgbdnsf", snumclass=S))
     net.load_state_dict(weights.make_state_dict(7, S))
     Cc = N * 5
     pipe = RelativePosePipeline(net, "suncg", "second", SUNCG_SIGMAS, max_edges=min(Cc * (Cc - 1), 1 << 20))
     nloc = hi - lo
-    ns_ = max(1, min(args.streams, nloc))
+    ns_ = 1 if depth > 1 else max(1, min(args.streams, nloc))
     cuts = [nloc * i // ns_ for i in range(ns_ + 1)]
     states = [pipe.prepare(data["rgb"][a:b], data["norm"][a:b], data["depth"][a:b], pts[a:b], ptw[a:b], dev)
               for a, b in zip(cuts[:-1], cuts[1:])]
+
+    # one prepared batch (own device buffers + HIP stream) per step in flight; slot j > 0 gets its own scan pairs
+    batches = [states[0]] if depth > 1 else None
+    for j in range(1, depth):
+        dj = synth.make_pairs(nloc, 2000 + lo + 100000 * j, "suncg")
+        pj, wj = synth.make_keypoints(nloc, N, 2000 + lo + 100000 * j, "second")
+        batches.append(pipe.prepare(dj["rgb"], dj["norm"], dj["depth"], pj, wj, dev))
 
     def step():
         if len(states) == 1:
@@ -103,13 +113,21 @@ def main():
             pose, status = torch.cat([r[0] for r in res]), torch.cat([r[1] for r in res])
         return D.gather_poses(pose, status, total, world)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(k):
+        """k steps = k batches of B pairs per GPU, each followed by the pose gather; returns the last result."""
+        if depth > 1:
+            return pipe.run_pipelined(batches, k, lambda i, pose, status: D.gather_poses(pose, status, total, world))[-1]
+        out = None
+        for _ in range(k):
+            out = step()
+        return out
+
+    if args.warmup:
+        run_steps(args.warmup)
     torch.cuda.synchronize()
     D.barrier(world)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        poses, status = step()
+    poses, status = run_steps(args.steps)
     torch.cuda.synchronize()
     D.barrier(world)
     dt = D.max_over_ranks(time.perf_counter() - t0, world, dev)
@@ -122,7 +140,7 @@ def main():
                "data": "synthetic (seeded box-room RGB-D panoramas, injected keypoints, random-init weights)",
                "config": {"workload": "SUNCG 160x640, N=200 keypoints, batch=32 pairs per GPU, alterStep=3 (BASELINE configs[1])",
                           "pairs_per_gpu": B, "keypoints": N, "recurrent_levels": 3, "parallelism": f"pairs sharded x{world}",
-                          "streams_per_gpu": len(states)},
+                          "batches_in_flight": depth, "streams_per_batch": len(states)},
                "status_ok_fraction": float((status == 0).double().mean().item())}
         # --- roofline of the dominant kernel: implicit-GEMM conv, HIP events on the launch stream
         x = torch.randn(2 * B, 16, 160, 640, device=dev)

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (SSLDS ? 3 : 2))
     constexpr int SS_CAP = (WN == 2) ? 1024 : 512;      // float2 entries of the LDS scale/shift table (8 / 4 KB: keeps 3 blocks per CU)
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDK];
-    __shared__ __attribute__((aligned(16))) float2 sstab[SSLDS ? SS_CAP : 4];
+    __shared__ __attribute__((aligned(16))) float sstab[SSLDS ? 2 * SS_CAP : 8];   // per 4 channels: 4 scales, then 4 shifts
     __shared__ __attribute__((aligned(16))) int rowpix[BM];
     __shared__ signed char rowslot[BM];        // BatchNorm group of the row relative to the tile's first group
     __shared__ int tapdelta[16];
@@ -152,8 +152,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (SSLDS ? 3 : 2))
         for (int idx = tid; idx < ng * d.Cin; idx += NT) {
             const int g = g0 + idx / d.Cin, c = idx % d.Cin;
             const bool s1 = c >= d.src[0].C;
-            sstab[idx] = rp_ldg2(reinterpret_cast<const float*>(s1 ? d.src[1].ss + (size_t)g * d.src[1].sstride + (c - d.src[0].C)
-                                                                    : d.src[0].ss + (size_t)g * d.src[0].sstride + c));
+            const float2 e = rp_ldg2(reinterpret_cast<const float*>(s1 ? d.src[1].ss + (size_t)g * d.src[1].sstride + (c - d.src[0].C)
+                                                                       : d.src[0].ss + (size_t)g * d.src[0].sstride + c));
+            sstab[(idx & ~3) * 2 + (idx & 3)] = e.x; sstab[(idx & ~3) * 2 + 4 + (idx & 3)] = e.y;
         }
     }
 
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (SSLDS ? 3 : 2))
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
             const bool ok_ = (r_mg[it] >> tap) & 1;                                                               \
             okm |= ok_ ? (1 << it) : 0;                                                                           \
-            const int pix_ = ok_ ? r_base[it] + td_ : 0;                                                          \
+            const int pix_ = (RP_ABLATE == 6) ? (it * 8) : (RP_ABLATE == 7) ? ((r_base[it] + td_) & 0xfff) : ok_ ? r_base[it] + td_ : 0;   \
             ra[it] = rp_ldg4(sx_ + (size_t)pix_ * scs_ + cc_);                                                    \
             if (!SSLDS && !UNI) {                                                                                 \
                 const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                             \
@@ -225,24 +226,33 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (SSLDS ? 3 : 2))
 
 #define RP_STORE_TILE(BUF)                                                                                        \
     {                                                                                                             \
-        float4 u0_ = qu0, u1_ = qu1;                                                                              \
+        /* BatchNorm scale/shift + LeakyReLU + zero padding as packed fp32 ops (v_pk_fma / v_pk_mul): u0_ = the   \
+           4 scales, u1_ = the 4 shifts of this thread's channels */                                             \
+        float4 u0_ = make_float4(qu0.x, qu0.z, qu1.x, qu1.z), u1_ = make_float4(qu0.y, qu0.w, qu1.y, qu1.w);      \
         if (SSLDS && UNI) {                                                                                       \
-            const float4* q = reinterpret_cast<const float4*>(&sstab[cst]);                                       \
+            const float4* q = reinterpret_cast<const float4*>(&sstab[2 * cst]);                                   \
             u0_ = q[0]; u1_ = q[1];                                                                               \
         }                                                                                                         \
+        const rp_v2f sl2_ = {slope, slope};                                                                       \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
-            float4 v = ra[it];                                                                                    \
             float4 s0_, s1v_;                                                                                     \
             if (UNI) { s0_ = u0_; s1v_ = u1_; }                                                                   \
             else if (SSLDS) {                                                                                     \
-                const float4* q = reinterpret_cast<const float4*>(&sstab[(r_mg[it] >> 16) + cst]);                \
+                const float4* q = reinterpret_cast<const float4*>(&sstab[2 * ((r_mg[it] >> 16) + cst)]);          \
                 s0_ = q[0]; s1v_ = q[1];                                                                          \
-            } else { s0_ = q0[SSLDS ? 0 : it]; s1v_ = q1[SSLDS ? 0 : it]; }                                       \
-            v.x = lrelu(v.x * s0_.x + s0_.y, slope); v.y = lrelu(v.y * s0_.z + s0_.w, slope);                     \
-            v.z = lrelu(v.z * s1v_.x + s1v_.y, slope); v.w = lrelu(v.w * s1v_.z + s1v_.w, slope);                 \
-            const bool ok_ = (okm >> it) & 1;                                                                     \
-            v.x = ok_ ? v.x : 0.f; v.y = ok_ ? v.y : 0.f; v.z = ok_ ? v.z : 0.f; v.w = ok_ ? v.w : 0.f;           \
-            *reinterpret_cast<float4*>(&As[BUF][(lrow + it * RPI) * LDK + kq * 4]) = v;                            \
+            } else {                                                                                              \
+                const float4 a_ = q0[SSLDS ? 0 : it], b_ = q1[SSLDS ? 0 : it];                                    \
+                s0_ = make_float4(a_.x, a_.z, b_.x, b_.z); s1v_ = make_float4(a_.y, a_.w, b_.y, b_.w);            \
+            }                                                                                                     \
+            rp_v2f v01 = {ra[it].x, ra[it].y}, v23 = {ra[it].z, ra[it].w};                                        \
+            v01 = v01 * (rp_v2f){s0_.x, s0_.y} + (rp_v2f){s1v_.x, s1v_.y};                                        \
+            v23 = v23 * (rp_v2f){s0_.z, s0_.w} + (rp_v2f){s1v_.z, s1v_.w};                                        \
+            const rp_v2f t01 = v01 * sl2_, t23 = v23 * sl2_;                                                      \
+            const float okf_ = ((okm >> it) & 1) ? 1.f : 0.f;                                                     \
+            const rp_v2f mk_ = {okf_, okf_};                                                                      \
+            v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                       \
+            v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                       \
+            *reinterpret_cast<float4*>(&As[BUF][(lrow + it * RPI) * LDK + kq * 4]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
         }                                                                                                         \
         if (BN >= RPI || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb0;              \
         if (B_IT > 1) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + RPI) * LDK + kq * 4]) = rb1;                     \

@@ -95,6 +95,52 @@ class RelativePosePipeline:
         self._net_token, self._chain_nets = None, False
         return [(o[0], o[1]) for o in out]
 
+    def run_pipelined(self, states, steps, on_result=None):
+        """`steps` consecutive batches through the hot path with len(states) of them in flight (a serving loop):
+        batch k uses the prepared buffers and the HIP stream of states[k % depth].  SCNet forwards are chained by
+        events exactly as in `run_interleaved`, so while batch k is in its launch-bound matcher phase the GPU
+        runs the SCNet forward of batch k+1 -- both at the FULL batch size (splitting one batch over streams
+        halves the SCNet batch and costs ~13 % conv efficiency).  on_result(k, pose, status) -> value is called
+        on the caller's stream as soon as batch k is complete.  Returns the per-batch results in order."""
+        import torch
+        cur = torch.cuda.current_stream()
+        depth = len(states)
+        self._net_token = None
+        self._chain_nets = depth > 1
+        for st in states:
+            if "stream" not in st:
+                st["stream"] = torch.cuda.Stream()
+            st["stream"].wait_stream(cur)
+        results = [None] * steps
+        live, nxt = {}, 0
+        while nxt < steps or live:
+            for slot in range(depth):
+                if slot not in live and nxt < steps:
+                    live[slot] = (nxt, self._run_gen(states[slot]))
+                    nxt += 1
+                if slot not in live:
+                    continue
+                k, gen = live[slot]
+                done = None
+                with torch.cuda.stream(states[slot]["stream"]):
+                    try:
+                        next(gen)
+                    except StopIteration as e:
+                        done = e.value
+                if done is not None:
+                    del live[slot]
+                    pose, status = done[0], done[1]
+                    if on_result is not None:
+                        cur.wait_stream(states[slot]["stream"])
+                        pose.record_stream(cur); status.record_stream(cur)
+                        results[k] = on_result(k, pose, status)
+                    else:
+                        results[k] = (pose, status)
+        for st in states:
+            cur.wait_stream(st["stream"])
+        self._net_token, self._chain_nets = None, False
+        return results
+
     def _net_input(self, st):
         """The network input [2B,16,h,4h] of a prepared batch (kept across calls): channels 0:8 = the masked own
         view of every image (util.apply_mask layout), channels 8:16 are rewritten by every level's warp."""
