@@ -438,8 +438,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __re
 // implicit GEMM; one wave handles 64 pixels of one (modality, stream) block so the weights are wave-uniform
 // (scalar loads, SGPR operands) and every lane accumulates its 32 outputs in registers.
 // w1: [6][9 taps][4 ch][32 out] (zero rows for the 2-channel depth block).
+// BatchNorm statistics of A1 are fused: each pass (256 pixels of ONE image) leaves a float64 {sum, sum of squares}
+// record per output channel in stat[group][pass in group][192][2], consumed by bn_finalize_kernel in pass order.
+constexpr int C1_PASSES_PER_GROUP = 2 * RS * RS / 256;      // 392
 __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __restrict__ x0, const float* __restrict__ w1,
-                                                            float* __restrict__ a1, int n) {
+                                                            float* __restrict__ a1, double* __restrict__ stat, int n) {
     const int q = blockIdx.y;                        // block 2*m + s
     const int m = q >> 1, sft = (q & 1) * 8;
     // input channels of this block inside the 16-channel pixel (mymodel.py:264-286)
@@ -510,17 +513,29 @@ __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __res
         }
         // transpose through LDS: lane l first holds pixel 4l+k (32 channels); it then writes chunk (l&7) of the
         // pixels 4*((l>>3)+8j)+k, so every store instruction covers 8 full 128-B lines
+        double ssum = 0.0, ssq = 0.0;                       // channel lane&31, pixel half lane>>5 of every 64-pixel run
 #pragma unroll
         for (int k = 0; k < PX; ++k) {
 #pragma unroll
             for (int o = 0; o < 8; ++o)
                 *reinterpret_cast<float4*>(tw + lane * 36 + o * 4) = make_float4(acc[k][2 * o].x, acc[k][2 * o].y, acc[k][2 * o + 1].x, acc[k][2 * o + 1].y);
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) {
+                const double v = (double)tw[((lane >> 5) * 32 + i) * 36 + (lane & 31)];
+                ssum += v; ssq += v * v;
+            }
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int pl = (lane >> 3) + 8 * jj;
                 const float4 v = *reinterpret_cast<const float4*>(tw + pl * 36 + (lane & 7) * 4);
                 *reinterpret_cast<float4*>(a1 + (base + (size_t)pl * PX + k) * 192 + q * 32 + (lane & 7) * 4) = v;
             }
+        }
+        ssum += rp_shfl_xor_d(ssum, 32); ssq += rp_shfl_xor_d(ssq, 32);
+        if (lane < 32) {
+            const size_t pass = base / (64 * PX);            // = group * C1_PASSES_PER_GROUP + pass in group
+            double* o = stat + (pass * 192 + q * 32 + lane) * 2;
+            o[0] = ssum; o[1] = ssq;
         }
     }
 }
@@ -656,6 +671,26 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nchun
     }
     const double mean = s / rows_per_group;
     double var = q / rows_per_group - mean * mean;       // biased variance (training-mode BN)
+    if (var < 0) var = 0;
+    const double sc = (double)gamma[c] / sqrt(var + BN_EPS);
+    ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
+}
+
+// Same, one wave per (channel, group) for long record lists (the 392 per-pass records of conv1): lane l adds records
+// l, l+64, ... in order, then a fixed xor tree.
+__global__ __launch_bounds__(64) void bn_finalize_wave_kernel(const double* __restrict__ partial, int nchunks, int C, int rows_per_group,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float2* __restrict__ ss) {
+    const int c = blockIdx.x, g = blockIdx.y;
+    double s = 0, q = 0;
+    for (int k = threadIdx.x; k < nchunks; k += 64) {
+        const double* p = partial + (((size_t)g * nchunks + k) * C + c) * 2;
+        s += p[0]; q += p[1];
+    }
+    s = rp_wave_sum(s); q = rp_wave_sum(q);
+    if (threadIdx.x) return;
+    const double mean = s / rows_per_group;
+    double var = q / rows_per_group - mean * mean;
     if (var < 0) var = 0;
     const double sc = (double)gamma[c] / sqrt(var + BN_EPS);
     ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
@@ -1012,7 +1047,7 @@ struct Builder {
     void stats(const std::string& b);
 };
 
-size_t partial_doubles(int G) { return (size_t)G * 64 * 1024 * 2; }
+size_t partial_doubles(int G) { return (size_t)G * std::max(64 * 1024 * 2, C1_PASSES_PER_GROUP * 192 * 2); }
 constexpr int MAX_DESCS = 256;
 
 void Builder::stats(const std::string& b) {
@@ -1162,6 +1197,7 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     // encoder, three modalities x two streams in concatenated buffers (mymodel.py:266-291)
     { Op o; o.type = OP_CONV1; o.first = o.count = o.cfg = 0; R.plan->ops.push_back(o); }   // direct kernel
     R.stats("A1");
+    R.plan->ops.back().cfg = 1;                   // partial records already written by conv1_direct_kernel
     R.begin_group();
     for (int q = 0; q < 6; ++q) R.conv(std::string("conv2") + mods[q / 2], R.src("A1", q * 32, 32), nullptr, 224, "A2", q * 64);
     R.end_group(); R.stats("A2");
@@ -1427,7 +1463,7 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         } else if (op.type == OP_CONV1) {
             mark(1);
             hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024, 6), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
-                               act + net->bufs["A1"].off * n, n);
+                               act + net->bufs["A1"].off * n, partial, n);
             mark(-1);
         } else if (op.type == OP_STATS_FUSED) {
             const Buf& B = net->bufs[op.buf];
@@ -1452,6 +1488,13 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         } else {
             const Buf& B = net->bufs[op.buf];
             const int rows = 2 * B.H * B.H;
+            if (op.cfg == 1) {                     // A1: finalise the per-pass records of conv1_direct_kernel
+                mark(2);
+                hipLaunchKernelGGL(bn_finalize_wave_kernel, dim3(B.C, G), dim3(64), 0, s, partial, C1_PASSES_PER_GROUP, B.C, rows,
+                                   net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
+                mark(-2);
+                continue;
+            }
             int nch = (2048 + G - 1) / G;
             if (nch > (rows + 63) / 64) nch = (rows + 63) / 64;
             if (nch > 64) nch = 64;
