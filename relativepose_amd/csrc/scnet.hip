@@ -443,16 +443,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __re
 constexpr int C1_PASSES_PER_GROUP = 2 * RS * RS / 256;      // 392
 __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __restrict__ x0, const float* __restrict__ w1,
                                                             float* __restrict__ a1, double* __restrict__ stat, int n) {
-    const int q = blockIdx.y;                        // block 2*m + s
-    const int m = q >> 1, sft = (q & 1) * 8;
-    // input channels of this block inside the 16-channel pixel (mymodel.py:264-286)
-    const int c0 = m == 0 ? sft + 0 : (m == 1 ? sft + 3 : sft + 6);
-    const int nch = m == 2 ? 2 : 4;                  // {rgb|n} + mask, or depth + mask
     const size_t total = (size_t)n * RS * RS;      // multiple of 256 (224*224 = 196*256): a wave's pass never straddles the end
-    __shared__ __attribute__((aligned(16))) float wl[9 * 4 * 32];      // this block's weights, read as LDS broadcasts
+    __shared__ __attribute__((aligned(16))) float wl[6 * 9 * 4 * 32];  // all six blocks' weights, read as LDS broadcasts
     __shared__ __attribute__((aligned(16))) float tile[4 * 64 * 36];
-    for (int i = threadIdx.x; i < 9 * 4 * 32; i += 256) wl[i] = w1[(size_t)q * 9 * 4 * 32 + i];
+    for (int i = threadIdx.x; i < 6 * 9 * 4 * 32; i += 256) wl[i] = w1[i];
     __syncthreads();
+    // The six (modality, stream) blocks q = 2*m + s of a pixel run are computed back to back by the SAME wave: the
+    // 16-channel input lines are fetched from HBM once (6 separate sweeps re-read X0 ~18x: 4.2 GB vs 0.2 GB, PMC)
+    // and a pixel's 768-byte output row is completed within one pass.
     // A wave takes 256 consecutive pixels per pass, lane l the 4 horizontal neighbours base + 4l .. 4l+3 (224 is a
     // multiple of 4: they share a row).  Per kernel row the lane fetches its 6 input columns ONCE (the 3x3 windows
     // of the 4 pixels overlap) and only the channel quads this block needs; every weight quad read from LDS (a
@@ -461,18 +459,32 @@ __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __res
     constexpr int PX = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tw = tile + wave * 64 * 36;
-    // quads of the 16-channel pixel that hold this block's inputs: A (first data quad) and B (second / mask quad)
-    const int qA = (m == 2 ? sft + 4 : sft), qB = sft + 4;
     for (size_t base = ((size_t)blockIdx.x * 4 + wave) * (64 * PX); base < total; base += (size_t)gridDim.x * 4 * (64 * PX)) {
-        rp_v2f acc[PX][16];
-#pragma unroll
-        for (int k = 0; k < PX; ++k)
-#pragma unroll
-            for (int o = 0; o < 16; ++o) acc[k][o] = (rp_v2f){0.f, 0.f};
         const size_t pix = base + lane * PX;             // first of the lane's 4 pixels
         const int x = (int)(pix % RS), y = (int)((pix / RS) % RS);
+        rp_v2f acc[PX][16];
+        float nx[PX + 2][4];                             // the 4 input channels of the 6 columns of the NEXT (q, ty) step
+        // Software pipeline over the 18 (block q, kernel row ty) steps: the loads of step it+1 are in flight while
+        // step it runs its 768 packed FMAs (two waves per SIMD cannot hide an HBM round trip per step otherwise).
+        // Only the channels the block needs are loaded: {rgb|n}: 3 + mask, depth: 1 + mask (mymodel.py:264-286).
+#define RP_C1_LOAD(IT)                                                                                           \
+        {                                                                                                        \
+            const int q_ = (IT) / 3, ty_ = (IT) - q_ * 3, m_ = q_ >> 1, sft_ = (q_ & 1) * 8;                     \
+            const int iy_ = y + ty_ - 1;                                                                         \
+            const bool oky_ = (iy_ >= 0) & (iy_ < RS);                                                           \
+            _Pragma("unroll") for (int cx = 0; cx < PX + 2; ++cx) {                                              \
+                const int ix_ = x + cx - 1;                                                                      \
+                const bool ok_ = oky_ & (ix_ >= 0) & (ix_ < RS);                                                 \
+                const float* p_ = x0 + (pix + (ok_ ? (ptrdiff_t)(ty_ - 1) * RS + (cx - 1) : 0)) * 16 + sft_;     \
+                if (m_ == 0) { nx[cx][0] = p_[0]; nx[cx][1] = p_[1]; nx[cx][2] = p_[2]; nx[cx][3] = p_[7]; }     \
+                else if (m_ == 1) { nx[cx][0] = p_[3]; nx[cx][1] = p_[4]; nx[cx][2] = p_[5]; nx[cx][3] = p_[7]; } \
+                else { nx[cx][0] = p_[6]; nx[cx][1] = p_[7]; nx[cx][2] = 0.f; nx[cx][3] = 0.f; }                 \
+            }                                                                                                    \
+        }
+        RP_C1_LOAD(0)
 #pragma unroll 1
-        for (int ty = 0; ty < 3; ++ty) {
+        for (int it = 0; it < 18; ++it) {
+            const int q = it / 3, ty = it - q * 3;           // block q = 2*modality + stream
             const int iy = y + ty - 1;
             const bool oky = (iy >= 0) & (iy < RS);
             float in[PX + 2][4];
@@ -480,16 +492,15 @@ __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __res
             for (int cx = 0; cx < PX + 2; ++cx) {
                 const int ix = x + cx - 1;
                 const bool ok = oky & (ix >= 0) & (ix < RS);
-                const float* p = x0 + (pix + (ok ? (ptrdiff_t)(ty - 1) * RS + (cx - 1) : 0)) * 16;
-                const float4 a = *reinterpret_cast<const float4*>(p + qA);
-                float4 b = a;
-                if (m != 2) b = *reinterpret_cast<const float4*>(p + qB);        // block-uniform
-                // block-uniform channel selection (mymodel.py:264-286): {rgb|n} + mask, or depth + mask
-                if (m == 0) { in[cx][0] = a.x; in[cx][1] = a.y; in[cx][2] = a.z; in[cx][3] = b.w; }
-                else if (m == 1) { in[cx][0] = a.w; in[cx][1] = b.x; in[cx][2] = b.y; in[cx][3] = b.w; }
-                else { in[cx][0] = a.z; in[cx][1] = a.w; in[cx][2] = 0.f; in[cx][3] = 0.f; }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) in[cx][c] = ok ? in[cx][c] : 0.f;       // zero padding
+                for (int c = 0; c < 4; ++c) in[cx][c] = ok ? nx[cx][c] : 0.f;       // zero padding
+            }
+            if (it + 1 < 18) RP_C1_LOAD(it + 1)
+            if (ty == 0) {
+#pragma unroll
+                for (int k = 0; k < PX; ++k)
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) acc[k][o] = (rp_v2f){0.f, 0.f};
             }
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx)
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __res
                     rp_v2f vv[PX];
 #pragma unroll
                     for (int k = 0; k < PX; ++k) vv[k] = (rp_v2f){in[k + tx][c], in[k + tx][c]};
-                    const float* wrow = &wl[((ty * 3 + tx) * 4 + c) * 32];
+                    const float* wrow = &wl[((it * 3 + tx) * 4 + c) * 32];      // [q][ty][tx][c][32 out]
 #pragma unroll
                     for (int o4 = 0; o4 < 8; ++o4) {
                         const float4 wv = *reinterpret_cast<const float4*>(wrow + o4 * 4);   // wave-uniform address
@@ -510,33 +521,35 @@ __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __res
                         }
                     }
                 }
-        }
-        // transpose through LDS: lane l first holds pixel 4l+k (32 channels); it then writes chunk (l&7) of the
-        // pixels 4*((l>>3)+8j)+k, so every store instruction covers 8 full 128-B lines
-        double ssum = 0.0, ssq = 0.0;                       // channel lane&31, pixel half lane>>5 of every 64-pixel run
+            if (ty != 2) continue;
+            // block q done.  Transpose through LDS: lane l first holds pixel 4l+k (32 channels); it then writes chunk
+            // (l&7) of the pixels 4*((l>>3)+8j)+k, so every store instruction covers 8 full 128-B lines
+            double ssum = 0.0, ssq = 0.0;                   // channel lane&31, pixel half lane>>5 of every 64-pixel run
 #pragma unroll
-        for (int k = 0; k < PX; ++k) {
+            for (int k = 0; k < PX; ++k) {
 #pragma unroll
-            for (int o = 0; o < 8; ++o)
-                *reinterpret_cast<float4*>(tw + lane * 36 + o * 4) = make_float4(acc[k][2 * o].x, acc[k][2 * o].y, acc[k][2 * o + 1].x, acc[k][2 * o + 1].y);
+                for (int o = 0; o < 8; ++o)
+                    *reinterpret_cast<float4*>(tw + lane * 36 + o * 4) = make_float4(acc[k][2 * o].x, acc[k][2 * o].y, acc[k][2 * o + 1].x, acc[k][2 * o + 1].y);
 #pragma unroll 8
-            for (int i = 0; i < 32; ++i) {
-                const double v = (double)tw[((lane >> 5) * 32 + i) * 36 + (lane & 31)];
-                ssum += v; ssq += v * v;
-            }
+                for (int i = 0; i < 32; ++i) {
+                    const double v = (double)tw[((lane >> 5) * 32 + i) * 36 + (lane & 31)];
+                    ssum += v; ssq += v * v;
+                }
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int pl = (lane >> 3) + 8 * jj;
-                const float4 v = *reinterpret_cast<const float4*>(tw + pl * 36 + (lane & 7) * 4);
-                *reinterpret_cast<float4*>(a1 + (base + (size_t)pl * PX + k) * 192 + q * 32 + (lane & 7) * 4) = v;
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int pl = (lane >> 3) + 8 * jj;
+                    const float4 v = *reinterpret_cast<const float4*>(tw + pl * 36 + (lane & 7) * 4);
+                    *reinterpret_cast<float4*>(a1 + (base + (size_t)pl * PX + k) * 192 + q * 32 + (lane & 7) * 4) = v;
+                }
+            }
+            ssum += rp_shfl_xor_d(ssum, 32); ssq += rp_shfl_xor_d(ssq, 32);
+            if (lane < 32) {
+                const size_t pass = base / (64 * PX);        // = group * C1_PASSES_PER_GROUP + pass in group
+                double* o = stat + (pass * 192 + q * 32 + lane) * 2;
+                o[0] = ssum; o[1] = ssq;
             }
         }
-        ssum += rp_shfl_xor_d(ssum, 32); ssq += rp_shfl_xor_d(ssq, 32);
-        if (lane < 32) {
-            const size_t pass = base / (64 * PX);            // = group * C1_PASSES_PER_GROUP + pass in group
-            double* o = stat + (pass * 192 + q * 32 + lane) * 2;
-            o[0] = ssum; o[1] = ssq;
-        }
+#undef RP_C1_LOAD
     }
 }
 
@@ -1462,7 +1475,7 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             mark(-1);
         } else if (op.type == OP_CONV1) {
             mark(1);
-            hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024, 6), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
+            hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                act + net->bufs["A1"].off * n, partial, n);
             mark(-1);
         } else if (op.type == OP_STATS_FUSED) {
