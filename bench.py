@@ -7,7 +7,9 @@ spectral-match), 160x640 RGB-D.  One "step" = one pass of the whole hot path
 synthetic scan pairs already resident in HBM.  Workload at N GPUs:
 BASELINE.json configs[1] per GPU -- SUNCG conventions, 160x640, 200 keypoints per
 view, 32 pairs per GPU (weak scaling: pairs shard across ranks, no data-path
-collective, one RCCL all_gather of the 4x4 poses per step).
+collective, one RCCL all_gather of the 4x4 poses per step).  Two steps are in flight
+(--inflight 2): the launch-bound matcher phase of step k runs under the SCNet forward of step k+1
+(pipeline.run_pipelined); every step still does the complete path on its own 32 pairs.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -152,7 +154,7 @@ def main():
                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                            # HBM bytes of the conv stack per forward: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
                            # FETCH doubled per the gfx950 correction) of tools/scnet_only.py at this batch: profiles/r01_scnet_hbm_pmc.txt
-                           "traffic": 74.9e9 if B == 32 else None, "traffic_unit": "bytes per forward (all conv launches)",
+                           "traffic": 75.4e9 if B == 32 else None, "traffic_unit": "bytes per forward (all conv launches)",
                            "launches_per_forward": int(n_gemm), "ms_per_forward_gemm": g_ms, "ms_per_forward_other": o_ms,
                            "algorithmic_gflop_per_forward": flops / 1e9}
         # --- N x N affinity build (materialised fp32 wij), the kernel the HBM target is stated on
