@@ -71,6 +71,7 @@ struct ConvDesc {
     int tanh_out;
     int M, K;
     int ksplit, kt_per;    // split-K: slices along K and k-tiles per slice (ksplit==1: direct store)
+    int tap_inner;         // K order of the main loop: 1 = channel chunk outer / tap inner, 0 = tap outer
     int ntiles_n;          // N tiles (grid.y = ntiles_n * ksplit)
     float* partial;        // [ksplit][M][CoutPad] partial sums when ksplit > 1
     double* stat_part;     // [mtiles][2 group slots][CoutPad][2] per-tile BatchNorm partial sums (or null)
@@ -85,7 +86,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (SSLDS ? 3 : 2)) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLDS ? 3 : 2)) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
     // ninner == 4 (the sub-pixel phases of one transposed conv, which gather from the SAME input tile):
@@ -182,7 +183,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (SSLDS ? 3 : 2))
     const float slope = d.src[0].slope;                 // both sources of a skip concatenation use LeakyReLU(0.1)
     const int kt_begin = ks * d.kt_per;
     const int nkt = min(d.K / BK, kt_begin + d.kt_per);
-    int tap = (kt_begin * BK) / d.Cin, c0 = kt_begin * BK - tap * d.Cin;
+    // K order of the loop: channel chunk outer, TAP INNER -- the 2x2 / 4x4 taps of one 32-channel chunk touch the same
+    // 128-byte lines (neighbouring pixels) in consecutive k-tiles, so they hit in L2; tap-major order re-read every
+    // line Cin/32 k-tiles later, after the other workgroups of the XCD had flushed the 4 MB L2 (16x HBM re-fetch on
+    // deconv2, PMC).  The weight rows stay [tap][Cin].
+    const int cpt = d.Cin / BK;                         // channel chunks per tap
+    int tap = d.tap_inner ? kt_begin % d.ntaps : kt_begin / cpt, c0 = (d.tap_inner ? kt_begin / d.ntaps : kt_begin % cpt) * BK;
     __syncthreads();       // tapdelta / rowpix / sstab / rtab visible
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -216,12 +222,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8) ? 4 : (SSLDS ? 3 : 2))
             const float* q = reinterpret_cast<const float*>(sss_ + (size_t)g0 * sst_ + cc_);                      \
             qu0 = rp_ldg4(q); qu1 = rp_ldg4(q + 4);                                                               \
         }                                                                                                         \
-        rb0 = rp_ldg4(b_src[0] + (size_t)(KT) * BK);                                                              \
-        if (B_IT > 1) rb1 = rp_ldg4(b_src[B_IT > 1 ? 1 : 0] + (size_t)(KT) * BK);                                   \
-        if (B_IT > 2) rb2 = rp_ldg4(b_src[B_IT > 2 ? 2 : 0] + (size_t)(KT) * BK);                                   \
-        if (B_IT > 3) rb3 = rp_ldg4(b_src[B_IT > 3 ? 3 : 0] + (size_t)(KT) * BK);                                   \
-        c0 += BK;                                                                                                 \
-        if (c0 == d.Cin) { c0 = 0; ++tap; }                                                                       \
+        const int kof_ = tap * d.Cin + c0;                                                                        \
+        rb0 = rp_ldg4(b_src[0] + kof_);                                                                           \
+        if (B_IT > 1) rb1 = rp_ldg4(b_src[B_IT > 1 ? 1 : 0] + kof_);                                                \
+        if (B_IT > 2) rb2 = rp_ldg4(b_src[B_IT > 2 ? 2 : 0] + kof_);                                                \
+        if (B_IT > 3) rb3 = rp_ldg4(b_src[B_IT > 3 ? 3 : 0] + kof_);                                                \
+        if (d.tap_inner) { ++tap; if (tap == d.ntaps) { tap = 0; c0 += BK; } }                                    \
+        else { c0 += BK; if (c0 == d.Cin) { c0 = 0; ++tap; } }                                                    \
     }
 
 #define RP_STORE_TILE(BUF)                                                                                        \
@@ -1113,6 +1120,10 @@ void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, con
         d.tanh_out = (L.kind == 2 && layer == "deconv1f" && net->use_tanh) ? 1 : 0;
         d.M = n * d.Hp * d.Wp; d.K = P.K;
         d.ksplit = 1; d.kt_per = d.K / BK; d.partial = nullptr;
+        {   // K order: tap-inner for the 2x2-tap phases of transposed convs (RELPOSE_TAP_INNER=0 none / 2 every conv: experiments)
+            static const int ti = getenv("RELPOSE_TAP_INNER") ? atoi(getenv("RELPOSE_TAP_INNER")) : 1;
+            d.tap_inner = (ti == 2 || (ti == 1 && d.osy == 2)) ? 1 : 0;
+        }
         if (d.K != d.ntaps * d.Cin || d.Cin % BK || (s1 && s0.C % BK)) { rc = RELPOSE_EINVAL; return; }
         plan->descs.push_back(d);
     }
@@ -1130,8 +1141,9 @@ void Builder::end_group() {
     for (int i = first; i < first + count; ++i) big_m = std::max(big_m, plan->descs[i].M / n * 64);   // at the nominal batch
     // tile configs: 0 = 128x128 (4 waves), 3 = 256x128 (8 waves, 4 waves/SIMD at 2 blocks/CU), 1 = 256x64, 2 = 256x32
     // (3 measured within 1 % of 0 on conv3/conv4/deconv4-6 but needs twice the split-K: off unless RELPOSE_8WAVE is set)
-    const int cfg = cp >= 128 ? ((big_m >= 8192 && getenv("RELPOSE_8WAVE")) ? 3 : 0) : (cp == 64 ? 1 : 2);
-    const int BMt = cfg == 0 ? 128 : 256, BNt = (cfg == 0 || cfg == 3) ? 128 : cp;
+    static const bool tile128 = getenv("RELPOSE_TILE128") != nullptr;      // experiment: 128-row tiles, 4 workgroups per CU
+    const int cfg = cp >= 128 ? ((big_m >= 8192 && getenv("RELPOSE_8WAVE")) ? 3 : 0) : (cp == 64 ? (tile128 ? 4 : 1) : (tile128 ? 5 : 2));
+    const int BMt = (cfg == 0 || cfg >= 4) ? 128 : 256, BNt = (cfg == 0 || cfg == 3) ? 128 : cp;
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
     for (int i = first; i < first + count; ++i) {
@@ -1178,9 +1190,10 @@ void Builder::end_group() {
         for (int i = first; i < first + count; i += 4)
             for (int k = 1; k < 4; ++k)
                 ph = ph && plan->descs[i + k].src[0].x == plan->descs[i].src[0].x && plan->descs[i + k].osy == 2 && plan->descs[i].osy == 2;
-        // measured neutral on deconv2/deconv3 (their re-reads are already served on-chip) and slightly negative on
-        // the small layers (grid padded to 8 tiles), so phase interleaving stays off: profiles/r01_*.txt
-        if (ph && getenv("RELPOSE_PHASE_INTERLEAVE")) o.ninner = 4;
+        // the 4 phase tiles of one spatial tile run back to back on the same XCD and share their input lines in its
+        // L2 (deconv2: -10 %, deconv3: -2 %); small layers lose to the grid padding (8 tiles), so only above 512 tiles
+        static const bool no_pi = getenv("RELPOSE_NO_PHASE_INTERLEAVE") != nullptr;
+        if (ph && !no_pi && max_mt >= 512) o.ninner = 4;
     }
     o.grid = (o.ninner == 1) ? dim3(max_mt * count, (cp / BNt) * ksplit, 1)
                              : dim3(((max_mt + 7) / 8) * 8 * count, (cp / BNt) * ksplit, 1);
@@ -1459,6 +1472,11 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             if (op.cfg == 3) {
                 if (op.sslds) hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, true>), op.grid, dim3(512), 0, s, dd, op.ninner, op.mt_max);
                 else hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, false>), op.grid, dim3(512), 0, s, dd, op.ninner, op.mt_max);
+            } else if (op.cfg >= 4 && op.sslds) {
+                if (op.cfg == 4 && op.uni) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 2, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else if (op.cfg == 4) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 2, true, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else if (op.uni) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
+                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, true, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
             } else if (op.uni) {
                 if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
                 else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
