@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
         b_src[it] = d.w + (size_t)(n0 + row) * d.K + kq * 4;
     }
 
-    int r_base[A_IT], r_mg[A_IT];
+    int r_base[A_IT], r_mg[UNI ? (A_IT + 1) / 2 : A_IT];     // UNI: no group field, two 16-bit tap masks per register
     float4 ra[A_IT], q0[SSLDS ? 1 : A_IT], q1[SSLDS ? 1 : A_IT];
     float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
     static_assert(B_IT <= 4 && (B_IT <= 2 || BN % RPI == 0), "B loader layout");
@@ -193,7 +193,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int2 e = *reinterpret_cast<const int2*>(&rtab[2 * (lrow + it * RPI)]);
-        r_base[it] = e.x; r_mg[it] = e.y;
+        r_base[it] = e.x;
+        if (!UNI) r_mg[UNI ? 0 : it] = e.y;
+        else if (it & 1) r_mg[it >> 1] |= e.y << 16;
+        else r_mg[it >> 1] = e.y & 0xffff;
     }
 
 #define RP_ISSUE_LOADS(KT)                                                                                        \
@@ -205,14 +208,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
         const int td_ = tapdelta[tap];                                                                            \
         okm = 0; cst = c0 + kq * 4;                                                                               \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                     \
-            const bool ok_ = (r_mg[it] >> tap) & 1;                                                               \
+            const bool ok_ = UNI ? ((r_mg[it >> 1] >> (tap + 16 * (it & 1))) & 1) : ((r_mg[UNI ? 0 : it] >> tap) & 1);                                                             \
             okm |= ok_ ? (1 << it) : 0;                                                                           \
             const int pix_ = (RP_ABLATE == 6) ? (it * 8) : (RP_ABLATE == 7) ? ((r_base[it] + td_) & 0xfff) : ok_ ? r_base[it] + td_ : 0;   \
             ra[it] = rp_ldg4(sx_ + (size_t)pix_ * scs_ + cc_);                                                    \
             if (!SSLDS && !UNI) {                                                                                 \
                 const float2* sss_ = s1_ ? d.src[1].ss : d.src[0].ss;                                             \
                 const int sst_ = s1_ ? d.src[1].sstride : d.src[0].sstride;                                       \
-                const float* q = reinterpret_cast<const float*>(sss_ + (size_t)(r_mg[it] >> 16) * sst_ + cc_);      \
+                const float* q = reinterpret_cast<const float*>(sss_ + (size_t)(r_mg[UNI ? 0 : it] >> 16) * sst_ + cc_);      \
                 q0[SSLDS ? 0 : it] = rp_ldg4(q); q1[SSLDS ? 0 : it] = rp_ldg4(q + 4);                             \
             }                                                                                                     \
         }                                                                                                         \
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
             float4 s0_, s1v_;                                                                                     \
             if (UNI) { s0_ = u0_; s1v_ = u1_; }                                                                   \
             else if (SSLDS) {                                                                                     \
-                const float4* q = reinterpret_cast<const float4*>(&sstab[2 * ((r_mg[it] >> 16) + cst)]);          \
+                const float4* q = reinterpret_cast<const float4*>(&sstab[2 * ((r_mg[UNI ? 0 : it] >> 16) + cst)]);          \
                 s0_ = q[0]; s1v_ = q[1];                                                                          \
             } else {                                                                                              \
                 const float4 a_ = q0[SSLDS ? 0 : it], b_ = q1[SSLDS ? 0 : it];                                    \
