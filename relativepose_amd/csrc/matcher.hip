@@ -513,13 +513,17 @@ __global__ __launch_bounds__(256) void eig_init_kernel(RelposeKeypoints kp, Grap
 }
 
 // a = base*(h[c]+h[cc]) (rpmodule.py:262-267 summed over the two halves); base = w, or mu*x for 'spectral' rounds > 0
-__global__ __launch_bounds__(256) void eig_spmv_kernel(RelposeKeypoints kp, Graph g, FitState fs, double mu_xe,
+#ifndef RP_SPMV_THREADS
+#define RP_SPMV_THREADS 256     // 16 rows per workgroup (64- and 1024-thread workgroups measured slower next to the conv stream)
+#endif
+#define RP_SPMV_ROWS (RP_SPMV_THREADS / 16)
+__global__ __launch_bounds__(RP_SPMV_THREADS) void eig_spmv_kernel(RelposeKeypoints kp, Graph g, FitState fs, double mu_xe,
                                                         const int32_t* __restrict__ status, int src_sel, int dst_sel, int want_norm) {
-    __shared__ double wsum[4];
+    __shared__ double wsum[RP_SPMV_THREADS / 64];
     const int b = blockIdx.y;
     const int C = g.pairC[b];
     if (C == 0 || fs.done[b]) return;
-    if (blockIdx.x * 16 >= C) return;
+    if (blockIdx.x * RP_SPMV_ROWS >= C) return;
     const size_t eoff = (size_t)b * g.max_edges;
     const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
     // buffers: 0 = u (unit vector, kept for the convergence test), 1 = y2, 2 = y (the one eig_norm reads)
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(256) void eig_spmv_kernel(RelposeKeypoints kp, Grap
     double* yo = (dst_sel == 1 ? fs.y2 : fs.y) + (size_t)b * g.Cmax;
     const double* h = fs.h + (size_t)b * g.Cmax;
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + grp;
+    const int c = blockIdx.x * RP_SPMV_ROWS + grp;
     double s = 0.0;
     if (c < C) {
         const double hc = h[c];
@@ -546,7 +550,12 @@ __global__ __launch_bounds__(256) void eig_spmv_kernel(RelposeKeypoints kp, Grap
     q += rp_shfl_xor_d(q, 16); q += rp_shfl_xor_d(q, 32);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = q;
     __syncthreads();
-    if (threadIdx.x == 0) fs.part[(size_t)b * fs.nblk + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) {
+        double t;
+        if (RP_SPMV_THREADS == 256) t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        else { t = 0.0; for (int w = 0; w < RP_SPMV_THREADS / 64; ++w) t += wsum[w]; }
+        fs.part[(size_t)b * fs.nblk + blockIdx.x] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void eig_norm_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status) {
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(256) void eig_norm_kernel(RelposeKeypoints kp, Grap
     const int b = blockIdx.x;
     const int C = g.pairC[b];
     if (C == 0 || fs.done[b]) return;
-    const int nb = (C + 15) / 16;
+    const int nb = (C + RP_SPMV_ROWS - 1) / RP_SPMV_ROWS;
     double a[1] = {0.0};
     for (int i = threadIdx.x; i < nb; i += blockDim.x) a[0] += fs.part[(size_t)b * fs.nblk + i];
     rp_block_sum<1>(a, red);
@@ -673,7 +682,7 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.state = take((size_t)B * 4 * L.Cmax * 8);
     L.geo = take((size_t)B * L.Cmax * 12 * 8);
     L.pairC = take((size_t)B * 4);
-    L.eig = take((size_t)B * (4 * (size_t)L.Cmax + (L.Cmax + 15) / 16) * 8 + (size_t)B * 2 * 4);
+    L.eig = take((size_t)B * (4 * (size_t)L.Cmax + (L.Cmax + RP_SPMV_ROWS - 1) / RP_SPMV_ROWS) * 8 + (size_t)B * 2 * 4);
     L.total = o;
     return L;
 }
@@ -733,14 +742,14 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     RP_CHECK_LAUNCH();
     // ---- fit: launch sequence (see fit_begin_kernel)
     FitState fs;
-    fs.nblk = (L.Cmax + 15) / 16;
+    fs.nblk = (L.Cmax + RP_SPMV_ROWS - 1) / RP_SPMV_ROWS;
     fs.u = (double*)(ws + L.eig); fs.y = fs.u + (size_t)kp->B * L.Cmax; fs.y2 = fs.y + (size_t)kp->B * L.Cmax;
     fs.h = fs.y2 + (size_t)kp->B * L.Cmax;
     fs.part = fs.h + (size_t)kp->B * L.Cmax;
     fs.done = (int32_t*)(fs.part + (size_t)kp->B * fs.nblk); fs.iters = fs.done + kp->B;
     double* trace = dbg ? dbg->trace : nullptr;
     int32_t* eig_iters = dbg ? dbg->eig_iters : nullptr;
-    dim3 grid16(fs.nblk, kp->B);
+    dim3 grid16((L.Cmax + 15) / 16, kp->B);
     hipLaunchKernelGGL(fit_begin_kernel, grid16, dim3(256), 0, s, *kp, g, p->topK, status, pose, trace, dbg ? dbg->counts : nullptr);
     hipLaunchKernelGGL(fit_commit_status_kernel, dim3((kp->B + 63) / 64), dim3(64), 0, s, *kp, g, status, kp->B);
     RP_CHECK_LAUNCH();
@@ -759,7 +768,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
                 const int j = it % RP_EIG_NORM_EVERY;
                 const int src = (j == 0) ? 0 : ((j & 1) ? 1 : 2), dst = (j & 1) ? 2 : 1;
                 const bool last = (j == RP_EIG_NORM_EVERY - 1);
-                hipLaunchKernelGGL(eig_spmv_kernel, grid16, dim3(256), 0, s, *kp, g, fs, mu_xe, status, src, dst, last ? 1 : 0);
+                hipLaunchKernelGGL(eig_spmv_kernel, dim3(fs.nblk, kp->B), dim3(RP_SPMV_THREADS), 0, s, *kp, g, fs, mu_xe, status, src, dst, last ? 1 : 0);
                 if (last) hipLaunchKernelGGL(eig_norm_kernel, dim3(kp->B), dim3(256), 0, s, *kp, g, fs, status);
             }
             hipLaunchKernelGGL(eig_finish_kernel, grid16, dim3(256), 0, s, *kp, g, fs, status, eig_iters ? eig_iters + round : nullptr);
