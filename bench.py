@@ -178,7 +178,7 @@ def main():
         res["roofline_affinity"] = {"kernel": "affinity_topk_kernel<true>", "bound": "hbm", "achieved": abytes / (a_ms * 1e-3) / 1e9,
                                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": abytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                     "traffic": None, "ms_per_launch": a_ms, "algorithmic_bytes_per_launch": abytes,
-                                    "note": "event pair around one launch incl. launch latency; batch is 6.8 MB so the launch is latency-bound"}
+                                    "note": "event pair around one launch incl. launch latency; the kernel is f64-VALU-bound (ocml exp per entry, numpy-order f32 distance for bit-exact top-K) and saturates at ~155 GB/s at any batch: profiles/r01_affinity_scaling.txt"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, data, pts, ptw, S)
         print(json.dumps(res), flush=True)
