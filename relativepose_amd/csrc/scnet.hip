@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
     constexpr int RPI = NT / KQ;                        // tile rows covered per loader iteration
     constexpr int A_IT = BM / RPI;                      // float4 slots per thread for the A tile
     constexpr int B_IT = (BN + RPI - 1) / RPI;
-    constexpr int SS_CAP = (WN == 2) ? 1024 : 512;      // float2 entries of the LDS scale/shift table (8 / 4 KB: keeps 3 blocks per CU)
+    constexpr int SS_CAP = (WN == 2) ? 2048 : 512;      // float2 entries of the LDS scale/shift table (16 / 4 KB: still 3 blocks per CU)
     __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDK];
     __shared__ __attribute__((aligned(16))) float sstab[SSLDS ? 2 * SS_CAP : 8];   // per 4 channels: 4 scales, then 4 shifts
@@ -1206,7 +1206,7 @@ void Builder::end_group() {
         const ConvDesc& d = plan->descs[i];
         const int hw = d.Hp * d.Wp;
         const int ng = (BMt - 1) / (2 * hw) + 2;
-        if ((long)ng * d.Cin > ((cfg == 0 || cfg == 3) ? 1024 : 512) || d.src[0].sstride == 0) o.sslds = 0;
+        if ((long)ng * d.Cin > ((cfg == 0 || cfg == 3) ? 2048 : 512) || d.src[0].sstride == 0) o.sslds = 0;
         if ((2 * hw) % BMt) o.uni = 0;             // some tile would straddle two BatchNorm groups
     }
     if (!o.sslds) o.uni = 0;
