@@ -1145,7 +1145,17 @@ void Builder::end_group() {
     // tile configs: 0 = 128x128 (4 waves), 3 = 256x128 (8 waves, 4 waves/SIMD at 2 blocks/CU), 1 = 256x64, 2 = 256x32
     // (3 measured within 1 % of 0 on conv3/conv4/deconv4-6 but needs twice the split-K: off unless RELPOSE_8WAVE is set)
     static const bool tile128 = getenv("RELPOSE_TILE128") != nullptr;      // experiment: 128-row tiles, 4 workgroups per CU
-    const int cfg = cp >= 128 ? ((big_m >= 8192 && getenv("RELPOSE_8WAVE")) ? 3 : 0) : (cp == 64 ? (tile128 ? 4 : 1) : (tile128 ? 5 : 2));
+    int cfg = cp >= 128 ? ((big_m >= 8192 && getenv("RELPOSE_8WAVE")) ? 3 : 0) : (cp == 64 ? (tile128 ? 4 : 1) : (tile128 ? 5 : 2));
+    {   // 256-row tiles that would straddle BatchNorm groups where 128-row tiles would not: take the 128-row variant
+        // (same throughput per tile shape, but it gets the uniform-group loader)
+        static const bool no_auto128 = getenv("RELPOSE_NO_AUTO128") != nullptr;
+        bool u256 = true, u128 = true;
+        for (int i = first; i < first + count; ++i) {
+            const int rows = 2 * plan->descs[i].Hp * plan->descs[i].Wp;
+            u256 = u256 && rows % 256 == 0; u128 = u128 && rows % 128 == 0;
+        }
+        if (!no_auto128 && !u256 && u128 && (cfg == 1 || cfg == 2)) cfg = cfg == 1 ? 4 : 5;
+    }
     const int BMt = (cfg == 0 || cfg >= 4) ? 128 : 256, BNt = (cfg == 0 || cfg == 3) ? 128 : cp;
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
