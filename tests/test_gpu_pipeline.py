@@ -146,3 +146,32 @@ def test_pipeline_interleaved_streams_equal_single_stream():
         torch.cuda.synchronize()
         assert torch.equal(torch.cat([r[0] for r in res]), pose)
         assert torch.equal(torch.cat([r[1] for r in res]), status)
+
+
+def test_pipeline_batches_in_flight_equal_sequential_runs():
+    """run_pipelined (the bench's serving loop: consecutive batches, two in flight, SCNet forwards chained on a dedicated
+    stream, matcher of batch k under the forward of batch k+1) returns bitwise what `run` returns batch by batch,
+    in order, through on_result as well."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, mm, S, tanh = "suncg", "second", 15, 1
+    net = _gpu_net(S, tanh, E2E_WEIGHT_SEED)
+    pipe = RelativePosePipeline(net, ds, mm)
+    states, want = [], []
+    for j in range(2):
+        d = synth.make_pairs(3, 1300 + 10 * j, ds)
+        pts, ptw = synth.make_keypoints(3, 60, 1300 + 10 * j, mm)
+        st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+        pose, status, _ = pipe.run(st)
+        states.append(st); want.append((pose.clone(), status.clone()))
+    torch.cuda.synchronize()
+    seen = []
+    res = pipe.run_pipelined(states, 5, on_result=lambda k, pose, status: (seen.append(k), (pose.clone(), status.clone()))[1])
+    torch.cuda.synchronize()
+    assert seen == [0, 1, 2, 3, 4]
+    for k, (pose, status) in enumerate(res):
+        assert torch.equal(pose, want[k % 2][0]) and torch.equal(status, want[k % 2][1]), k
+    res = pipe.run_pipelined(states[:1], 2)                     # depth 1: plain sequential path
+    torch.cuda.synchronize()
+    assert all(torch.equal(r[0], want[0][0]) for r in res)
