@@ -154,7 +154,7 @@ def main():
                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                            # HBM bytes of the conv stack per forward: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
                            # FETCH doubled per the gfx950 correction) of tools/scnet_only.py at this batch: profiles/r01_scnet_hbm_pmc.txt
-                           "traffic": 38.9e9 if B == 32 else None, "traffic_unit": "bytes per forward (all conv launches)",
+                           "traffic": 38.2e9 if B == 32 else None, "traffic_unit": "bytes per forward (all conv launches)",
                            "launches_per_forward": int(n_gemm), "ms_per_forward_gemm": g_ms, "ms_per_forward_other": o_ms,
                            "algorithmic_gflop_per_forward": flops / 1e9}
         # --- N x N affinity build (materialised fp32 wij), the kernel the HBM target is stated on
