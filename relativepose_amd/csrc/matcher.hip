@@ -516,7 +516,10 @@ __global__ __launch_bounds__(256) void eig_init_kernel(RelposeKeypoints kp, Grap
 #ifndef RP_SPMV_THREADS
 #define RP_SPMV_THREADS 256     // 16 rows per workgroup (64- and 1024-thread workgroups measured slower next to the conv stream)
 #endif
-#define RP_SPMV_ROWS (RP_SPMV_THREADS / 16)
+#ifndef RP_SPMV_LPR
+#define RP_SPMV_LPR 16          // lanes per CSR row
+#endif
+#define RP_SPMV_ROWS (RP_SPMV_THREADS / RP_SPMV_LPR)
 __global__ __launch_bounds__(RP_SPMV_THREADS) void eig_spmv_kernel(RelposeKeypoints kp, Graph g, FitState fs, double mu_xe,
                                                         const int32_t* __restrict__ status, int src_sel, int dst_sel, int want_norm) {
     __shared__ double wsum[RP_SPMV_THREADS / 64];
@@ -530,24 +533,25 @@ __global__ __launch_bounds__(RP_SPMV_THREADS) void eig_spmv_kernel(RelposeKeypoi
     const double* u = (src_sel == 0 ? fs.u : src_sel == 1 ? fs.y2 : fs.y) + (size_t)b * g.Cmax;
     double* yo = (dst_sel == 1 ? fs.y2 : fs.y) + (size_t)b * g.Cmax;
     const double* h = fs.h + (size_t)b * g.Cmax;
-    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    const int grp = threadIdx.x / RP_SPMV_LPR, gl = threadIdx.x % RP_SPMV_LPR;
     const int c = blockIdx.x * RP_SPMV_ROWS + grp;
     double s = 0.0;
     if (c < C) {
         const double hc = h[c];
-        for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) {
+        for (int k = rp[c] + gl; k < rp[c + 1]; k += RP_SPMV_LPR) {
             const int cc = g.col[eoff + k];
             const double base = mu_xe != 0.0 ? mu_xe * g.xe[eoff + k] : g.wv[eoff + k];
             s += (base * (hc + h[cc])) * u[cc];
         }
     }
 #pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
+    for (int m = RP_SPMV_LPR / 2; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
     if (c < C && gl == 0) yo[c] = s;
     if (!want_norm) return;
     // per-block sum of squares (fixed order: 4 rows per wave via lanes 0,16,32,48; then 4 waves)
     double q = (gl == 0 && c < C) ? s * s : 0.0;
-    q += rp_shfl_xor_d(q, 16); q += rp_shfl_xor_d(q, 32);
+#pragma unroll
+    for (int m = RP_SPMV_LPR; m < 64; m <<= 1) q += rp_shfl_xor_d(q, m);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = q;
     __syncthreads();
     if (threadIdx.x == 0) {
