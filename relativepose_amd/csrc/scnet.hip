@@ -1322,9 +1322,9 @@ RelposeSCNet* relpose_scnet_create(int32_t snumclass, int32_t use_tanh) {
 
 void relpose_scnet_destroy(RelposeSCNet* net) {
     if (!net) return;
-    if (net->d_w) hipFree(net->d_w);
-    if (net->d_gb) hipFree(net->d_gb);
-    if (net->d_ident) hipFree(net->d_ident);
+    if (net->d_w) (void)hipFree(net->d_w);
+    if (net->d_gb) (void)hipFree(net->d_gb);
+    if (net->d_ident) (void)hipFree(net->d_ident);
     free_plan(net);
     delete net;
 }
@@ -1418,8 +1418,8 @@ int relpose_scnet_finalize(RelposeSCNet* net) {
         net->bufs[b.name] = b;
     }
     net->per_image_floats = off; net->ss_float2_per_group = ssoff; net->gb_floats = gboff;
-    if (net->d_w) { hipFree(net->d_w); net->d_w = nullptr; }
-    if (net->d_gb) { hipFree(net->d_gb); net->d_gb = nullptr; }
+    if (net->d_w) { (void)hipFree(net->d_w); net->d_w = nullptr; }
+    if (net->d_gb) { (void)hipFree(net->d_gb); net->d_gb = nullptr; }
     RP_HIP(hipMalloc((void**)&net->d_w, blob.size() * sizeof(float)));
     RP_HIP(hipMemcpy(net->d_w, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     RP_HIP(hipMalloc((void**)&net->d_gb, gb.size() * sizeof(float)));
@@ -1588,10 +1588,10 @@ int relpose_scnet_profile(RelposeSCNet* net, const float* x, float* out, int32_t
         RP_HIP(hipStreamSynchronize((hipStream_t)stream));
         for (size_t i = 0; i + 1 < net->ev.size(); i += 2) {
             float ms = 0;
-            hipEventElapsedTime(&ms, net->ev[i], net->ev[i + 1]);
+            if (hipEventElapsedTime(&ms, net->ev[i], net->ev[i + 1]) != hipSuccess) ms = 0.f;
             if (net->ev_kind[i] == 1) { tg += ms; ++ng; } else to += ms;
         }
-        for (auto e : net->ev) hipEventDestroy(e);
+        for (auto e : net->ev) (void)hipEventDestroy(e);
         net->ev.clear(); net->ev_kind.clear();
     }
     if (ms_gemm) *ms_gemm = tg / iters;
