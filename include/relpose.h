@@ -184,6 +184,14 @@ int relpose_scnet_set_param(RelposeSCNet* net, const char* key, const float* dat
 int relpose_scnet_finalize(RelposeSCNet* net);
 int64_t relpose_scnet_num_params(const RelposeSCNet* net);
 
+/* Arithmetic of the implicit-GEMM convolutions.  RELPOSE_PREC_F32 (default): exact fp32 products on
+ * v_mfma_f32_32x32x2_f32 -- the parity configuration.  RELPOSE_PREC_BF16X3 (opt-in): both operands are split
+ * into bfloat16 hi + lo and a*b ~= hi*hi + hi*lo + lo*hi runs on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation (products exact to ~2^-16 instead of 2^-24; activations, BatchNorm statistics, conv1 and the heads
+ * stay fp32).  May be switched at any time after finalize. */
+enum { RELPOSE_PREC_F32 = 0, RELPOSE_PREC_BF16X3 = 1 };
+int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode);
+
 size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n_images, int32_t H, int32_t W);
 
 /* forward: x [n,16,H,W] -> out [n,7+S+32,H,W]; n even, BatchNorm statistics over each

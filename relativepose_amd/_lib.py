@@ -56,6 +56,7 @@ SIGNATURES = {
     "relpose_scnet_destroy": (None, [c_void_p]),
     "relpose_scnet_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
     "relpose_scnet_finalize": (c_int, [c_void_p]),
+    "relpose_scnet_set_precision": (c_int, [c_void_p, c_int]),
     "relpose_scnet_num_params": (c_int64, [c_void_p]),
     "relpose_scnet_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "relpose_scnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -29,6 +29,9 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float rp_f4v __attribute__((ext_vector_type(4)));
 
 #ifndef RP_ABLATE
 #define RP_ABLATE 0
@@ -85,7 +88,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // scale/shift, B weights) are issued BEFORE the MFMAs of tile kt and consumed AFTER them, so their
 // latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
-template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false>
+template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLDS ? 3 : 2)) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
@@ -262,7 +265,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
             const rp_v2f mk_ = {okf_, okf_};                                                                      \
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                       \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                       \
-            *reinterpret_cast<float4*>(&As[BUF][(lrow + it * RPI) * LDK + kq * 4]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+            if (!SPLIT) *reinterpret_cast<float4*>(&As[BUF][(lrow + it * RPI) * LDK + kq * 4]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+            else {   /* row = [32 x bf16 hi | 32 x bf16 lo]: v = hi + lo to 2^-16 */                               \
+                const rp_f4v vf_ = {v01.x, v01.y, v23.x, v23.y};                                                  \
+                const bf16x4 hi_ = __builtin_convertvector(vf_, bf16x4);                                          \
+                const bf16x4 lo_ = __builtin_convertvector(vf_ - __builtin_convertvector(hi_, rp_f4v), bf16x4);   \
+                bf16x4* ar_ = reinterpret_cast<bf16x4*>(&As[BUF][(lrow + it * RPI) * LDK]);                       \
+                ar_[kq] = hi_; ar_[8 + kq] = lo_;                                                                 \
+            }                                                                                                     \
         }                                                                                                         \
         if (BN >= RPI || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb0;              \
         if (B_IT > 1) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + RPI) * LDK + kq * 4]) = rb1;                     \
@@ -284,6 +294,31 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
 #if RP_ABLATE != 2 && RP_ABLATE != 5
         if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
 #endif
+        if constexpr (SPLIT) {
+            // bf16x3: a*b ~= hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), 2 steps of 16 k per tile
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LDK + st * 8]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LDK + 16 + st * 8]);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LDK + st * 8]);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LDK + 16 + st * 8]);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             float4 a[MI], b[NI];
@@ -832,6 +867,7 @@ struct Phase {                       // one launch of the implicit GEMM
     int ntaps; signed char offy[16], offx[16];
     int py, px, Hp, Wp;              // Hp/Wp resolved against the layer's Hout/Wout
     size_t w_off;                    // float offset into the packed-weight blob
+    size_t ws_off = 0;               // the same weights split into bf16 hi / lo halves per 32-wide k-tile (bf16x3 mode; 0 = none)
     int K;
 };
 
@@ -853,6 +889,7 @@ struct RelposeSCNet {
     std::map<std::string, std::vector<float>> params;   // raw state dict (host)
     std::map<std::string, std::vector<int64_t>> shapes;
     bool finalized = false;
+    int prec = 0;                    // RELPOSE_PREC_F32 / RELPOSE_PREC_BF16X3 (relpose_scnet_set_precision)
     int64_t nparams = 0;
     // device
     float* d_w = nullptr;        // packed weights + biases
@@ -926,6 +963,15 @@ bool have(RelposeSCNet* net, const std::string& key, size_t numel) {
     }
     return true;
 }
+
+// round-to-nearest-even float32 -> bfloat16 (what v_cvt_pk_bf16_f32 does on the device side of the split)
+inline uint16_t f32_to_bf16(float v) {
+    uint32_t u; memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);       // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float v; memcpy(&v, &u, 4); return v; }
 
 int pack_layer(RelposeSCNet* net, const LayerSpec& sp, std::vector<float>& blob) {
     Layer L;
@@ -1002,6 +1048,25 @@ int pack_layer(RelposeSCNet* net, const LayerSpec& sp, std::vector<float>& blob)
                 L.phases.push_back(P);
             }
     }
+    // bf16x3 mode: every [CoutPad][K] row re-packed k-tile by k-tile as [32 x bf16 hi | 32 x bf16 lo] (w ~= hi + lo to
+    // 2^-16; same 128 bytes per k-tile, so the B loader and the LDS geometry are those of the fp32 kernel)
+    if (L.name != "conv1")
+        for (Phase& P : L.phases) {
+            if (P.K % 32) continue;
+            P.ws_off = blob.size();
+            blob.resize(blob.size() + (size_t)L.cout_pad * P.K, 0.f);
+            const float* w = blob.data() + P.w_off;
+            uint16_t* ws = reinterpret_cast<uint16_t*>(blob.data() + P.ws_off);
+            for (int n_ = 0; n_ < L.cout_pad; ++n_)
+                for (int kt = 0; kt < P.K / 32; ++kt)
+                    for (int e = 0; e < 32; ++e) {
+                        const float v = w[(size_t)n_ * P.K + kt * 32 + e];
+                        const uint16_t hi = f32_to_bf16(v);
+                        const uint16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+                        uint16_t* o = ws + ((size_t)n_ * P.K + kt * 32) * 2;
+                        o[e] = hi; o[32 + e] = lo;
+                    }
+        }
     net->layers[L.name] = L;
     return 0;
 }
@@ -1042,7 +1107,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
 enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5 };
-struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0; int ninner = 1, mt_max = 1; };
+struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0, split = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
     int n = 0; void* ws = nullptr;
@@ -1116,7 +1181,7 @@ void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, con
         }
         d.ntaps = P.ntaps;
         memcpy(d.offy, P.offy, 16); memcpy(d.offx, P.offx, 16);
-        d.w = net->d_w + P.w_off;
+        d.w = net->d_w + ((net->prec == 1 && P.ws_off) ? P.ws_off : P.w_off);
         d.Cout = L.cout; d.cout_pad = L.cout_pad;
         d.y = buf(out); d.Hout = Hout; d.Wout = Hout; d.ycstride = (out == "OUT") ? net->cf : O.C; d.ychoff = ochoff;
         d.bias = (L.kind == 2) ? net->d_w + L.bias_off : nullptr;
@@ -1220,6 +1285,7 @@ void Builder::end_group() {
         if ((2 * hw) % BMt) o.uni = 0;             // some tile would straddle two BatchNorm groups
     }
     if (!o.sslds) o.uni = 0;
+    o.split = (net->prec == 1 && cfg != 3) ? 1 : 0;
     plan->ops.push_back(o);
     if (ksplit > 1) {
         Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
@@ -1341,6 +1407,12 @@ int64_t relpose_scnet_num_params(const RelposeSCNet* net) {
     int64_t n = 0;
     for (auto& kv : net->params) n += (int64_t)kv.second.size();
     return n;
+}
+
+int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode) {
+    if (!net || (mode != RELPOSE_PREC_F32 && mode != RELPOSE_PREC_BF16X3)) return RELPOSE_EINVAL;
+    if (net->prec != mode) { net->prec = mode; free_plan(net); }     // the launch plans hold weight pointers and kernel variants
+    return 0;
 }
 
 int relpose_scnet_finalize(RelposeSCNet* net) {
@@ -1482,27 +1554,32 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         if (op.type == OP_CONV) {
             mark(1);
             const ConvDesc* dd = plan->d_descs + op.first;
+            // 4-wave tiles: cfg 0 = 128x128 (2x2 waves of 64x64), 1 = 256x64, 2 = 256x32, 4 = 128x64, 5 = 128x32
+#define RP_LAUNCH_V(WM_, WN_, MI_, NI_, SS_, UNI_, SP_) \
+            hipLaunchKernelGGL((conv_igemm_kernel<WM_, WN_, MI_, NI_, SS_, UNI_, SP_>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max)
+#define RP_LAUNCH_T(WM_, WN_, MI_, NI_)                                                                        \
+            do {                                                                                               \
+                if (op.split) {                                                                                \
+                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, true);                             \
+                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, true);                     \
+                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, true);                                  \
+                } else {                                                                                       \
+                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, false);                            \
+                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, false);                    \
+                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, false);                                 \
+                }                                                                                              \
+            } while (0)
             if (op.cfg == 3) {
                 if (op.sslds) hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, true>), op.grid, dim3(512), 0, s, dd, op.ninner, op.mt_max);
                 else hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, false>), op.grid, dim3(512), 0, s, dd, op.ninner, op.mt_max);
-            } else if (op.cfg >= 4 && op.sslds) {
-                if (op.cfg == 4 && op.uni) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 2, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else if (op.cfg == 4) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 2, true, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else if (op.uni) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, true, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-            } else if (op.uni) {
-                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, true, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-            } else if (op.sslds) {
-                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, true>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-            } else {
-                if (op.cfg == 0) hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else if (op.cfg == 1) hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
-                else hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, false>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max);
             }
+            else if (op.cfg == 0) RP_LAUNCH_T(2, 2, 2, 2);
+            else if (op.cfg == 1) RP_LAUNCH_T(4, 1, 2, 2);
+            else if (op.cfg == 2) RP_LAUNCH_T(4, 1, 2, 1);
+            else if (op.cfg == 4) RP_LAUNCH_T(4, 1, 1, 2);
+            else RP_LAUNCH_T(4, 1, 1, 1);
+#undef RP_LAUNCH_T
+#undef RP_LAUNCH_V
             mark(-1);
         } else if (op.type == OP_CONV1) {
             mark(1);

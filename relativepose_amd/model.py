@@ -70,6 +70,13 @@ class SCNet:
         self._loaded = True
         return self
 
+    def set_precision(self, mode):
+        """'f32' (default, the parity configuration) or 'bf16x3' (split-bfloat16 MFMA products, fp32 accumulation:
+        relpose_scnet_set_precision).  Not part of the reference interface."""
+        code = {"f32": 0, "bf16x3": 1}[mode]
+        _lib.check(_lib.lib().relpose_scnet_set_precision(self._h, code), "relpose_scnet_set_precision")
+        return self
+
     def num_params(self):
         return int(_lib.lib().relpose_scnet_num_params(self._h))
 
