@@ -73,6 +73,8 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
+            _build_locked()          # a fresh checkout on a box with hipcc: compile the HIP library once (no CPU fallback exists)
+        if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not built: run `python -m relativepose_amd.build` "
                                "(or __graft_entry__.build()). There is no CPU fallback.")
         # torch ships its own libamdhip64; import it first so this library binds to the SAME HIP runtime
@@ -87,6 +89,21 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+def _build_locked():
+    """Compile librelpose_hip.so with hipcc if it is missing; one process builds, concurrent ranks wait on the lock."""
+    import fcntl
+    from . import build as _b
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        return
+    with open(LIB_PATH + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB_PATH):
+                _b.build(verbose=False)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
 
 
 def check(rc, what):
