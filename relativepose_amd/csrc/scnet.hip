@@ -3,17 +3,20 @@
 //
 // Design (DESIGN.md "SCNet"):
 //  * activations live in HBM as NHWC float32, RAW conv outputs (pre-BatchNorm); every buffer has a
-//    companion per-(group,channel) {scale,shift} table produced by a two-stage float64 statistics
-//    pass (BatchNorm uses batch statistics over each group of 2 images, mymodel.py:19,32);
-//  * one implicit-GEMM kernel for every conv / transposed conv / 1x1 head: M = output pixels,
-//    N = Cout, K = taps x Cin.  The A-tile loader gathers the im2col slice from up to two NHWC
+//    companion per-(group,channel) {scale,shift} table: float64 statistics written by the producing
+//    kernel's epilogue + a fixed-order finalize (BatchNorm uses batch statistics over each group of
+//    2 images, mymodel.py:19,32);
+//  * one implicit-GEMM kernel for every conv / transposed conv: M = output pixels, N = Cout,
+//    K = taps x Cin, k-tiles of 32.  The A-tile loader gathers the im2col slice from up to two NHWC
 //    sources (skip concatenations are never materialised), applies scale/shift + LeakyReLU(0.1)
 //    on the fly and zero-pads; B = weights pre-packed [Cout][K].  Tiles are staged through LDS
-//    (row stride 20 floats: conflict-free ds_read_b128) and contracted with
-//    v_mfma_f32_32x32x2_f32 (exact fp32, 64 lanes);
-//  * stride-2 transposed convs are decomposed into their sub-pixel phases (4 launches of a 2x2-tap
-//    conv) so no multiply-by-zero work is issued; shared-weight encoder streams (self / warped
-//    view) are channel blocks of one concatenated buffer;
+//    (row stride 36 floats: conflict-free ds_read_b128) and contracted with
+//    v_mfma_f32_32x32x2_f32 (exact fp32, 64 lanes) -- or, opt-in, with three bf16 MFMA products per
+//    fp32 product (relpose_scnet_set_precision);
+//  * stride-2 transposed convs are decomposed into their sub-pixel phases (4 members of a 2x2-tap
+//    conv, launched phase-interleaved so one XCD's L2 serves all four) so no multiply-by-zero work
+//    is issued; shared-weight encoder streams (self / warped view) are channel blocks of one
+//    concatenated buffer; conv1 (K = 18/36) and the five 1x1 heads have their own direct kernels;
 //  * bilinear resize kernels (align_corners=False) in and out.
 #include "common.h"
 #include <map>
@@ -86,7 +89,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // Tile: WM x WN waves (WM*WN = 4), each wave MI x NI MFMA 32x32 blocks.
 // Both tiles are register-staged: the global loads of tile kt+1 (A values, their BatchNorm
 // scale/shift, B weights) are issued BEFORE the MFMAs of tile kt and consumed AFTER them, so their
-// latency hides under 32 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
+// latency hides under 64 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLDS ? 3 : 2)) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
