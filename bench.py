@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="scan pairs per GPU")
     ap.add_argument("--keypoints", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3"], default="f32",
                     help="conv arithmetic: f32 = exact fp32 MFMA (the parity configuration, default); bf16x3 = opt-in split-bf16 products")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
@@ -145,7 +145,7 @@ def main():
         ms = dt / args.steps * 1e3
         res = {"metric": "scan-pairs/sec end-to-end (completion+feat+spectral-match), 160x640 RGB-D",
                "value": total * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (conv products as 3 x bf16 MFMA, fp32 accumulate; opt-in, NOT the parity configuration)",
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else f"f32 (conv products as 3 x {args.precision[:-2]} MFMA, fp32 accumulate; opt-in, NOT the parity configuration)",
                "data": "synthetic (seeded box-room RGB-D panoramas, injected keypoints, random-init weights)",
                "config": {"workload": "SUNCG 160x640, N=200 keypoints, batch=32 pairs per GPU, alterStep=3 (BASELINE configs[1])",
                           "pairs_per_gpu": B, "keypoints": N, "recurrent_levels": 3, "parallelism": f"pairs sharded x{world}",
@@ -159,7 +159,7 @@ def main():
         ach = flops / (g_ms * 1e-3) / 1e12
         # bf16x3 (opt-in): every fp32 product costs three dense bf16 MFMA products -> algorithmic peak = 2500 / 3
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else 2500.0 / 3
-        res["roofline"] = {"kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2)" if args.precision == "f32" else "conv_igemm_kernel (3 x bf16 MFMA 32x32x16)",
+        res["roofline"] = {"kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2)" if args.precision == "f32" else f"conv_igemm_kernel (3 x {args.precision[:-2]} MFMA 32x32x16)",
                            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                            # HBM bytes of the conv stack per forward: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
                            # FETCH doubled per the gfx950 correction) of tools/scnet_only.py at this batch: profiles/r01_scnet_hbm_pmc.txt

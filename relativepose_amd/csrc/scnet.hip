@@ -34,6 +34,10 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int SPLIT> struct SplitT { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct SplitT<2> { typedef f16x8 v8; typedef f16x4 v4; };
 typedef float rp_f4v __attribute__((ext_vector_type(4)));
 
 #ifndef RP_ABLATE
@@ -78,6 +82,7 @@ struct ConvDesc {
     int M, K;
     int ksplit, kt_per;    // split-K: slices along K and k-tiles per slice (ksplit==1: direct store)
     int tap_inner;         // K order of the main loop: 1 = channel chunk outer / tap inner, 0 = tap outer
+    float wscale;          // f16x3 mode: the packed weights carry a power-of-two factor 1/wscale (keeps their lo halves normal); 1 otherwise
     int ntiles_n;          // N tiles (grid.y = ntiles_n * ksplit)
     float* partial;        // [ksplit][M][CoutPad] partial sums when ksplit > 1
     double* stat_part;     // [mtiles][2 group slots][CoutPad][2] per-tile BatchNorm partial sums (or null)
@@ -91,7 +96,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // scale/shift, B weights) are issued BEFORE the MFMAs of tile kt and consumed AFTER them, so their
 // latency hides under 64 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
-template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false, bool SPLIT = false>
+template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false, int SPLIT = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLDS ? 3 : 2)) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
@@ -269,11 +274,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                       \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                       \
             if (!SPLIT) *reinterpret_cast<float4*>(&As[BUF][(lrow + it * RPI) * LDK + kq * 4]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
-            else {   /* row = [32 x bf16 hi | 32 x bf16 lo]: v = hi + lo to 2^-16 */                               \
+            else {   /* row = [32 x 16-bit hi | 32 x 16-bit lo]: v = hi + lo to 2^-16 (bf16) / ~2^-22 (f16) */    \
+                typedef typename SplitT<SPLIT>::v4 h4_;                                                           \
                 const rp_f4v vf_ = {v01.x, v01.y, v23.x, v23.y};                                                  \
-                const bf16x4 hi_ = __builtin_convertvector(vf_, bf16x4);                                          \
-                const bf16x4 lo_ = __builtin_convertvector(vf_ - __builtin_convertvector(hi_, rp_f4v), bf16x4);   \
-                bf16x4* ar_ = reinterpret_cast<bf16x4*>(&As[BUF][(lrow + it * RPI) * LDK]);                       \
+                const h4_ hi_ = __builtin_convertvector(vf_, h4_);                                                \
+                const h4_ lo_ = __builtin_convertvector(vf_ - __builtin_convertvector(hi_, rp_f4v), h4_);         \
+                h4_* ar_ = reinterpret_cast<h4_*>(&As[BUF][(lrow + it * RPI) * LDK]);                             \
                 ar_[kq] = hi_; ar_[8 + kq] = lo_;                                                                 \
             }                                                                                                     \
         }                                                                                                         \
@@ -297,28 +303,35 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
 #if RP_ABLATE != 2 && RP_ABLATE != 5
         if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
 #endif
-        if constexpr (SPLIT) {
-            // bf16x3: a*b ~= hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), 2 steps of 16 k per tile
+        if constexpr (SPLIT != 0) {
+            // x3 split: a*b ~= hi*hi + hi*lo + lo*hi on the 16-bit MFMA (fp32 accumulate), 2 steps of 16 k per tile
+            typedef typename SplitT<SPLIT>::v8 h8;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+                h8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    ah[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LDK + st * 8]);
-                    al[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LDK + 16 + st * 8]);
+                    ah[i] = *reinterpret_cast<const h8*>(&As[buf][arow + i * 32 * LDK + st * 8]);
+                    al[i] = *reinterpret_cast<const h8*>(&As[buf][arow + i * 32 * LDK + 16 + st * 8]);
                 }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LDK + st * 8]);
-                    bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LDK + 16 + st * 8]);
+                    bh[j] = *reinterpret_cast<const h8*>(&Bs[buf][brow + j * 32 * LDK + st * 8]);
+                    bl[j] = *reinterpret_cast<const h8*>(&Bs[buf][brow + j * 32 * LDK + 16 + st * 8]);
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        if constexpr (SPLIT == 1) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
                     }
             }
         } else
@@ -360,6 +373,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
     }
 #undef RP_ISSUE_LOADS
 #undef RP_STORE_TILE
+    if constexpr (SPLIT == 2) {                        // undo the power-of-two weight pre-scale (exact)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= d.wscale;
+    }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (d.ksplit > 1) {                                // partial sums, reduced in fixed order by splitk_reduce_kernel
@@ -871,6 +892,8 @@ struct Phase {                       // one launch of the implicit GEMM
     int py, px, Hp, Wp;              // Hp/Wp resolved against the layer's Hout/Wout
     size_t w_off;                    // float offset into the packed-weight blob
     size_t ws_off = 0;               // the same weights split into bf16 hi / lo halves per 32-wide k-tile (bf16x3 mode; 0 = none)
+    size_t wh_off = 0;               // ... into float16 hi / lo halves (f16x3 mode), pre-multiplied by 1 / wh_scale
+    float wh_scale = 1.f;            // power of two
     int K;
 };
 
@@ -1069,6 +1092,29 @@ int pack_layer(RelposeSCNet* net, const LayerSpec& sp, std::vector<float>& blob)
                         uint16_t* o = ws + ((size_t)n_ * P.K + kt * 32) * 2;
                         o[e] = hi; o[32 + e] = lo;
                     }
+            // float16 split (f16x3 mode): 11 + 11 mantissa bits, subnormal lo halves keep an absolute error <= 2^-25
+            P.wh_off = blob.size();
+            blob.resize(blob.size() + (size_t)L.cout_pad * P.K, 0.f);
+            w = blob.data() + P.w_off;
+            _Float16* wh = reinterpret_cast<_Float16*>(blob.data() + P.wh_off);
+            // exact power-of-two pre-scale so that max |w| lands in [512, 1024): the lo halves (~2^-12 |w|) of all but
+            // the tiniest weights are then NORMAL float16 numbers; the kernel multiplies the accumulators by wh_scale
+            float wmax = 0.f;
+            for (size_t i = 0; i < (size_t)L.cout_pad * P.K; ++i) wmax = std::max(wmax, fabsf(w[i]));
+            int ex = 0;
+            if (wmax > 0.f) { (void)frexpf(wmax, &ex); ex = 10 - ex; }        // wmax * 2^ex in [512, 1024)
+            ex = std::max(-14, std::min(ex, 24));
+            const float up = ldexpf(1.f, ex);
+            P.wh_scale = ldexpf(1.f, -ex);
+            for (int n_ = 0; n_ < L.cout_pad; ++n_)
+                for (int kt = 0; kt < P.K / 32; ++kt)
+                    for (int e = 0; e < 32; ++e) {
+                        const float v = w[(size_t)n_ * P.K + kt * 32 + e] * up;
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        _Float16* o = wh + ((size_t)n_ * P.K + kt * 32) * 2;
+                        o[e] = hi; o[32 + e] = lo;
+                    }
         }
     net->layers[L.name] = L;
     return 0;
@@ -1184,7 +1230,8 @@ void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, con
         }
         d.ntaps = P.ntaps;
         memcpy(d.offy, P.offy, 16); memcpy(d.offx, P.offx, 16);
-        d.w = net->d_w + ((net->prec == 1 && P.ws_off) ? P.ws_off : P.w_off);
+        d.w = net->d_w + ((net->prec == 1 && P.ws_off) ? P.ws_off : (net->prec == 2 && P.wh_off) ? P.wh_off : P.w_off);
+        d.wscale = (net->prec == 2 && P.wh_off) ? P.wh_scale : 1.f;
         d.Cout = L.cout; d.cout_pad = L.cout_pad;
         d.y = buf(out); d.Hout = Hout; d.Wout = Hout; d.ycstride = (out == "OUT") ? net->cf : O.C; d.ychoff = ochoff;
         d.bias = (L.kind == 2) ? net->d_w + L.bias_off : nullptr;
@@ -1288,7 +1335,7 @@ void Builder::end_group() {
         if ((2 * hw) % BMt) o.uni = 0;             // some tile would straddle two BatchNorm groups
     }
     if (!o.sslds) o.uni = 0;
-    o.split = (net->prec == 1 && cfg != 3) ? 1 : 0;
+    o.split = (cfg != 3) ? net->prec : 0;
     plan->ops.push_back(o);
     if (ksplit > 1) {
         Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
@@ -1413,7 +1460,7 @@ int64_t relpose_scnet_num_params(const RelposeSCNet* net) {
 }
 
 int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode) {
-    if (!net || (mode != RELPOSE_PREC_F32 && mode != RELPOSE_PREC_BF16X3)) return RELPOSE_EINVAL;
+    if (!net || mode < RELPOSE_PREC_F32 || mode > RELPOSE_PREC_F16X3) return RELPOSE_EINVAL;
     if (net->prec != mode) { net->prec = mode; free_plan(net); }     // the launch plans hold weight pointers and kernel variants
     return 0;
 }
@@ -1562,14 +1609,18 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             hipLaunchKernelGGL((conv_igemm_kernel<WM_, WN_, MI_, NI_, SS_, UNI_, SP_>), op.grid, dim3(256), 0, s, dd, op.ninner, op.mt_max)
 #define RP_LAUNCH_T(WM_, WN_, MI_, NI_)                                                                        \
             do {                                                                                               \
-                if (op.split) {                                                                                \
-                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, true);                             \
-                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, true);                     \
-                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, true);                                  \
+                if (op.split == 1) {                                                                           \
+                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 1);                                \
+                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 1);                        \
+                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, 1);                                     \
+                } else if (op.split == 2) {                                                                    \
+                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 2);                                \
+                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 2);                        \
+                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, 2);                                     \
                 } else {                                                                                       \
-                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, false);                            \
-                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, false);                    \
-                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, false);                                 \
+                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 0);                                \
+                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 0);                        \
+                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, 0);                                     \
                 }                                                                                              \
             } while (0)
             if (op.cfg == 3) {
