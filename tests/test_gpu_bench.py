@@ -1,0 +1,36 @@
+"""bench.py contract (GPU): one JSON line with the driver's keys, the roofline and cpu_baseline objects, and a
+pipelined run whose poses equal the plain sequential run (checked by tests/test_gpu_pipeline.py); here only the schema
+and basic sanity of the numbers at a tiny batch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract_small_batch():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "4", "--steps", "3", "--warmup", "1", "--keypoints", "60"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["unit"] == "pairs/s" and r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f32" and "workload" in r["config"]
+    assert abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3 / 1e3)) < 1e-6 * r["value"]
+    rf = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = r["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert r["status_ok_fraction"] == 1.0

@@ -1,4 +1,4 @@
-"""fp32 vs bf16x3 SCNet: output difference and forward time at the bench batch."""
+"""fp32 vs an opt-in split-precision mode (argv[2]: f16x3 | bf16x3) of SCNet: output difference and forward time at the bench batch."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
@@ -23,7 +23,7 @@ y16, t16 = run(sys.argv[2] if len(sys.argv) > 2 else "bf16x3")
 y32b, _ = run("f32")
 d = (y16 - y32).abs()
 print(f"forward ms: f32 {t32:.2f}  {sys.argv[2] if len(sys.argv) > 2 else chr(98)+chr(102)+'16x3'} {t16:.2f}")
-print(f"bf16x3 vs f32: max abs {d.max().item():.3e}  mean abs {d.mean().item():.3e}  (output abs mean {y32.abs().mean().item():.3f}, max {y32.abs().max().item():.2f})")
+print(f"{sys.argv[2] if len(sys.argv) > 2 else chr(98)+chr(102)+chr(49)+chr(54)+chr(120)+chr(51)} vs f32: max abs {d.max().item():.3e}  mean abs {d.mean().item():.3e}  (output abs mean {y32.abs().mean().item():.3f}, max {y32.abs().max().item():.2f})")
 for name, sl in (("rgb", slice(0, 3)), ("normal", slice(3, 6)), ("depth", slice(6, 7)), ("sem", slice(7, 22)), ("feat", slice(22, 54))):
     print(f"   {name:7s} max abs {d[:, sl].max().item():.3e}  ref scale {y32[:, sl].abs().max().item():.3f}")
 print("f32 reproducible after switching back:", torch.equal(y32, y32b))
