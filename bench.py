@@ -11,7 +11,7 @@ collective, one RCCL all_gather of the 4x4 poses per step).  Two steps are in fl
 (--inflight 2): the launch-bound matcher phase of step k runs under the SCNet forward of step k+1
 (pipeline.run_pipelined); every step still does the complete path on its own 32 pairs.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
@@ -66,8 +66,8 @@ def cpu_baseline(args, data, pts, ptw, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=32, help="scan pairs per GPU")
     ap.add_argument("--keypoints", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
