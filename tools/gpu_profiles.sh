@@ -9,10 +9,10 @@ cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_bench gpurun_out/prof_fwd gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
 grep '"metric"' gpurun_out/prof_bench.log > gpurun_out/prof_bench.json
-python tools_prof.py gpurun_out/prof_bench/bench_results.db > gpurun_out/bench_kernel_stats.txt 2>&1
+python tools/kernel_stats.py gpurun_out/prof_bench/bench_results.db > gpurun_out/bench_kernel_stats.txt 2>&1
 python tools/overlap.py gpurun_out/prof_bench/bench_results.db 250 1 > gpurun_out/overlap.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_fwd -o p -- python tools/scnet_only.py 64 3 > gpurun_out/prof_fwd.log 2>&1
-python tools_prof.py gpurun_out/prof_fwd/p_results.db 64 > gpurun_out/conv_layers.txt 2>&1
+python tools/kernel_stats.py gpurun_out/prof_fwd/p_results.db 64 > gpurun_out/conv_layers.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc_$c -o p -- python tools/scnet_only.py 64 2 > gpurun_out/pmc_$c.log 2>&1
 done

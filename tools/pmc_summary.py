@@ -1,8 +1,8 @@
 """Summarise the rocprofv3 --pmc passes of tools/scnet_only.py (one forward at 64 images) into profiles/."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools_prof import pmc, short
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_stats import pmc, short
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 

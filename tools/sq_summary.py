@@ -1,7 +1,7 @@
 """Per-kernel SQ counter summary of a rocprofv3 --pmc pass over tools/scnet_only.py (last forward)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools_prof import pmc, short
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_stats import pmc, short
 db = sys.argv[1]
 items = sorted(pmc(db).items(), key=lambda kv: kv[0][2])
 idx = [i for i, (k, v) in enumerate(items) if 'resize_in' in k[1]]
