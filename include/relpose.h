@@ -9,12 +9,16 @@
  *
  * Conventions
  *  - every pointer argument is DEVICE memory unless its name ends in _host;
- *  - the caller owns all buffers; the library never frees caller memory and
- *    allocates only inside relpose_scnet_create (packed weights, freed by
- *    relpose_scnet_destroy); scratch comes from caller-provided workspaces whose
- *    size is returned by the *_workspace_bytes functions;
+ *  - the caller owns all buffers; the library never frees caller memory.  Its own
+ *    device allocations belong to a RelposeSCNet handle and are freed by
+ *    relpose_scnet_destroy: the packed weights (relpose_scnet_finalize) and one
+ *    launch-descriptor table per (workspace, n_images) pair, built by the FIRST
+ *    relpose_scnet_forward on that workspace (that first call hipMallocs + copies
+ *    synchronously; later calls only enqueue).  Scratch comes from caller-provided
+ *    workspaces whose size is returned by the *_workspace_bytes functions;
  *  - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
- *    default stream); no entry point synchronises;
+ *    default stream); apart from the first-forward plan build and
+ *    relpose_scnet_finalize / relpose_scnet_profile no entry point synchronises;
  *  - return value: 0 = enqueued, <0 = invalid argument (RELPOSE_EINVAL) or HIP
  *    error (-(1000+hipError_t)).  Per-pair degenerate inputs are NOT errors: the
  *    reference returns identity for them (rpmodule.py:346-348,377-379,406-408,
@@ -47,6 +51,7 @@ enum {
 
 enum { RELPOSE_SUNCG = 0, RELPOSE_MATTERPORT = 1, RELPOSE_SCANNET = 2 };   /* dataset conventions */
 enum { RELPOSE_MASK_SECOND = 0, RELPOSE_MASK_KINECT = 1 };                   /* util.apply_mask methods */
+enum { RELPOSE_COMPOSE_EVAL = 0, RELPOSE_COMPOSE_LIB = 1 };                       /* output composition variants */
 enum { RELPOSE_FIT_IRLS_SM = 0, RELPOSE_FIT_HORN87 = 1, RELPOSE_FIT_IRLS = 2, RELPOSE_FIT_SPECTRAL = 3 };
 
 /* Hyper-parameters of the pose module: class opts, RPModule/rputil.py:11-22. */
@@ -143,12 +148,22 @@ int relpose_pose_inverse(const double* pose, double* inv, int32_t n, void* strea
  *   f        [n, cf, h, 4h]  network output; normal = ch 3:6, depth = ch 6, feat = ch feat_off:feat_off+32
  *   obs_norm [n,3,h,4h], obs_depth [n,h,4h]  the complete input scan (evaluation.py:248-253)
  *   pts      [n, npts_max, 2] f64 pixel coords (x,y), x<=4h-2, y<=h-2 ; npts [n]
+ *   compose  RELPOSE_COMPOSE_EVAL: normal / (|obs normal| + 1e-6)   evaluation.py:250-251
+ *            RELPOSE_COMPOSE_LIB : normal / (|normal| + 1e-12)      rpmodule.py:633-634 (RelativePoseEstimationViaCompletion)
  *   outputs  pc [n,npts_max,3] f64, normal [n,npts_max,3] f64, feat [n,npts_max,32] f32 */
 int relpose_sample_primitives(const float* f, int32_t cf, int32_t feat_off,
                               const float* obs_norm, const float* obs_depth,
                               const double* pts, const int32_t* npts, int32_t npts_max,
                               double* pc, double* normal, float* feat,
-                              int32_t n, int32_t h, int32_t mask_method, int32_t dataset, void* stream);
+                              int32_t n, int32_t h, int32_t mask_method, int32_t compose, int32_t dataset, void* stream);
+
+/* The same two samplers on caller-composed maps, for the reference-named host shims:
+ * rputil.getPixel (rputil.py:88-119, incl. getPixel_helper :61-86): depth [h,4h] f64, normal [h,4h,3] f64 (HWC),
+ * pts [k,2] f64 pixel coords -> pc [k,3] f64 (the reference returns the transpose), nn [k,3] f64 (renormalised, not rotated). */
+int relpose_get_pixel(const double* depth, const double* normal, const double* pts, int32_t k, int32_t h, int32_t dataset,
+                      double* pc, double* nn, void* stream);
+/* rputil.interpolate (rputil.py:43-58): feat [c,h,w] f32, pt [k,2] f32 normalised to [0,1] -> out [c,k] f32. */
+int relpose_interpolate(const float* feat, const float* pt, float* out, int32_t c, int32_t h, int32_t w, int32_t k, void* stream);
 
 /* ------------------------------------------------- evaluation-side statistics
  * util.depth2pc (util.py:468-523) of the observed block of each panorama (the face / kinect crop that

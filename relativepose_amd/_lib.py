@@ -46,7 +46,9 @@ SIGNATURES = {
     "relpose_warp_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "relpose_pose_inverse": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "relpose_sample_primitives": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "relpose_get_pixel": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "relpose_interpolate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "relpose_observed_points": (c_int, [c_int, c_int]),
     "relpose_depth2pc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "relpose_nn_dist": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -229,23 +229,26 @@ __global__ void pose_inverse_kernel(const double* __restrict__ pose, double* __r
 // ---- compose + sample ------------------------------------------------------------------------
 // evaluation.py:248-253 in float32 exactly as numpy evaluates it:
 //   normal = ((1-m)*f_n + m*obs_n) / (||obs_n|| + 1e-6) ;  depth = (1-m)*f_d + m*obs_d
+// compose = 1 is the library form of the same loop (rpmodule.py:629-636): the blended normal is divided by ITS OWN norm + 1e-12.
 __device__ __forceinline__ void composed_pixel(const float* f, int cf, const float* on, const float* od, size_t hw, int h, Box bx,
-                                               int y, int x, float* nout, float& dout) {
+                                               int compose, int y, int x, float* nout, float& dout) {
     const size_t p = (size_t)y * 4 * h + x;
     const float m = (y >= bx.y0 && y < bx.y1 && x >= bx.x0 && x < bx.x1) ? 1.0f : 0.0f;
     const float om = 1.0f - m;
     const float o0 = on[p], o1 = on[hw + p], o2 = on[2 * hw + p];
-    const float nn = sqrtf((o0 * o0 + o1 * o1) + o2 * o2) + 1e-6f;
-    nout[0] = (om * f[3 * hw + p] + m * o0) / nn;
-    nout[1] = (om * f[4 * hw + p] + m * o1) / nn;
-    nout[2] = (om * f[5 * hw + p] + m * o2) / nn;
+    const float b0 = om * f[3 * hw + p] + m * o0, b1 = om * f[4 * hw + p] + m * o1, b2 = om * f[5 * hw + p] + m * o2;
+    const float nn = compose ? sqrtf((b0 * b0 + b1 * b1) + b2 * b2) + 1e-12f : sqrtf((o0 * o0 + o1 * o1) + o2 * o2) + 1e-6f;
+    nout[0] = b0 / nn;
+    nout[1] = b1 / nn;
+    nout[2] = b2 / nn;
     dout = om * f[6 * hw + p] + m * od[p];
 }
 
 __global__ void sample_primitives_kernel(const float* __restrict__ f, int cf, int feat_off, const float* __restrict__ obs_norm,
                                          const float* __restrict__ obs_depth, const double* __restrict__ pts,
                                          const int* __restrict__ npts, int npts_max, double* __restrict__ pc,
-                                         double* __restrict__ normal, float* __restrict__ feat, int n, int h, Box bx, int dataset) {
+                                         double* __restrict__ normal, float* __restrict__ feat, int n, int h, Box bx, int dataset,
+                                         int compose) {
     const int img = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= npts[img]) return;
@@ -259,10 +262,10 @@ __global__ void sample_primitives_kernel(const float* __restrict__ f, int cf, in
     const int tx = (int)floor(px), ty = (int)floor(py);
     const double fx1 = px - tx, fx0 = tx + 1 - px, fy1 = py - ty, fy0 = ty + 1 - py;
     float n00[3], n01[3], n10[3], n11[3], d00, d01, d10, d11;
-    composed_pixel(fi, cf, on, od, hw, h, bx, ty, tx, n00, d00);
-    composed_pixel(fi, cf, on, od, hw, h, bx, ty, tx + 1, n01, d01);
-    composed_pixel(fi, cf, on, od, hw, h, bx, ty + 1, tx, n10, d10);
-    composed_pixel(fi, cf, on, od, hw, h, bx, ty + 1, tx + 1, n11, d11);
+    composed_pixel(fi, cf, on, od, hw, h, bx, compose, ty, tx, n00, d00);
+    composed_pixel(fi, cf, on, od, hw, h, bx, compose, ty, tx + 1, n01, d01);
+    composed_pixel(fi, cf, on, od, hw, h, bx, compose, ty + 1, tx, n10, d10);
+    composed_pixel(fi, cf, on, od, hw, h, bx, compose, ty + 1, tx + 1, n11, d11);
     const double val = (((double)d00 * fy0 * fx0 + (double)d01 * fx1 * fy0) + (double)d10 * fy1 * fx0) + (double)d11 * fx1 * fy1;
     double nn[3];
 #pragma unroll
@@ -291,6 +294,50 @@ __global__ void sample_primitives_kernel(const float* __restrict__ f, int cf, in
         const float v00 = fc[(size_t)yi * W + xi], v10 = fc[(size_t)(yi + 1) * W + xi];
         const float v01 = fc[(size_t)yi * W + xi + 1], v11 = fc[(size_t)(yi + 1) * W + xi + 1];
         fo[c] = ((v00 * wx0 * wy0 + v10 * wx0 * wy1) + v01 * wx1 * wy0) + v11 * wx1 * wy1;
+    }
+}
+
+// ---- stand-alone rputil.getPixel / rputil.interpolate (the reference-named shims) ---------------------------------
+// rputil.getPixel :88-119 + getPixel_helper :61-86 on caller-composed maps: depth [h,4h] f64, normal [h,4h,3] f64 (HWC like
+// the reference's numpy arrays), pts [k,2] f64 pixel coords -> pc [k,3] (the reference returns its transpose), nn [k,3].
+__global__ void get_pixel_kernel(const double* __restrict__ depth, const double* __restrict__ normal, const double* __restrict__ pts,
+                                 int k_total, int h, int dataset, double* __restrict__ pc, double* __restrict__ nn_out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= k_total) return;
+    const int W = 4 * h;
+    const double px = pts[(size_t)k * 2 + 0], py = pts[(size_t)k * 2 + 1];
+    const int tx = (int)floor(px), ty = (int)floor(py);
+    const double fx1 = px - tx, fx0 = tx + 1 - px, fy1 = py - ty, fy0 = ty + 1 - py;
+    const size_t p00 = (size_t)ty * W + tx, p01 = p00 + 1, p10 = p00 + W, p11 = p10 + 1;
+    const double val = ((depth[p00] * fy0 * fx0 + depth[p01] * fx1 * fy0) + depth[p10] * fy1 * fx0) + depth[p11] * fx1 * fy1;
+    double nn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        nn[a] = ((normal[p00 * 3 + a] * fy0 * fx0 + normal[p01 * 3 + a] * fx1 * fy0) + normal[p10 * 3 + a] * fy1 * fx0) +
+                normal[p11 * 3 + a] * fx1 * fy1;
+    const double nl = rp_norm3(nn[0], nn[1], nn[2]);
+    nn_out[(size_t)k * 3 + 0] = nn[0] / nl; nn_out[(size_t)k * 3 + 1] = nn[1] / nl; nn_out[(size_t)k * 3 + 2] = nn[2] / nl;
+    const int slot = (int)floor(px / h);
+    const double ystp = (0.5 - py / h) * 2, xstp = ((px - slot * h) / h - 0.5) * 2;
+    double ox, oy, oz;
+    face_rot(face_index(dataset, slot), xstp * val, ystp * val, -val, ox, oy, oz);
+    pc[(size_t)k * 3 + 0] = ox; pc[(size_t)k * 3 + 1] = oy; pc[(size_t)k * 3 + 2] = oz;
+}
+
+// rputil.interpolate :43-58 (float32 like torch): feat [c,h,w], pt [k,2] normalised -> out [c,k]
+__global__ void interpolate_kernel(const float* __restrict__ feat, const float* __restrict__ pt, float* __restrict__ out, int c_total,
+                                   int h, int w, int k_total) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= k_total) return;
+    const float x = pt[(size_t)k * 2 + 0] * (float)(w - 1), y = pt[(size_t)k * 2 + 1] * (float)(h - 1);
+    const float x0 = floorf(x), y0 = floorf(y);
+    const int xi = (int)x0, yi = (int)y0;
+    const float wx0 = x0 + 1.0f - x, wy0 = y0 + 1.0f - y, wx1 = x - x0, wy1 = y - y0;
+    for (int c = 0; c < c_total; ++c) {
+        const float* fc = feat + (size_t)c * h * w;
+        const float v00 = fc[(size_t)yi * w + xi], v10 = fc[(size_t)(yi + 1) * w + xi];
+        const float v01 = fc[(size_t)yi * w + xi + 1], v11 = fc[(size_t)(yi + 1) * w + xi + 1];
+        out[(size_t)c * k_total + k] = ((v00 * wx0 * wy0 + v10 * wx0 * wy1) + v01 * wx1 * wy0) + v11 * wx1 * wy1;
     }
 }
 
@@ -493,12 +540,13 @@ int relpose_pose_inverse(const double* pose, double* inv, int32_t n, void* strea
 
 int relpose_sample_primitives(const float* f, int32_t cf, int32_t feat_off, const float* obs_norm, const float* obs_depth,
                               const double* pts, const int32_t* npts, int32_t npts_max, double* pc, double* normal, float* feat,
-                              int32_t n, int32_t h, int32_t mask_method, int32_t dataset, void* stream) {
+                              int32_t n, int32_t h, int32_t mask_method, int32_t compose, int32_t dataset, void* stream) {
     if (!f || !obs_norm || !obs_depth || !pts || !npts || !pc || !normal || !feat || n <= 0 || h <= 0 || npts_max <= 0 ||
-        cf < 7 || feat_off < 7 || feat_off + 32 > cf || mask_method < 0 || mask_method > 1 || dataset < 0 || dataset > 2)
+        cf < 7 || feat_off < 7 || feat_off + 32 > cf || mask_method < 0 || mask_method > 1 || compose < 0 || compose > 1 ||
+        dataset < 0 || dataset > 2)
         return RELPOSE_EINVAL;
     hipLaunchKernelGGL(sample_primitives_kernel, dim3((npts_max + 63) / 64, n), dim3(64), 0, (hipStream_t)stream, f, cf, feat_off,
-                       obs_norm, obs_depth, pts, npts, npts_max, pc, normal, feat, n, h, observed_box(mask_method, h), dataset);
+                       obs_norm, obs_depth, pts, npts, npts_max, pc, normal, feat, n, h, observed_box(mask_method, h), dataset, compose);
     RP_CHECK_LAUNCH();
     return 0;
 }
@@ -508,6 +556,21 @@ int relpose_depth2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, 
     if (!depth || !pc || !valid || n <= 0 || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
     const WarpSrc src = warp_src(dataset, h);
     hipLaunchKernelGGL(depth2pc_kernel, dim3((src.npts + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, depth, pc, valid, n, h, dataset, src);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int relpose_get_pixel(const double* depth, const double* normal, const double* pts, int32_t k, int32_t h, int32_t dataset, double* pc,
+                      double* nn, void* stream) {
+    if (!depth || !normal || !pts || !pc || !nn || k <= 0 || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(get_pixel_kernel, dim3((k + 63) / 64), dim3(64), 0, (hipStream_t)stream, depth, normal, pts, k, h, dataset, pc, nn);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int relpose_interpolate(const float* feat, const float* pt, float* out, int32_t c, int32_t h, int32_t w, int32_t k, void* stream) {
+    if (!feat || !pt || !out || c <= 0 || h < 2 || w < 2 || k <= 0) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(interpolate_kernel, dim3((k + 63) / 64), dim3(64), 0, (hipStream_t)stream, feat, pt, out, c, h, w, k);
     RP_CHECK_LAUNCH();
     return 0;
 }

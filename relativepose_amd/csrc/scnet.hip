@@ -860,6 +860,23 @@ __global__ __launch_bounds__(256) void resize_out_kernel(const float* __restrict
         lin_coef(ox_first, sww, RS, xa, xb, t0, t1);
         lin_coef(ox_last, sww, RS, xc, xd, t0, t1);
         const int sx = xa, width = xd - xa + 1;           // <= RO_MAXW for scale <= 0.4 (224/640 = 0.35)
+        if (width > RO_MAXW || (C & 1)) {
+            // generic shapes (W < ~560: the 64-pixel segment spans more source pixels than the LDS region holds; odd C:
+            // pixel rows are not 8-byte aligned): every lane gathers its 4 taps straight from global memory
+            const int ox = ox_first + lane;
+            if (ox < W) {
+                int x0, x1; float lx0, lx1;
+                lin_coef(ox, sww, RS, x0, x1, lx0, lx1);
+                const float* r0 = x + ((size_t)img * RS + y0) * RS * C;
+                const float* r1 = x + ((size_t)img * RS + y1) * RS * C;
+                const float* a = r0 + (size_t)x0 * C; const float* b = r0 + (size_t)x1 * C;
+                const float* cc = r1 + (size_t)x0 * C; const float* dd = r1 + (size_t)x1 * C;
+                float* o = y + (size_t)img * C * H * W + (size_t)oy * W + ox;
+                for (int c = 0; c < C; ++c)
+                    o[(size_t)c * H * W] = ly0 * (lx0 * a[c] + lx1 * b[c]) + ly1 * (lx0 * cc[c] + lx1 * dd[c]);
+            }
+            continue;
+        }
         const int nf2 = width * C / 2;
         for (int r = 0; r < 2; ++r) {
             const float2* src = reinterpret_cast<const float2*>(x + (((size_t)img * RS + (r ? y1 : y0)) * RS + sx) * C);
@@ -1449,6 +1466,7 @@ int relpose_scnet_set_param(RelposeSCNet* net, const char* key, const float* dat
     if (!net || !key || !data) return RELPOSE_EINVAL;
     net->params[key] = std::vector<float>(data, data + numel);
     net->finalized = false;
+    free_plan(net);                  // cached launch plans hold absolute pointers into the packed-weight blob
     return 0;
 }
 
@@ -1467,6 +1485,7 @@ int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode) {
 
 int relpose_scnet_finalize(RelposeSCNet* net) {
     if (!net) return RELPOSE_EINVAL;
+    free_plan(net);                  // descriptors of an earlier state dict point into the blob that is re-allocated below
     std::vector<float> blob;
     net->layers.clear();
     for (const LayerSpec& sp : layer_specs(net->S)) {

@@ -22,6 +22,9 @@ BUFFER_SHAPES = {"X0": (224, 16), "A1": (224, 192), "A2": (112, 384), "A3": (56,
                  "D7": (7, 512), "D6": (14, 512), "D5": (28, 256), "D4": (56, 128), "D3": (112, 320), "D2": (224, 224)}
 
 
+_REGISTRY = {}          # C handle -> weakref(SCNet): lets torch.ops.relpose.scnet_forward(x, net.handle) find the workspace cache
+
+
 class SCNet:
     def __init__(self, args):
         if not getattr(args, "batchnorm", 1) or not getattr(args, "skipLayer", 1):
@@ -37,10 +40,26 @@ class SCNet:
         self._wss = {}          # one workspace (and launch plan) per (stream, n): streams must not share scratch
         self._ws = None
         self._loaded = False
+        import weakref
+        _REGISTRY[int(self._h)] = weakref.ref(self)
+
+    @property
+    def handle(self):
+        """The RelposeSCNet* as an int: the ``net_handle`` argument of torch.ops.relpose.scnet_forward."""
+        return int(self._h)
+
+    @staticmethod
+    def from_handle(handle):
+        ref = _REGISTRY.get(int(handle))
+        net = ref() if ref is not None else None
+        if net is None:
+            raise RuntimeError(f"relpose: no live SCNet with handle {handle}")
+        return net
 
     def __del__(self):
         try:
             if getattr(self, "_h", None):
+                _REGISTRY.pop(int(self._h), None)
                 _lib.lib().relpose_scnet_destroy(self._h)
                 self._h = None
         except Exception:
@@ -54,8 +73,13 @@ class SCNet:
         return self
 
     def load_state_dict(self, state_dict, strict=True):
+        """Takes the reference's key names (model/mymodel.py:142-257); a ``module.`` prefix (checkpoints saved from a
+        torch.nn.DataParallel wrapper, mainPanoCompletion2view.py:154-156) is stripped.  May be called again with a
+        different state dict (cached launch plans are rebuilt)."""
         L = _lib.lib()
         spec = state_dict_spec(self.snumclass)
+        if any(k.startswith("module.") for k in state_dict):
+            state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         missing = [k for k in spec if k not in state_dict]
         if missing and strict:
             raise RuntimeError(f"Missing key(s) in state_dict: {missing[:4]}...")
@@ -69,6 +93,11 @@ class SCNet:
         _lib.check(L.relpose_scnet_finalize(self._h), "relpose_scnet_finalize")
         self._loaded = True
         return self
+
+    def load_checkpoint(self, path):
+        """evaluation.py:143-153: ``torch.load(path)['state_dict']`` -> load_state_dict."""
+        from .weights import load_checkpoint
+        return self.load_state_dict(load_checkpoint(path))
 
     def set_precision(self, mode):
         """'f32' (default, the parity configuration), 'bf16x3' or 'f16x3' (split 16-bit MFMA products, fp32 accumulation:

@@ -1,0 +1,134 @@
+"""``torch.ops.relpose.*``: the hot path as PyTorch-ROCm custom operators.
+
+north_star / SURVEY.md §8(b): "surfaced to Python as PyTorch-ROCm custom ops so
+evaluation.py / mainPanoCompletion2view.py call them unchanged".  The operator
+schemas are registered with ``torch.library`` for the ``CUDA`` (= HIP) dispatch key
+only; every implementation is a direct call into the C ABI of
+librelpose_hip.so (include/relpose.h) on the CURRENT torch HIP stream, with outputs
+and workspaces allocated through the torch caching allocator.  There is no CPU
+kernel: calling an op with CPU tensors raises torch's "no kernel for backend CPU"
+error (no silent fallback).
+
+    import relativepose_amd.ops            # registers the namespace
+    f = torch.ops.relpose.scnet_forward(x, net.handle)
+    x16 = torch.ops.relpose.warp_pairs_(x16, poses, dataset_id)
+    pc, nrm, feat = torch.ops.relpose.sample_primitives(f, feat_off, obs_n, obs_d, pts, npts, mask_id, compose, dataset_id)
+    pose, status = torch.ops.relpose.match_pairs(pc_s, n_s, f_s, w_s, pc_t, n_t, f_t, w_t, ns, nt, params, topK, method, max_edges)
+
+Operator                    replaces (reference file:line)
+  scnet_forward             SCNet.forward, model/mymodel.py:259-380
+  apply_mask                util.apply_mask, util.py:209-232
+  build_view                evaluation.py:217-230
+  warp / warp_pairs_        util.warping, util.py:94-172 (+ depth2pc, reproj_helper)
+  pano2pc                   util.Pano2PointCloud, util.py:751-811
+  pose_inverse              np.linalg.inv, evaluation.py:235
+  sample_primitives         evaluation.py:246-253 + rputil.getPixel / interpolate
+  affinity_topk             rpmodule.py:342-379
+  match_pairs               RelativePoseEstimation_helper, rpmodule.py:317-508
+"""
+import torch
+
+from . import model as _model
+from . import rpmodule as _rp
+from . import util as _util
+
+_INV_DATASET = {v: k for k, v in _util.DATASETS.items()}
+_INV_MASK = {v: k for k, v in _util.MASKS.items()}
+_INV_METHOD = {v: k for k, v in _rp.METHODS.items()}
+
+_lib = torch.library.Library("relpose", "DEF")
+
+_lib.define("scnet_forward(Tensor x, int net_handle) -> Tensor")
+_lib.define("apply_mask(Tensor x, int method) -> (Tensor, Tensor)")
+_lib.define("build_view(Tensor rgb, Tensor norm, Tensor depth, int method) -> Tensor")
+_lib.define("warp(Tensor view, Tensor pose, int dataset) -> Tensor")
+_lib.define("warp_pairs_(Tensor(a!) x, Tensor pose, int dataset) -> Tensor(a!)")
+_lib.define("pano2pc(Tensor depth, int dataset) -> (Tensor, Tensor)")
+_lib.define("pose_inverse(Tensor pose) -> Tensor")
+_lib.define("sample_primitives(Tensor f, int feat_off, Tensor obs_norm, Tensor obs_depth, Tensor pts, Tensor npts, "
+            "int mask_method, int compose, int dataset) -> (Tensor, Tensor, Tensor)")
+_lib.define("affinity_topk(Tensor feat_s, Tensor weight_s, Tensor feat_t, Tensor weight_t, Tensor ns, Tensor nt, "
+            "float[] params, int topK, bool want_wij) -> (Tensor, Tensor, Tensor, Tensor)")
+_lib.define("match_pairs(Tensor pc_s, Tensor normal_s, Tensor feat_s, Tensor weight_s, Tensor pc_t, Tensor normal_t, "
+            "Tensor feat_t, Tensor weight_t, Tensor ns, Tensor nt, float[] params, int topK, int method, int max_edges) "
+            "-> (Tensor, Tensor)")
+
+PARAM_ORDER = ("distThre", "distSepThre", "angleThre", "sigmaAngle1", "sigmaAngle2", "sigmaDist", "sigmaFeat", "mu")
+
+
+def params_list(para):
+    """rputil.opts -> the float[] the matcher ops take (PARAM_ORDER)."""
+    return [float(getattr(para, k)) for k in PARAM_ORDER]
+
+
+def _para(params, topK, method=0):
+    p = _rp.opts()
+    if len(params) != len(PARAM_ORDER):
+        raise RuntimeError(f"relpose: params must hold {PARAM_ORDER}")
+    for k, v in zip(PARAM_ORDER, params):
+        setattr(p, k, float(v))
+    p.topK = int(topK)
+    if int(method) not in _INV_METHOD:
+        raise Exception("unknown method!")
+    p.method = _INV_METHOD[int(method)]
+    return p
+
+
+def _scnet_forward(x, net_handle):
+    net = _model.SCNet.from_handle(net_handle)
+    return net.forward(x)
+
+
+def _apply_mask(x, method):
+    y = x.contiguous().clone()
+    y, m = _util.apply_mask_dev(y, _INV_MASK[int(method)])
+    return y, m
+
+
+def _build_view(rgb, norm, depth, method):
+    return _util.build_view_dev(rgb, norm, depth, _INV_MASK[int(method)])
+
+
+def _warp(view, pose, dataset):
+    return _util.warping_dev(view.contiguous(), pose.contiguous(), _INV_DATASET[int(dataset)])
+
+
+def _warp_pairs_(x, pose, dataset):
+    return _util.warp_pairs_dev(x, pose.contiguous(), _INV_DATASET[int(dataset)])
+
+
+def _pano2pc(depth, dataset):
+    return _util.pano2pc_dev(depth, _INV_DATASET[int(dataset)])
+
+
+def _pose_inverse(pose):
+    return _util.pose_inverse_dev(pose.contiguous())
+
+
+def _sample_primitives(f, feat_off, obs_norm, obs_depth, pts, npts, mask_method, compose, dataset):
+    return _util.sample_primitives_dev(f.contiguous(), int(feat_off), obs_norm.contiguous(), obs_depth.contiguous(), pts.contiguous(),
+                                       npts.contiguous(), _INV_MASK[int(mask_method)], _INV_DATASET[int(dataset)], int(compose))
+
+
+def _affinity_topk(feat_s, weight_s, feat_t, weight_t, ns, nt, params, topK, want_wij):
+    wij, cj, cw, keff = _rp.affinity_topk(feat_s.contiguous(), weight_s.contiguous(), feat_t.contiguous(), weight_t.contiguous(),
+                                          ns.contiguous(), nt.contiguous(), _para(params, topK), want_wij=bool(want_wij))
+    if wij is None:
+        wij = feat_s.new_empty(0)
+    return wij, cj, cw, keff
+
+
+def _match_pairs(pc_s, normal_s, feat_s, weight_s, pc_t, normal_t, feat_t, weight_t, ns, nt, params, topK, method, max_edges):
+    c = lambda t: t.contiguous()
+    res = _rp.match_pairs(c(pc_s), c(normal_s), c(feat_s), c(weight_s), c(pc_t), c(normal_t), c(feat_t), c(weight_t), c(ns), c(nt),
+                          _para(params, topK, method), max_edges=int(max_edges))
+    return res.pose, res.status
+
+
+for _name, _fn in (("scnet_forward", _scnet_forward), ("apply_mask", _apply_mask), ("build_view", _build_view), ("warp", _warp),
+                   ("warp_pairs_", _warp_pairs_), ("pano2pc", _pano2pc), ("pose_inverse", _pose_inverse),
+                   ("sample_primitives", _sample_primitives), ("affinity_topk", _affinity_topk), ("match_pairs", _match_pairs)):
+    _lib.impl(_name, _fn, "CUDA")
+
+OPS = ("scnet_forward", "apply_mask", "build_view", "warp", "warp_pairs_", "pano2pc", "pose_inverse", "sample_primitives",
+       "affinity_topk", "match_pairs")

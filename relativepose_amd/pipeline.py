@@ -20,20 +20,21 @@ class RelativePosePipeline:
     _chain_nets = False
     _net_stream = None
 
-    def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0):
+    def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0, compose=0):
         self.net = net
         self.dataset = dataset
         self.mask_method = mask_method
         self.alter_steps = alter_steps
         self.completion = completion
         self.max_edges = max_edges
+        self.compose = compose          # 0: evaluation.py:250-251 (the driver), 1: rpmodule.py:633-634 (the library loop)
         if sigmas is None:
             o = rpmodule.opts()
             sigmas = [[o.sigmaAngle1, o.sigmaAngle2, o.sigmaDist, o.sigmaFeat]] * alter_steps
         self.sigmas = np.asarray(sigmas, dtype=np.float64).reshape(-1, 4)
         self.feat_off = 7 + net.snumclass
 
-    def prepare(self, rgb, norm, depth, pts, ptw, device):
+    def prepare(self, rgb, norm, depth, pts, ptw, device, keep_host=False):
         """Host arrays (dataset dict layout: rgb/norm [B,2,3,h,4h], depth [B,2,h,4h] f32; pts [B,2,N,2],
         ptw [B,2,N] f64) -> device-resident state.  Not part of the timed region."""
         import torch
@@ -63,7 +64,23 @@ class RelativePosePipeline:
         st["ns"] = t(npts[:, 0], torch.int32)
         st["nt"] = t(npts[:, 1], torch.int32)
         st["eye"] = torch.eye(4, dtype=torch.float64, device=device).repeat(B, 1, 1).contiguous()
+        if keep_host:      # pinned host copies of the per-batch inputs, for upload_inputs (PCIe-inclusive timing)
+            st["host"] = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dt).pin_memory() for k, a, dt in (
+                ("rgb", rgb.reshape(2 * B, 3, h, w), torch.float32), ("norm", norm.reshape(2 * B, 3, h, w), torch.float32),
+                ("depth", depth.reshape(2 * B, h, w), torch.float32), ("pts", pts.reshape(2 * B, N, 2), torch.float64))}
         return st
+
+    @staticmethod
+    def upload_inputs(st, copy_stream):
+        """Re-upload the batch's panoramas + keypoints from pinned host memory on `copy_stream` (async), ordered after
+        the previous use of the device buffers and before the batch's next use (both on st["stream"])."""
+        import torch
+        ms = st["stream"] if "stream" in st else torch.cuda.current_stream()
+        copy_stream.wait_stream(ms)
+        with torch.cuda.stream(copy_stream):
+            for k, src in st["host"].items():
+                st[k].copy_(src, non_blocking=True)
+        ms.wait_stream(copy_stream)
 
     def run_interleaved(self, states):
         """Several prepared batches software-pipelined on their own HIP streams: the SCNet forwards are chained
@@ -105,16 +122,20 @@ class RelativePosePipeline:
             self._net_stream = torch.cuda.Stream()
         self._net_stream.wait_stream(torch.cuda.current_stream())
 
-    def run_pipelined(self, states, steps, on_result=None):
-        """`steps` consecutive batches through the hot path with len(states) of them in flight (a serving loop):
-        batch k uses the prepared buffers and the HIP stream of states[k % depth].  SCNet forwards are chained by
-        events exactly as in `run_interleaved`, so while batch k is in its launch-bound matcher phase the GPU
-        runs the SCNet forward of batch k+1 -- both at the FULL batch size (splitting one batch over streams
-        halves the SCNet batch and costs ~13 % conv efficiency).  on_result(k, pose, status) -> value is called
-        on the caller's stream as soon as batch k is complete.  Returns the per-batch results in order."""
+    def run_pipelined(self, states, steps, on_result=None, depth=None, before_batch=None):
+        """`steps` consecutive batches through the hot path with `depth` of them in flight (a serving loop;
+        default depth = len(states)): batch k uses the prepared buffers and the HIP stream of
+        states[k % len(states)], so with more prepared states than batches in flight the loop rotates through
+        distinct inputs.  SCNet forwards are chained by events exactly as in `run_interleaved`, so while batch k
+        is in its launch-bound matcher phase the GPU runs the SCNet forward of batch k+1 -- both at the FULL
+        batch size (splitting one batch over streams halves the SCNet batch and costs ~13 % conv efficiency).
+        before_batch(k, state) is called (under the state's stream) right before batch k is started -- the
+        bench uploads the batch's inputs there.  on_result(k, pose, status) -> value is called on the caller's
+        stream as soon as batch k is complete.  Returns the per-batch results in order."""
         import torch
         cur = torch.cuda.current_stream()
-        depth = len(states)
+        nst = len(states)
+        depth = nst if depth is None else max(1, min(depth, nst))
         self._chain_nets = depth > 1
         self._ensure_net_stream()
         for st in states:
@@ -126,13 +147,17 @@ class RelativePosePipeline:
         while nxt < steps or live:
             for slot in range(depth):
                 if slot not in live and nxt < steps:
-                    live[slot] = (nxt, self._run_gen(states[slot]))
+                    st = states[nxt % nst]
+                    if before_batch is not None:
+                        with torch.cuda.stream(st["stream"]):
+                            before_batch(nxt, st)
+                    live[slot] = (nxt, st, self._run_gen(st))
                     nxt += 1
                 if slot not in live:
                     continue
-                k, gen = live[slot]
+                k, st, gen = live[slot]
                 done = None
-                with torch.cuda.stream(states[slot]["stream"]):
+                with torch.cuda.stream(st["stream"]):
                     try:
                         next(gen)
                     except StopIteration as e:
@@ -141,7 +166,7 @@ class RelativePosePipeline:
                     del live[slot]
                     pose, status = done[0], done[1]
                     if on_result is not None:
-                        cur.wait_stream(states[slot]["stream"])
+                        cur.wait_stream(st["stream"])
                         pose.record_stream(cur); status.record_stream(cur)
                         results[k] = on_result(k, pose, status)
                     else:
@@ -184,11 +209,12 @@ class RelativePosePipeline:
                     done = torch.cuda.Event()
                     done.record()
                 ms.wait_event(done)
+                f.record_stream(ms)        # allocated under the net stream, consumed on the batch stream
                 yield                                            # one yield per level: the other batches enqueue theirs
             else:
                 f = self.net(x)
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
-                                                    self.mask_method, self.dataset)
+                                                    self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
             para = rpmodule.opts(*self.sigmas[min(step, len(self.sigmas) - 1)])
             res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), st["w_s"],
@@ -215,7 +241,7 @@ class RelativePosePipeline:
             util.warp_pairs_dev(x, poses, self.dataset)       # x[:, 8:] = partner view warped by the pose estimate
             f = self.net(x)
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
-                                                    self.mask_method, self.dataset)
+                                                    self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
             para = rpmodule.opts(*self.sigmas[min(step, len(self.sigmas) - 1)])
             res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), st["w_s"],

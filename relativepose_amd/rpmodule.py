@@ -5,7 +5,15 @@ rputil.py for the hot-path entry points:
 
   opts                               rputil.py:11-22
   RelativePoseEstimation_helper      rpmodule.py:317   (numpy dicts in, 4x4 numpy out)
+  getMatchingPrimitive               rpmodule.py:511   (completed-scan dicts -> keypoint primitives)
+  RelativePoseEstimation             rpmodule.py:540   (getMatchingPrimitive + helper)
+  RelativePoseEstimationViaCompletion rpmodule.py:569  (the recurrent completion / matching loop for one scan pair)
   match_pairs                        batched device API the helper is built on
+
+Keypoint DETECTION (rputil.getKeypoint / getKeypoint_kinect: cv2 SIFT + feature-guided + random sampling,
+rputil.py:141-353) is not part of this build (third-party OpenCV-contrib, RNG driven).  The
+shims call a *keypoint provider* with the reference's own getKeypoint signature instead; install one with
+``set_keypoint_provider`` -- e.g. the reference's getKeypoint itself, or ``fixed_keypoints(...)`` for injected points.
 
 Degenerate inputs return identity like the reference; status codes say why.
 """
@@ -105,20 +113,26 @@ def match_pairs(pc_s, n_s, f_s, w_s, pc_t, n_t, f_t, w_t, ns, nt, para, debug=Fa
     return res
 
 
-def affinity_topk(f_s, w_s, f_t, w_t, ns, nt, para, want_wij=True):
-    """Stage A+B only (rpmodule.py:342-379): returns (wij or None, corres_j, corres_w, k_eff)."""
+def affinity_topk_buffers(B, ns_max, nt_max, topK, dev, want_wij=True):
+    """Output buffers of affinity_topk (zero-filled: padded rows / columns are never written)."""
     import torch
+    wij = torch.zeros(B, ns_max, nt_max, dtype=torch.float32, device=dev) if want_wij else None
+    cj = torch.zeros(B, ns_max, topK, dtype=torch.int32, device=dev)
+    cw = torch.zeros(B, ns_max, topK, dtype=torch.float64, device=dev)
+    keff = torch.zeros(B, dtype=torch.int32, device=dev)
+    return wij, cj, cw, keff, torch.zeros(1, dtype=torch.float64, device=dev)
+
+
+def affinity_topk(f_s, w_s, f_t, w_t, ns, nt, para, want_wij=True, out=None):
+    """Stage A+B only (rpmodule.py:342-379): returns (wij or None, corres_j, corres_w, k_eff).
+    out = affinity_topk_buffers(...) reuses output buffers (back-to-back launches without allocator calls)."""
     dev = _lib.require_gpu()
     L = _lib.lib()
     B, ns_max, nt_max = f_s.shape[0], f_s.shape[1], f_t.shape[1]
     p = _c_params(para)
-    dummy = torch.zeros(1, dtype=torch.float64, device=dev)
+    wij, cj, cw, keff, dummy = out if out is not None else affinity_topk_buffers(B, ns_max, nt_max, p.topK, dev, want_wij)
     kp = _lib.Keypoints(B, ns_max, nt_max, _lib.ptr(ns), _lib.ptr(nt), _lib.ptr(dummy), _lib.ptr(dummy), _lib.ptr(f_s), _lib.ptr(w_s),
                         _lib.ptr(dummy), _lib.ptr(dummy), _lib.ptr(f_t), _lib.ptr(w_t))
-    wij = torch.zeros(B, ns_max, nt_max, dtype=torch.float32, device=dev) if want_wij else None
-    cj = torch.zeros(B, ns_max, p.topK, dtype=torch.int32, device=dev)
-    cw = torch.zeros(B, ns_max, p.topK, dtype=torch.float64, device=dev)
-    keff = torch.zeros(B, dtype=torch.int32, device=dev)
     rc = L.relpose_affinity_topk(C.byref(p), C.byref(kp), _lib.ptr(wij), _lib.ptr(cj), _lib.ptr(cw), _lib.ptr(keff), _lib.stream_ptr())
     _lib.check(rc, "relpose_affinity_topk")
     return wij, cj, cw, keff
@@ -153,3 +167,143 @@ def RelativePoseEstimation_helper(dataS, dataT, para):
     dev = _lib.require_gpu()
     res = match_pairs(*pack_keypoints([(dataS, dataT)], dev), para)
     return res.pose[0].cpu().numpy()
+
+
+# ---- keypoint provider hook -------------------------------------------------------------------------------------
+_keypoint_provider = None
+
+
+def set_keypoint_provider(fn):
+    """fn(rgbS, rgbT, featS, featT[, rgb_fullS, rgb_fullT]) -> (pts, ptsNorm, ptsW, ptt, pttNorm, pttW): the signature
+    of the reference's rputil.getKeypoint (:141) / getKeypoint_kinect (:240).  pts [k,2] pixel coords (x,y),
+    ptsNorm = pts / (W,H), ptsW in {1, .99}.  Returns the previous provider."""
+    global _keypoint_provider
+    old, _keypoint_provider = _keypoint_provider, fn
+    return old
+
+
+def fixed_keypoints(pts, ptsW, ptt, pttW):
+    """Provider that injects given keypoints (what the parity tests and the bench use)."""
+    pts, ptt = np.asarray(pts, dtype=np.float64), np.asarray(ptt, dtype=np.float64)
+
+    def provider(rgbS, rgbT, featS, featT, *rest):
+        H, W = featS.shape[1], featS.shape[2]
+        return pts, pts / np.array([W, H], dtype=np.float64), np.asarray(ptsW), ptt, ptt / np.array([W, H], dtype=np.float64), np.asarray(pttW)
+    return provider
+
+
+def getKeypoint(rgbS, rgbT, featS, featT, *rest):
+    if _keypoint_provider is None:
+        raise RuntimeError("relativepose_amd: keypoint detection (cv2 SIFT, rputil.getKeypoint) is not part of this build; "
+                           "install a provider with rpmodule.set_keypoint_provider(fn)")
+    return _keypoint_provider(rgbS, rgbT, featS, featT, *rest)
+
+
+getKeypoint_kinect = getKeypoint
+
+
+def getMatchingPrimitive(dataS, dataT, dataset, representation, doCompletion):
+    """rpmodule.py:511-538, same signature and return value: dataS/dataT hold 'rgb' [h,4h,3] u8, 'normal' [h,4h,3],
+    'depth' [h,4h] (numpy) and 'feat' [32,h,4h] (torch) of the completed scans; returns
+    (pts3d [3,k], ptt3d [3,k'], ptsns [k,3], ptsnt [k',3], dess [k,32], dest [k',32], ptsW, pttW) or 8 x None."""
+    import torch
+    from . import rputil
+    if 'suncg' in dataset or 'matterport' in dataset:
+        kp = getKeypoint(dataS['rgb'], dataT['rgb'], dataS['feat'], dataT['feat'])
+    elif 'scannet' in dataset:
+        kp = getKeypoint_kinect(dataS['rgb'], dataT['rgb'], dataS['feat'], dataT['feat'], dataS.get('rgb_full'), dataT.get('rgb_full'))
+    else:
+        raise ValueError(f"unknown dataset {dataset}")
+    pts, ptsNorm, ptsW, ptt, pttNorm, pttW = kp
+    if pts is None or ptt is None or pts.shape[1] < 2 or ptt.shape[1] < 2:          # rpmodule.py:522-523
+        return None, None, None, None, None, None, None, None
+    pts3d, ptsns = rputil.getPixel(dataS['depth'], dataS['normal'], pts, dataset=dataset, representation=representation)
+    ptt3d, ptsnt = rputil.getPixel(dataT['depth'], dataT['normal'], ptt, dataset=dataset, representation=representation)
+    v = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()                  # torch_op.v: float32
+    dess = rputil.interpolate(dataS['feat'], v(ptsNorm)).cpu().numpy().T
+    dest = rputil.interpolate(dataT['feat'], v(pttNorm)).cpu().numpy().T
+    ptsW, pttW = np.asarray(ptsW), np.asarray(pttW)
+    if not doCompletion:                                                             # rpmodule.py:534-537
+        pts3d, ptsns, dess, ptsW = pts3d[:, ptsW == 1], ptsns[ptsW == 1], dess[ptsW == 1], ptsW[ptsW == 1]
+        ptt3d, ptsnt, dest, pttW = ptt3d[:, pttW == 1], ptsnt[pttW == 1], dest[pttW == 1], pttW[pttW == 1]
+    return pts3d, ptt3d, ptsns, ptsnt, dess, dest, ptsW, pttW
+
+
+def RelativePoseEstimation(dataS, dataT, para, dataset, representation, maskMethod, doCompletion=True, index=None):
+    """rpmodule.py:540-567, same signature: keypoint primitives of two completed scans -> 4x4 pose (identity when
+    too few keypoints are found)."""
+    R_hat = np.eye(4)
+    pts3d, ptt3d, ptsns, ptsnt, dess, dest, ptsW, pttW = getMatchingPrimitive(dataS, dataT, dataset, representation, doCompletion)
+    if pts3d is None or ptt3d is None or pts3d.shape[0] < 2:                         # rpmodule.py:557 (sic: tests shape[0] == 3)
+        return R_hat
+    return RelativePoseEstimation_helper({'pc': pts3d.T, 'normal': ptsns, 'feat': dess, 'weight': ptsW},
+                                         {'pc': ptt3d.T, 'normal': ptsnt, 'feat': dest, 'weight': pttW}, para)
+
+
+def RelativePoseEstimationViaCompletion(net, data_s, data_t, args):
+    """rpmodule.py:569-662, same signature: alternate scan completion and pairwise matching for ONE scan pair.
+    data_s/data_t: 'rgb' [h,4h,3], 'norm' [h,4h,3], 'depth' [h,4h] numpy (HWC like the reference).  args needs
+    snumclass, featureDim, outputType, maskMethod, alterStep, dataset, para (an opts whose four sigmas are per-step
+    sequences), representation, completion.  The loop stays on the device: warp -> SCNet -> compose + sample -> match;
+    only the keypoint provider sees host data (rgb u8 + the feature maps as CUDA tensors), once per alternation like
+    the reference's getKeypoint call.  Output composition follows THIS function (normal / (|normal| + 1e-12),
+    :633-634), not evaluation.py's variant."""
+    import copy
+
+    import torch
+    from . import util
+    dev = _lib.require_gpu()
+    if args.outputType != 'rgbdnsf':
+        raise NotImplementedError("only outputType='rgbdnsf' is built")
+    args.idx_f_start = 3 + 3 + 1 + args.snumclass                                   # rpmodule.py:583-593
+    args.idx_f_end = args.idx_f_start + args.featureDim
+    assert args.featureDim == 32
+    h = data_s['depth'].shape[0]
+    chw = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32).transpose(2, 0, 1)))
+    rgb = torch.stack((chw(data_s['rgb']), chw(data_t['rgb']))).to(dev)
+    nrm = torch.stack((chw(data_s['norm']), chw(data_t['norm']))).to(dev)
+    dep = torch.from_numpy(np.stack((np.asarray(data_s['depth'], dtype=np.float32), np.asarray(data_t['depth'], dtype=np.float32)))).to(dev)
+    view = util.build_view_dev(rgb, nrm, dep, args.maskMethod)                       # apply_mask + valid channel (:603-613)
+    x = torch.empty(2, 16, h, 4 * h, dtype=torch.float32, device=dev)
+    x[:, :8].copy_(view)
+    m_dev = util.apply_mask_dev(torch.ones(2, 1, h, 4 * h, dtype=torch.float32, device=dev), args.maskMethod)[1]
+    m_np = m_dev[:, 0].cpu().numpy()[..., None]
+    rgb_u8 = [(m_np[v] * np.asarray(d['rgb']) * 255).astype('uint8') for v, d in enumerate((data_s, data_t))]     # :640-641
+    R_hat = np.eye(4)
+    for alter_ in range(args.alterStep):
+        R_dev = torch.from_numpy(np.ascontiguousarray(R_hat, dtype=np.float64)[None]).to(dev)
+        poses = torch.cat((util.pose_inverse_dev(R_dev), R_dev)).contiguous()       # image 0 gets t2s (inv R), image 1 gets s2t (R)
+        util.warp_pairs_dev(x, poses, args.dataset)
+        f = net(x)
+        feats = [f[v, args.idx_f_start:args.idx_f_end] for v in range(2)]
+        if 'scannet' in args.dataset:
+            kp = getKeypoint_kinect(rgb_u8[0], rgb_u8[1], feats[0], feats[1],
+                                    (np.asarray(data_s['rgb_full']) * 255).astype('uint8') if 'rgb_full' in data_s else None,
+                                    (np.asarray(data_t['rgb_full']) * 255).astype('uint8') if 'rgb_full' in data_t else None)
+        else:
+            kp = getKeypoint(rgb_u8[0], rgb_u8[1], feats[0], feats[1])
+        pts, _, ptsW, ptt, _, pttW = kp
+        if pts is None or ptt is None or pts.shape[1] < 2 or ptt.shape[1] < 2:
+            R_hat = np.eye(4)                                                        # RelativePoseEstimation's early return (:557-559)
+            continue
+        ptsW, pttW = np.asarray(ptsW, dtype=np.float64), np.asarray(pttW, dtype=np.float64)
+        if not args.completion:
+            pts, ptsW = pts[ptsW == 1], ptsW[ptsW == 1]
+            ptt, pttW = ptt[pttW == 1], pttW[pttW == 1]
+        N = max(len(pts), len(ptt), 1)
+        P = np.zeros((2, N, 2)); P[0, :len(pts)] = pts; P[1, :len(ptt)] = ptt
+        Wt = np.zeros((2, N)); Wt[0, :len(pts)] = ptsW; Wt[1, :len(ptt)] = pttW
+        npts = torch.tensor([len(pts), len(ptt)], dtype=torch.int32, device=dev)
+        pc, nn, ft = util.sample_primitives_dev(f, args.idx_f_start, nrm, dep, torch.from_numpy(P).to(dev), npts, args.maskMethod,
+                                                args.dataset, compose=1)
+        para_this = copy.copy(args.para)
+        para_this.sigmaAngle1 = args.para.sigmaAngle1[alter_]
+        para_this.sigmaAngle2 = args.para.sigmaAngle2[alter_]
+        para_this.sigmaDist = args.para.sigmaDist[alter_]
+        para_this.sigmaFeat = args.para.sigmaFeat[alter_]
+        Wd = torch.from_numpy(Wt).to(dev)
+        res = match_pairs(pc[0:1].contiguous(), nn[0:1].contiguous(), ft[0:1].contiguous(), Wd[0:1].contiguous(),
+                          pc[1:2].contiguous(), nn[1:2].contiguous(), ft[1:2].contiguous(), Wd[1:2].contiguous(),
+                          npts[0:1].contiguous(), npts[1:2].contiguous(), para_this)
+        R_hat = res.pose[0].cpu().numpy()
+    return R_hat

@@ -1,6 +1,12 @@
-"""Host-side mirror of the keypoint-augmentation pieces of the reference's rputil.py that are
-deterministic functions: the descriptor-to-map distance of getKeypoint (:182-190) and
-``Sampling`` (:355-371).  SIFT detection and the random selection around them stay with the caller."""
+"""Host-side mirror of the reference's RPModule/rputil.py, backed by the HIP library:
+
+  opts            rputil.py:11-22      (re-exported from rpmodule)
+  interpolate     rputil.py:43-58      bilinear descriptor sampling
+  getPixel        rputil.py:88-119     bilinear depth / normal sampling + unprojection
+  Sampling        rputil.py:355-371    NMS keypoint sampling on distance maps
+  feature_distance_map_dev             the descriptor-to-map distance of getKeypoint :182-190
+
+SIFT detection (getKeypoint's cv2 part) is not built: see rpmodule.set_keypoint_provider."""
 import numpy as np
 
 from . import _lib
@@ -34,3 +40,42 @@ def Sampling(heatmap, K):
     import torch
     dev = _lib.require_gpu()
     return sampling_dev(torch.from_numpy(np.ascontiguousarray(heatmap, dtype=np.float32)).to(dev), K).cpu().numpy()
+
+
+def interpolate(feat, pt):
+    """rputil.py:43-58, same signature: feat torch [c,h,w] float32, pt torch [k,2] normalised (x/W, y/H) -> torch [c,k]
+    (on the GPU; CPU tensors are uploaded, like torch_op.v does in the reference)."""
+    import torch
+    dev = _lib.require_gpu()
+    f = feat.to(dev, torch.float32).contiguous()
+    p = pt.to(dev, torch.float32).contiguous()
+    c, h, w = f.shape
+    k = p.shape[0]
+    out = torch.empty(c, k, dtype=torch.float32, device=dev)
+    if k:
+        _lib.check(_lib.lib().relpose_interpolate(_lib.ptr(f), _lib.ptr(p), _lib.ptr(out), c, h, w, k, _lib.stream_ptr()),
+                   "relpose_interpolate")
+    return out
+
+
+def getPixel(depth, normal, pts, dataset='suncg', representation='skybox'):
+    """rputil.py:88-119, same signature: depth numpy [h,4h], normal numpy [h,4h,3], pts numpy [k,2] pixel coords
+    (x <= 4h-2, y <= h-2) -> (pc [3,k], nn [k,3]) float64 numpy."""
+    import torch
+    from .util import dataset_id
+    assert representation == 'skybox'                                    # rputil.py:62
+    depth = np.ascontiguousarray(depth, dtype=np.float64)
+    normal = np.ascontiguousarray(normal, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    h = depth.shape[0]
+    assert depth.shape[1] == 4 * h and normal.shape == (h, 4 * h, 3)    # the reference asserts 160 x 640 (:63-64)
+    k = pts.shape[0]
+    if k == 0:
+        return np.zeros((3, 0)), np.zeros((0, 3))
+    dev = _lib.require_gpu()
+    d, n, p = (torch.from_numpy(a).to(dev) for a in (depth, normal, pts))
+    pc = torch.empty(k, 3, dtype=torch.float64, device=dev)
+    nn = torch.empty(k, 3, dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().relpose_get_pixel(_lib.ptr(d), _lib.ptr(n), _lib.ptr(p), k, h, dataset_id(dataset), _lib.ptr(pc), _lib.ptr(nn),
+                                            _lib.stream_ptr()), "relpose_get_pixel")
+    return pc.cpu().numpy().T, nn.cpu().numpy()

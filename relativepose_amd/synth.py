@@ -51,15 +51,18 @@ def _texture(p):
     return (0.5 + 0.5 * f).astype(np.float32)
 
 
-def render_room(rs, dataset="suncg", hole_frac=0.0, h=H):
+def render_room(rs, dataset="suncg", hole_frac=0.0, h=H, poses=None, half=None):
     """One scan pair of a box room: returns rgb[2,3,h,4h], norm[2,3,h,4h],
-    depth[2,h,4h] (float32) and poses R[2,4,4] (camera-to-world)."""
-    half = rs.uniform(1.5, 4.0, 3)
-    poses = []
-    for _ in range(2):
-        T = random_rigid(rs, np.pi, 1.0)
-        T[:3, 3] = np.clip(T[:3, 3], -0.6 * half, 0.6 * half)
-        poses.append(T)
+    depth[2,h,4h] (float32) and poses R[2,4,4] (camera-to-world).  ``poses`` / ``half``
+    (optional) fix the two camera poses / the room half-extents instead of drawing them."""
+    if half is None:
+        half = rs.uniform(1.5, 4.0, 3)
+    if poses is None:
+        poses = []
+        for _ in range(2):
+            T = random_rigid(rs, np.pi, 1.0)
+            T[:3, 3] = np.clip(T[:3, 3], -0.6 * half, 0.6 * half)
+            poses.append(T)
     rgb = np.zeros((2, 3, h, 4 * h), np.float32)
     nrm = np.zeros((2, 3, h, 4 * h), np.float32)
     dep = np.zeros((2, h, 4 * h), np.float32)
@@ -175,3 +178,62 @@ def make_match_case(N, seed, inlier=0.6, noise=0.005, Nt=None):
     S = {"pc": P, "normal": n, "feat": f, "weight": ws}
     Tt = {"pc": Pt, "normal": nt, "feat": ft, "weight": wt}
     return S, Tt, T
+
+
+# ---- well-conditioned scan pair (tests/golden "wc" fixtures) ---------------------------------------------------
+def _ray_box(half, T, dataset, slot, px, py, h):
+    """World points hit by the rays of sub-pixel panorama coords (px, py) of face ``slot`` (camera pose T)."""
+    xn, yn = ((px - slot * h) / h - 0.5) * 2, (0.5 - py / h) * 2
+    d_w = (np.stack([xn, yn, -np.ones_like(xn)], -1) @ face_rotation(dataset, slot).T) @ T[:3, :3].T
+    tw = T[:3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = np.where(d_w > 0, (half - tw) / d_w, (-half - tw) / d_w)
+    s[~np.isfinite(s)] = np.inf
+    return tw + s.min(-1)[:, None] * d_w
+
+
+def _project(P_w, T, dataset, slot, h):
+    """Sub-pixel panorama coords of world points in face ``slot`` of the camera with pose T (+ in-frustum flag)."""
+    q = ((P_w - T[:3, 3]) @ T[:3, :3]) @ face_rotation(dataset, slot)
+    z = -q[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xs, ys = q[:, 0] / z, q[:, 1] / z
+    return (xs / 2 + 0.5) * h + slot * h, (0.5 - ys / 2) * h, (z > 0) & (np.abs(xs) < 1) & (np.abs(ys) < 1)
+
+
+def make_wc_pair(seed, n_match=150, n_free=50, angle=0.2, shift=0.25, h=H, margin=14.0):
+    """A scan pair on which the recurrent loop is WELL-CONDITIONED (SUNCG conventions, 'second' mask): the two
+    cameras differ by a small rigid motion so that their observed faces see the same walls; ``n_match`` keypoints
+    are the projections of common world points into BOTH observed faces (sub-pixel coordinates), ``n_free`` more
+    per view are unrelated; all lie in the observed region (weight 1).  With a network whose descriptors follow
+    the view-invariant wall texture (weights.make_descriptor_state_dict) the true correspondences dominate the
+    matching graph.  Returns (data dict like make_pairs, pts [1,2,N,2], ptw [1,2,N], T_rel 4x4 source->target)."""
+    rs = np.random.RandomState(seed)
+    dataset = "suncg"
+    half = rs.uniform(2.0, 3.5, 3)
+    T0 = random_rigid(rs, np.pi, 0.3)
+    dT = random_rigid(rs, angle, shift)
+    T1 = T0 @ dT
+    rgb, nrm, dep, poses = render_room(rs, dataset, 0.0, h, poses=[T0, T1], half=half)
+    N = n_match + n_free
+    pts = np.zeros((1, 2, N, 2))
+    lo, hi_x, hi_y = margin, h - margin, h - margin
+    got = 0
+    while got < n_match:
+        px = rs.uniform(h + lo, h + hi_x, 4 * n_match)
+        py = rs.uniform(lo, hi_y, 4 * n_match)
+        Pw = _ray_box(half, T0, dataset, 1, px, py, h)
+        tx, ty, ok = _project(Pw, T1, dataset, 1, h)
+        ok &= (tx > h + lo) & (tx < h + hi_x) & (ty > lo) & (ty < hi_y)
+        k = min(int(ok.sum()), n_match - got)
+        pts[0, 0, got:got + k, 0], pts[0, 0, got:got + k, 1] = px[ok][:k], py[ok][:k]
+        pts[0, 1, got:got + k, 0], pts[0, 1, got:got + k, 1] = tx[ok][:k], ty[ok][:k]
+        got += k
+    for v in range(2):
+        pts[0, v, n_match:, 0] = rs.uniform(h + lo, h + hi_x, n_free)
+        pts[0, v, n_match:, 1] = rs.uniform(lo, hi_y, n_free)
+    perm = rs.permutation(N)                       # the target list is not in source order
+    pts[0, 1] = pts[0, 1][perm]
+    ptw = np.ones((1, 2, N))
+    data = {"rgb": rgb[None], "norm": nrm[None], "depth": dep[None], "R": poses[None]}
+    return data, pts, ptw, np.linalg.inv(T1) @ T0

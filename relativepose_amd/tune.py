@@ -9,14 +9,7 @@ A cached primitive is the reference's dict (trainRelativePoseModuleRecFD.py:207-
 import numpy as np
 
 from . import _lib, rpmodule
-
-
-def angular_distance_np(R_hat, R):
-    """util.py:176-187 (degrees)."""
-    R_hat = np.asarray(R_hat).reshape(-1, 3, 3)
-    R = np.asarray(R).reshape(-1, 3, 3)
-    tr = np.matmul(R_hat, R.transpose(0, 2, 1)).reshape(len(R), -1)[:, [0, 4, 8]].sum(1)
-    return np.arccos(((tr - 1) / 2).clip(-1, 1)) / np.pi * 180.0
+from .evaluation import angular_distance_np  # noqa: F401  (util.py:176-187)
 
 
 class PrimitiveSet:

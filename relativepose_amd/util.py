@@ -107,9 +107,9 @@ def pano2pc_dev(depth, dataset):
     return pc, valid
 
 
-def sample_primitives_dev(f, feat_off, obs_norm, obs_depth, pts, npts, mask_method, dataset):
+def sample_primitives_dev(f, feat_off, obs_norm, obs_depth, pts, npts, mask_method, dataset, compose=0):
     """f [n,cf,h,4h] net output, obs_norm [n,3,h,4h], obs_depth [n,h,4h] f32, pts [n,N,2] f64, npts [n] i32
-    -> pc [n,N,3] f64, normal [n,N,3] f64, feat [n,N,32] f32."""
+    -> pc [n,N,3] f64, normal [n,N,3] f64, feat [n,N,32] f32.  compose: 0 = evaluation.py:250-251, 1 = rpmodule.py:633-634."""
     import torch
     _lib.require_gpu()
     n, cf, h, w = f.shape
@@ -122,7 +122,7 @@ def sample_primitives_dev(f, feat_off, obs_norm, obs_depth, pts, npts, mask_meth
         assert t.is_contiguous() and t.is_cuda
     rc = _lib.lib().relpose_sample_primitives(_lib.ptr(f), cf, feat_off, _lib.ptr(obs_norm), _lib.ptr(obs_depth), _lib.ptr(pts),
                                               _lib.ptr(npts), N, _lib.ptr(pc), _lib.ptr(nn), _lib.ptr(ft), n, h,
-                                              MASKS[mask_method], dataset_id(dataset), _lib.stream_ptr())
+                                              MASKS[mask_method], int(compose), dataset_id(dataset), _lib.stream_ptr())
     _lib.check(rc, "relpose_sample_primitives")
     return pc, nn, ft
 

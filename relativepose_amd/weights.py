@@ -90,3 +90,42 @@ def make_state_dict(seed=0, snumclass=15):
 
 def num_params(snumclass=15):
     return int(sum(np.prod(s) for s in state_dict_spec(snumclass).values()))
+
+
+def make_descriptor_state_dict(seed=0, snumclass=15):
+    """``make_state_dict`` with the feature head cut down to a LOCAL function of the colour streams: conv4 reads only
+    the own-view and warped-view rgb encoders (normal / depth streams: zero weights), and deconv4 reads only its
+    conv4 skip input (the deep conv5..deconv5 path: zero weights).  On the synthetic rooms (view-invariant wall
+    texture) the 32-d descriptors then agree for the same world point seen from two nearby cameras, which makes the
+    matching problem of tests/golden "wc" fixtures well-conditioned.  Every layer still runs; only values change."""
+    sd = make_state_dict(seed, snumclass)
+    g = NGF
+    w = sd["conv4.0.weight"]                     # [256, 768, 4, 4]; inputs: rgb, rgb_t2s, n, n_t2s, d, d_t2s (128 each)
+    w[:, 2 * 2 * g:] = 0
+    w[:, :2 * 2 * g] *= np.float32(np.sqrt(3.0))
+    w = sd["deconv4.0.weight"]                   # [512, 128, 4, 4]; inputs: deconv5 output (256), conv4 skip (256)
+    w[:4 * g] = 0
+    # the three stride-2 transposed convs of the feature path become (bilinear x2 upsampling) o (random channel mix):
+    # random 4x4 taps would give every output-pixel parity its own filter, i.e. a descriptor that depends on the pixel
+    # position modulo 8 more than on the surface it sees
+    u = np.array([0.25, 0.75, 0.75, 0.25], np.float32)
+    for key in ("deconv4.0.weight", "deconv3f.0.weight", "deconv2f.0.weight"):
+        w = sd[key]
+        mix = w[:, :, 1, 1] * np.float32(4.0)
+        w[...] = mix[:, :, None, None] * (u[:, None] * u[None, :])[None, None]
+    return sd
+
+
+def load_checkpoint(path, map_location="cpu"):
+    """The reference's checkpoint container (evaluation.py:143-153: ``torch.load('...comp.pth.tar')['state_dict']``;
+    written by train_op.save_checkpoint from ``netG.state_dict()``, optionally under torch.nn.DataParallel, i.e. with
+    ``module.``-prefixed keys, mainPanoCompletion2view.py:154-156).  Returns {reference key: float32 numpy array}; keys of
+    sub-modules this build does not run (e.g. a discriminator) are dropped by SCNet.load_state_dict, not here."""
+    import torch
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
+    out = OrderedDict()
+    for k, v in sd.items():
+        k = k[7:] if k.startswith("module.") else k
+        out[k] = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
+    return out

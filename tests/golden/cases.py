@@ -18,3 +18,15 @@ E2E_CASES = [("suncg", "second", 15, 1, 1000 + i) for i in range(4)] + \
     [("matterport", "second", 21, 1, 3000), ("scannet", "kinect", 21, 0, 4000)]
 E2E_N = 80
 E2E_WEIGHT_SEED = 7
+
+# perturbation envelope of the reference loop (make_golden.gen_e2e_env / gen_e2e_wc): uniform noise of this amplitude on
+# every network output (= the measured float32 kernel-vs-reference output difference), this many noise seeds
+ENV_AMP = 3e-5
+ENV_SEEDS = 8
+
+# well-conditioned end-to-end fixtures: synth.make_wc_pair(seed, **WC_KW) + weights.make_descriptor_state_dict
+WC_CASES = (9000, 9002, 9004)
+WC_KW = dict(n_match=170, n_free=30, angle=0.15, shift=0.2)
+WC_S = 15
+WC_WEIGHT_SEED = 21
+WC_SIGMAS = (0.26, 0.26, 0.04, 0.1)      # sigmaAngle1, sigmaAngle2, sigmaDist, sigmaFeat for all three steps

@@ -6,7 +6,7 @@ regenerated from seeds, expected outputs are stored) travel with the repo.
     python tests/golden/make_golden.py            # all groups
     python tests/golden/make_golden.py matcher    # one group
 
-Groups: matcher, geometry, scnet, e2e.  See SURVEY.md §8c for the plan.
+Groups: matcher, geometry, scnet, e2e, e2e_env, e2e_wc, stats, keypoints, metrics.  See SURVEY.md §8c for the plan.
 """
 import hashlib
 import os
@@ -42,7 +42,8 @@ def sample_idx(n, k, seed):
     return np.random.RandomState(seed).randint(0, n, size=k)
 
 
-from cases import MATCH_CASES, MATCH_METHODS, GEOM_CASES, WARP_ANGLES, SCNET_CASES, E2E_CASES, E2E_N, E2E_WEIGHT_SEED  # noqa: E402
+from cases import (MATCH_CASES, MATCH_METHODS, GEOM_CASES, WARP_ANGLES, SCNET_CASES, E2E_CASES, E2E_N, E2E_WEIGHT_SEED,  # noqa: E402
+                   ENV_AMP, ENV_SEEDS, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED)
 
 
 def gen_matcher():
@@ -134,11 +135,11 @@ class _Args:
         self.snumclass, self.useTanh = S, tanh
 
 
-def ref_net(S, tanh, seed):
+def ref_net(S, tanh, seed, sd=None):
     import torch
     R = ref_loader.load()
     net = R["mymodel"].SCNet(_Args(S, tanh))
-    sd = {k: torch.from_numpy(v) for k, v in weights.make_state_dict(seed, S).items()}
+    sd = {k: torch.from_numpy(v) for k, v in (sd if sd is not None else weights.make_state_dict(seed, S)).items()}
     net.load_state_dict(sd, strict=True)
     return net
 
@@ -194,80 +195,141 @@ def gen_scnet():
     np.savez_compressed(os.path.join(HERE, "scnet.npz"), **out)
 
 
+def ref_loop(net, d, pts, ptw, ds, mm, S, sigmas, noise_amp=0.0, noise_seed=0, keep_prims=None):
+    """evaluation.py:217-284 for ONE scan pair driven through the reference's own functions (util.apply_mask,
+    util.warping, the reference SCNet, rpmodule.getMatchingPrimitive with getKeypoint replaced by the injected
+    keypoints, rpmodule.RelativePoseEstimation_helper).  Returns [R_hat after each of the 3 steps].
+    noise_amp > 0 adds uniform(-amp, amp) float32 noise to every network output (perturbation envelope)."""
+    import torch
+    R = ref_loader.load()
+    util, rp, ru, top = R["util"], R["rpmodule"], R["rputil"], R["torch_op"]
+    rs_noise = np.random.RandomState(noise_seed)
+
+    def fake_kp(rs, rt, fs, ft, *a, **k):
+        ps, pt = pts[0, 0], pts[0, 1]
+        pn, tn = ps.copy(), pt.copy()
+        pn[:, 0] /= 640; pn[:, 1] /= 160; tn[:, 0] /= 640; tn[:, 1] /= 160
+        return ps, pn, ptw[0, 0], pt, tn, ptw[0, 1]
+
+    rp.getKeypoint = fake_kp
+    rp.getKeypoint_kinect = fake_kp
+    data = {k: torch.from_numpy(v) for k, v in d.items()}
+    rgb_u8 = (d["rgb"] * 255).clip(0, 255).astype("uint8")
+    trace = []
+    with torch.no_grad():
+        R_hat = np.eye(4)
+        comp = [torch.cat((top.v(data["rgb"][:, v]), top.v(data["norm"][:, v]), top.v(data["depth"][:, v:v + 1])), 1)
+                for v in range(2)]
+        views, masks = [], []
+        for v in range(2):
+            x, m, _ = util.apply_mask(comp[v].clone(), mm)
+            masks.append(top.npy(m[0]).transpose(1, 2, 0))
+            views.append(torch.cat((x, (x[:, 6:7] != 0).float()), 1))
+        obs = [{"rgb": rgb_u8[0, v].transpose(1, 2, 0), "depth": d["depth"][0, v],
+                "normal": d["norm"][0, v].transpose(1, 2, 0)} for v in range(2)]
+        fs, fe = 7 + S, 7 + S + 32
+        for step in range(3):
+            t2s = top.v(util.warping(top.npy(views[1]), np.linalg.inv(R_hat), ds))
+            s2t = top.v(util.warping(top.npy(views[0]), R_hat, ds))
+            f = net(torch.cat((torch.cat((views[0], t2s), 1), torch.cat((views[1], s2t), 1))))
+            if noise_amp:
+                f = f + torch.from_numpy(rs_noise.uniform(-noise_amp, noise_amp, tuple(f.shape)).astype(np.float32))
+            dc = []
+            for v in range(2):
+                fv = top.npy(f[v])
+                m = masks[v]
+                c = {}
+                c["normal"] = ((1 - m) * fv[3:6].transpose(1, 2, 0) + m * obs[v]["normal"]) \
+                    / (np.linalg.norm(obs[v]["normal"], axis=2, keepdims=True) + 1e-6)
+                c["depth"] = (1 - m[:, :, 0]) * fv[6] + m[:, :, 0] * obs[v]["depth"]
+                c["rgb"] = (m * obs[v]["rgb"]).astype("uint8")
+                c["rgb_full"] = c["rgb"]
+                c["feat"] = f[v, fs:fe]
+                dc.append(c)
+            para = ru.opts(*sigmas[step])
+            prim = rp.getMatchingPrimitive(dc[0], dc[1], ds, "skybox", 1)
+            p3s, p3t, ns_, nt_, des, det, ws, wt = prim
+            R_hat = rp.RelativePoseEstimation_helper({"pc": p3s.T, "normal": ns_, "feat": des, "weight": ws},
+                                                     {"pc": p3t.T, "normal": nt_, "feat": det, "weight": wt}, para)
+            trace.append(R_hat)
+            if step == 0 and keep_prims is not None:
+                keep_prims.update(pc=p3s, n=ns_, des=des, pct=p3t, nt=nt_, dest=det)
+    return trace
+
+
 def gen_e2e():
     """evaluation.py:217-284 driven through the reference's own functions with
     rputil.getKeypoint replaced by injected keypoints (4 SUNCG-shaped pairs,
     config 1 of BASELINE.json, + 1 matterport + 1 scannet pair)."""
-    import torch
-    R = ref_loader.load()
-    util, rp, ru, top = R["util"], R["rpmodule"], R["rputil"], R["torch_op"]
     params = load_params()
     out = {}
-    cases = E2E_CASES
-    N = E2E_N
     nets = {}
-    for ci, (ds, mm, S, tanh, seed) in enumerate(cases):
+    for ci, (ds, mm, S, tanh, seed) in enumerate(E2E_CASES):
         key = (S, tanh)
         if key not in nets:
             nets[key] = ref_net(S, tanh, E2E_WEIGHT_SEED)
-        net = nets[key]
         d = synth.make_pairs(1, seed, ds)
-        pts, ptw = synth.make_keypoints(1, N, seed, mm)
-        inj = {}
-
-        def fake_kp(rs, rt, fs, ft, *a, **k):
-            ps, pt = pts[0, 0], pts[0, 1]
-            pn, tn = ps.copy(), pt.copy()
-            pn[:, 0] /= 640; pn[:, 1] /= 160; tn[:, 0] /= 640; tn[:, 1] /= 160
-            return ps, pn, ptw[0, 0], pt, tn, ptw[0, 1]
-
-        rp.getKeypoint = fake_kp
-        rp.getKeypoint_kinect = fake_kp
-        data = {k: torch.from_numpy(v) for k, v in d.items()}
-        rgb_u8 = (d["rgb"] * 255).clip(0, 255).astype("uint8")
-        with torch.no_grad():
-            R_hat = np.eye(4)
-            comp = [torch.cat((top.v(data["rgb"][:, v]), top.v(data["norm"][:, v]), top.v(data["depth"][:, v:v + 1])), 1)
-                    for v in range(2)]
-            views, masks = [], []
-            for v in range(2):
-                x, m, _ = util.apply_mask(comp[v].clone(), mm)
-                masks.append(top.npy(m[0]).transpose(1, 2, 0))
-                views.append(torch.cat((x, (x[:, 6:7] != 0).float()), 1))
-            obs = [{"rgb": rgb_u8[0, v].transpose(1, 2, 0), "depth": d["depth"][0, v],
-                    "normal": d["norm"][0, v].transpose(1, 2, 0)} for v in range(2)]
-            fs, fe = 7 + S, 7 + S + 32
-            t0 = time.time()
-            for step in range(3):
-                t2s = top.v(util.warping(top.npy(views[1]), np.linalg.inv(R_hat), ds))
-                s2t = top.v(util.warping(top.npy(views[0]), R_hat, ds))
-                f = net(torch.cat((torch.cat((views[0], t2s), 1), torch.cat((views[1], s2t), 1))))
-                dc = []
-                for v in range(2):
-                    fv = top.npy(f[v])
-                    m = masks[v]
-                    c = {}
-                    c["normal"] = ((1 - m) * fv[3:6].transpose(1, 2, 0) + m * obs[v]["normal"]) \
-                        / (np.linalg.norm(obs[v]["normal"], axis=2, keepdims=True) + 1e-6)
-                    c["depth"] = (1 - m[:, :, 0]) * fv[6] + m[:, :, 0] * obs[v]["depth"]
-                    c["rgb"] = (m * obs[v]["rgb"]).astype("uint8")
-                    c["rgb_full"] = c["rgb"]
-                    c["feat"] = f[v, fs:fe]
-                    dc.append(c)
-                para = ru.opts(*params[ds][step])
-                prim = rp.getMatchingPrimitive(dc[0], dc[1], ds, "skybox", 1)
-                p3s, p3t, ns_, nt_, des, det, ws, wt = prim
-                R_hat = rp.RelativePoseEstimation_helper({"pc": p3s.T, "normal": ns_, "feat": des, "weight": ws},
-                                                         {"pc": p3t.T, "normal": nt_, "feat": det, "weight": wt}, para)
-                out[f"e2e_{ci}_R{step}"] = R_hat
-                if step == 0:
-                    out[f"e2e_{ci}_prim_pc"], out[f"e2e_{ci}_prim_n"] = p3s, ns_
-                    out[f"e2e_{ci}_prim_des"] = des
-                    out[f"e2e_{ci}_prim_pct"], out[f"e2e_{ci}_prim_nt"], out[f"e2e_{ci}_prim_dest"] = p3t, nt_, det
-            print(f"e2e case {ci} {ds}: {time.time()-t0:.1f}s")
-        out[f"e2e_{ci}_cfg"] = np.array([ds, mm, str(S), str(tanh), str(seed), str(N)])
-    out["n_cases"] = np.array(len(cases))
+        pts, ptw = synth.make_keypoints(1, E2E_N, seed, mm)
+        t0 = time.time()
+        prims = {}
+        trace = ref_loop(nets[key], d, pts, ptw, ds, mm, S, params[ds], keep_prims=prims)
+        for step in range(3):
+            out[f"e2e_{ci}_R{step}"] = trace[step]
+        out[f"e2e_{ci}_prim_pc"], out[f"e2e_{ci}_prim_n"], out[f"e2e_{ci}_prim_des"] = prims["pc"], prims["n"], prims["des"]
+        out[f"e2e_{ci}_prim_pct"], out[f"e2e_{ci}_prim_nt"], out[f"e2e_{ci}_prim_dest"] = prims["pct"], prims["nt"], prims["dest"]
+        print(f"e2e case {ci} {ds}: {time.time()-t0:.1f}s")
+        out[f"e2e_{ci}_cfg"] = np.array([ds, mm, str(S), str(tanh), str(seed), str(E2E_N)])
+    out["n_cases"] = np.array(len(E2E_CASES))
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
+
+
+def gen_e2e_env():
+    """Perturbation envelope of the REFERENCE loop on the e2e cases (random-init weights: ill-conditioned): the loop is
+    re-run ENV_SEEDS times with uniform(-ENV_AMP, ENV_AMP) noise on every network output -- ENV_AMP = the size of the
+    float32 kernel-vs-reference difference of the network output -- and the rotation difference to the unperturbed
+    reference poses is stored per step.  The free-running GPU test asserts its own difference against this envelope."""
+    params = load_params()
+    ge = np.load(os.path.join(HERE, "e2e.npz"))
+    out = {"amp": np.array(ENV_AMP), "n_seeds": np.array(ENV_SEEDS)}
+    nets = {}
+    for ci, (ds, mm, S, tanh, seed) in enumerate(E2E_CASES):
+        key = (S, tanh)
+        if key not in nets:
+            nets[key] = ref_net(S, tanh, E2E_WEIGHT_SEED)
+        d = synth.make_pairs(1, seed, ds)
+        pts, ptw = synth.make_keypoints(1, E2E_N, seed, mm)
+        env = np.zeros((ENV_SEEDS, 3))
+        t0 = time.time()
+        for k in range(ENV_SEEDS):
+            tr = ref_loop(nets[key], d, pts, ptw, ds, mm, S, params[ds], noise_amp=ENV_AMP, noise_seed=7000 + 100 * ci + k)
+            env[k] = [np.linalg.norm(tr[s][:3, :3] - ge[f"e2e_{ci}_R{s}"][:3, :3]) for s in range(3)]
+        out[f"env_{ci}"] = env
+        print(f"e2e_env case {ci} {ds}: max per step {env.max(0)}  median {np.median(env, 0)}  ({time.time()-t0:.1f}s)")
+    np.savez_compressed(os.path.join(HERE, "e2e_env.npz"), **out)
+
+
+def gen_e2e_wc():
+    """Well-conditioned end-to-end fixtures (cases.WC_CASES): synth.make_wc_pair scan pairs (keypoints = projections of
+    common world points) + weights.make_descriptor_state_dict (descriptors follow the view-invariant texture).  Stores
+    the reference poses after each step and the same perturbation envelope as gen_e2e_env (expected << 1e-5)."""
+    out = {"amp": np.array(ENV_AMP), "n_seeds": np.array(ENV_SEEDS)}
+    net = ref_net(WC_S, 1, None, sd=weights.make_descriptor_state_dict(WC_WEIGHT_SEED, WC_S))
+    sig = np.tile(np.array([WC_SIGMAS]), (3, 1))
+    for ci, seed in enumerate(WC_CASES):
+        d, pts, ptw, T = synth.make_wc_pair(seed, **WC_KW)
+        t0 = time.time()
+        trace = ref_loop(net, d, pts, ptw, "suncg", "second", WC_S, sig)
+        env = np.zeros((ENV_SEEDS, 3))
+        for k in range(ENV_SEEDS):
+            tr = ref_loop(net, d, pts, ptw, "suncg", "second", WC_S, sig, noise_amp=ENV_AMP, noise_seed=8000 + 100 * ci + k)
+            env[k] = [np.linalg.norm(tr[s][:3, :3] - trace[s][:3, :3]) for s in range(3)]
+        for s in range(3):
+            out[f"wc_{ci}_R{s}"] = trace[s]
+        out[f"wc_{ci}_T"] = T
+        out[f"wc_env_{ci}"] = env
+        print(f"e2e_wc case {ci} seed {seed}: rot err vs true motion {[float(np.linalg.norm(trace[s][:3,:3]-T[:3,:3])) for s in range(3)]}"
+              f"  envelope max {env.max(0)}  ({time.time()-t0:.1f}s)")
+    np.savez_compressed(os.path.join(HERE, "e2e_wc.npz"), **out)
 
 
 def gen_keypoints():
@@ -307,9 +369,21 @@ def gen_stats():
     np.savez_compressed(os.path.join(HERE, "stats.npz"), **out)
 
 
+def gen_metrics():
+    """util.angular_distance_np of the reference (util.py:176-187) on random rotation pairs."""
+    R = ref_loader.load()
+    util = R["util"]
+    rs = np.random.RandomState(31)
+    Rh = np.stack([synth.random_rigid(rs)[:3, :3] for _ in range(16)])
+    Rg = np.stack([synth.random_rigid(rs)[:3, :3] for _ in range(16)])
+    Rh[3] = Rg[3]                                    # zero-angle case (arccos clip)
+    out = {"R_hat": Rh, "R_gt": Rg, "angular_distance": util.angular_distance_np(Rh, Rg)}
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
-    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e", "stats", "keypoints"]
+    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e", "e2e_env", "e2e_wc", "stats", "keypoints", "metrics"]
     for g in groups:
         t = time.time()
         globals()["gen_" + g]()

@@ -1,6 +1,7 @@
 """Helpers shared by the -m gpu parity tests."""
 import json
 import os
+import time
 
 import numpy as np
 
@@ -8,9 +9,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 
 
+# one file per test run (gpurun merges gpurun_out/ back by file name: a shared parity.jsonl written by a later partial
+# run would replace the full log of an earlier one)
+RUN_LOG = os.path.join(OUT, "parity", time.strftime("%Y%m%d-%H%M%S") + f"-{os.getpid()}.jsonl")
+
+
 def log(name, **kv):
-    """Append a JSON line to gpurun_out/parity.jsonl (merged back by gpurun)."""
-    os.makedirs(OUT, exist_ok=True)
+    """Append a JSON line to this run's gpurun_out/parity/<start time>-<pid>.jsonl (merged back by gpurun)."""
+    os.makedirs(os.path.dirname(RUN_LOG), exist_ok=True)
     rec = {"test": name}
     for k, v in kv.items():
         if isinstance(v, (np.floating, np.integer)):
@@ -18,7 +24,7 @@ def log(name, **kv):
         elif isinstance(v, np.ndarray):
             v = v.tolist()
         rec[k] = v
-    with open(os.path.join(OUT, "parity.jsonl"), "a") as f:
+    with open(RUN_LOG, "a") as f:
         f.write(json.dumps(rec) + "\n")
 
 

@@ -24,6 +24,7 @@ def test_bench_json_contract_small_batch():
         assert k in r, k
     assert r["unit"] == "pairs/s" and r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["higher_is_better"] is True
     assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f32" and "workload" in r["config"]
+    assert r["config"]["baseline_config_index"] == 1 and "pcie_inclusive" in r and "roofline_affinity" in r and r["roofline"]["traffic"] is None
     assert abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3 / 1e3)) < 1e-6 * r["value"]
     rf = r["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -51,3 +52,57 @@ def test_bench_world2_path_two_ranks_sharing_one_gpu():
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["config"]["pairs_per_gpu"] == 4
     assert abs(r["value"] - 8 * 2 / (r["ms_per_step"] * 2 / 1e3)) < 1e-6 * r["value"]      # whole-job pairs / max-over-ranks time
     assert r["status_ok_fraction"] == 1.0 and "cpu_baseline" not in r
+
+
+def test_bench_gpus2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` launched PLAINLY (no torchrun, WORLD_SIZE unset) must run two ranks itself and report
+    n_gpus 2 -- never fall through to one GPU.  With a single visible GPU the two ranks share it through the
+    gloo test hook; with >= 2 GPUs the same command runs one rank per GPU over RCCL (next test)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RELPOSE_DIST_BACKEND="gloo", RELPOSE_FORCE_DEVICE="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "4", "--keypoints", "60",
+                          "--no-aux", "--no-h2d"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["dist_world_size"] == 2 and r["config"]["dist_backend"] == "gloo"
+    assert r["config"]["pairs_per_step_total"] == 8 and r["status_ok_fraction"] == 1.0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RELPOSE_FORCE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "refusing" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rccl_two_gpus_weak_and_strong():
+    """The RCCL (backend "nccl") branch, one rank per GPU -- needs >= 2 GPUs, skipped on the 1-GPU test box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RELPOSE_FORCE_DEVICE", "RELPOSE_DIST_BACKEND")}
+    for extra, total in ((["--pairs", "4"], 8), (["--scaling", "strong", "--total-pairs", "6"], 6)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--keypoints", "60",
+                              "--no-aux", "--no-h2d"] + extra, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert r["n_gpus"] == 2 and r["config"]["dist_backend"] == "nccl" and r["config"]["pairs_per_step_total"] == total
+
+
+@pytest.mark.parametrize("config", [2, 3, 4])
+def test_bench_other_baseline_configs_run(config):
+    """--config 2|3|4 (Matterport N=400, ScanNet/kinect, SUNCG 320x1280 + f16x3) produce a line naming their workload; small batch."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--pairs", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-aux", "--batches", "2"], capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    c = r["config"]
+    assert c["baseline_config_index"] == config and r["status_ok_fraction"] == 1.0 and "pcie_inclusive" in r
+    want = {2: ("matterport", "second", "160x640", 400, "f32"), 3: ("scannet", "kinect", "160x640", 200, "f32"), 4: ("suncg", "second", "320x1280", 200, "f16x3")}[config]
+    assert (c["dataset"], c["mask"], c["pano"], c["keypoints"], c["conv_precision"]) == want
+    assert (r["dtype"] == "f32") == (config != 4)

@@ -1,0 +1,141 @@
+"""Free-running recurrent loop on the GPU (the pose estimate of level k is fed back into the warp of level k+1,
+evaluation.py:232-284) against the REFERENCE's poses after each level.
+
+Three kinds of fixtures (all captured from the reference by tests/golden/make_golden.py):
+
+* ``e2e.npz``      random-init weights, 6 scan pairs (4 SUNCG = BASELINE configs[0], 1 Matterport, 1 ScanNet).  With
+                   random weights the descriptors carry no information and the loop is CHAOTIC: ``e2e_env.npz`` holds the
+                   reference's own response to uniform(+-3e-5) noise on the network output (the size of the float32
+                   kernel-vs-reference difference) -- ~1e-3 after level 0 and O(1) (an unrelated pose) after levels 1-2.
+                   The GPU loop is asserted to stay inside that measured envelope; both numbers are logged.
+* ``e2e_wc.npz``   WELL-CONDITIONED pairs (synth.make_wc_pair + weights.make_descriptor_state_dict: keypoints are
+                   projections of common world points, descriptors follow the view-invariant texture).  The reference's
+                   envelope there is ~1e-7, and the free-running GPU pose is asserted within the north-star bar,
+                   1e-4 Frobenius on the rotation, after EVERY level.
+* BASELINE configs[1] size (32 pairs, N=200): batch result bitwise == single-pair runs, all status 0.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from cases import E2E_CASES, E2E_N, E2E_WEIGHT_SEED, ENV_AMP, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED
+from gpu_util import log
+from relativepose_amd import synth, weights
+
+pytestmark = pytest.mark.gpu
+
+ENV_SLACK = 3.0      # the GPU run is one more sample of a heavy-tailed distribution of which the envelope holds 8
+
+
+def _net(S, tanh, sd):
+    from relativepose_amd.model import SCNet
+    net = SCNet(SimpleNamespace(batchnorm=1, useTanh=tanh, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+    net.load_state_dict(sd)
+    return net
+
+
+def _rot_err(a, b):
+    return float(np.linalg.norm(a[:3, :3] - b[:3, :3]))
+
+
+@pytest.mark.parametrize("ci", range(len(E2E_CASES)))
+def test_free_running_random_weights_inside_reference_envelope(ci, golden_dir):
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    ge = np.load(os.path.join(golden_dir, "e2e.npz"))
+    gm = np.load(os.path.join(golden_dir, "matcher.npz"))
+    env = np.load(os.path.join(golden_dir, "e2e_env.npz"))
+    assert float(env["amp"]) == ENV_AMP
+    ds, mm, S, tanh, seed = E2E_CASES[ci]
+    d = synth.make_pairs(1, seed, ds)
+    pts, ptw = synth.make_keypoints(1, E2E_N, seed, mm)
+    dev = torch.device("cuda:0")
+    pipe = RelativePosePipeline(_net(S, tanh, weights.make_state_dict(E2E_WEIGHT_SEED, S)), ds, mm, gm[f"params_{ds}"])
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    pose, status, trace = pipe.run(st)                     # free running: no R_forced
+    e = env[f"env_{ci}"]                                   # [seeds, 3]
+    errs = [_rot_err(trace[s][0].cpu().numpy(), ge[f"e2e_{ci}_R{s}"]) for s in range(3)]
+    log("e2e_free_running", case=ci, ds=ds, gpu_rot_err_vs_reference=errs, reference_envelope_max=e.max(0), reference_envelope_median=np.median(e, 0),
+        noise_amp=ENV_AMP)
+    assert int(status[0]) == 0
+    for s in range(3):
+        bound = min(ENV_SLACK * e[:, s].max(), 2.0 * np.sqrt(2.0) + 1e-9)
+        assert errs[s] <= bound, (s, errs[s], bound)
+
+
+@pytest.mark.parametrize("ci", range(len(WC_CASES)))
+def test_free_running_well_conditioned_within_1e4(ci, golden_dir):
+    """The north-star parity bar on the whole loop: rotation within 1e-4 Frobenius of the reference after every level,
+    with the GPU's own pose fed back (pose_inverse -> warp_pairs -> SCNet -> sample -> match)."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    g = np.load(os.path.join(golden_dir, "e2e_wc.npz"))
+    d, pts, ptw, T = synth.make_wc_pair(WC_CASES[ci], **WC_KW)
+    assert np.array_equal(T, g[f"wc_{ci}_T"])
+    dev = torch.device("cuda:0")
+    sig = np.tile(np.array([WC_SIGMAS]), (3, 1))
+    pipe = RelativePosePipeline(_net(WC_S, 1, weights.make_descriptor_state_dict(WC_WEIGHT_SEED, WC_S)), "suncg", "second", sig)
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    pose, status, trace = pipe.run(st)
+    errs = [_rot_err(trace[s][0].cpu().numpy(), g[f"wc_{ci}_R{s}"]) for s in range(3)]
+    terr = [float(np.linalg.norm(trace[s][0].cpu().numpy()[:3, 3] - g[f"wc_{ci}_R{s}"][:3, 3])) for s in range(3)]
+    e = g[f"wc_env_{ci}"]
+    log("e2e_wc_free_running", case=ci, seed=WC_CASES[ci], gpu_rot_err_vs_reference=errs, gpu_trans_err_vs_reference=terr,
+        reference_envelope_max=e.max(0), rot_err_vs_true_motion=[_rot_err(trace[s][0].cpu().numpy(), T) for s in range(3)])
+    assert int(status[0]) == 0
+    assert e.max() < 1e-5, "fixture is not well-conditioned"
+    for s in range(3):
+        assert errs[s] < 1e-4, (s, errs)
+        assert terr[s] < 1e-4, (s, terr)
+
+
+def test_wc_teacher_forcing_changes_nothing_but_feedback_matters(golden_dir):
+    """The feedback path is live on the well-conditioned fixture: forcing a WRONG pose into level 1 moves the level-1
+    result (so the <1e-4 agreement above does pin pose_inverse -> warp_pairs with the GPU's own pose)."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    d, pts, ptw, T = synth.make_wc_pair(WC_CASES[0], **WC_KW)
+    dev = torch.device("cuda:0")
+    sig = np.tile(np.array([WC_SIGMAS]), (3, 1))
+    pipe = RelativePosePipeline(_net(WC_S, 1, weights.make_descriptor_state_dict(WC_WEIGHT_SEED, WC_S)), "suncg", "second", sig, alter_steps=2)
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    _, _, free = pipe.run(st)
+    wrong = synth.random_rigid(np.random.RandomState(3), 0.6, 0.5)
+    forced = [torch.eye(4, dtype=torch.float64, device=dev)[None], torch.from_numpy(wrong[None]).to(dev)]
+    _, _, tf = pipe.run(st, R_forced=forced)
+    assert torch.equal(free[0], tf[0])
+    moved = _rot_err(free[1][0].cpu().numpy(), tf[1][0].cpu().numpy())
+    log("e2e_wc_feedback_sensitivity", level1_rot_change_with_wrong_pose=moved)
+    assert moved > 1e-6
+
+
+def test_baseline_config1_batch_equals_single_pairs():
+    """BASELINE configs[1] size: 32 SUNCG pairs x 200 keypoints in one batch (workspace sizing, the 2048-entry LDS
+    scale/shift table at 64 images, max_edges as the bench sets it): bitwise equal to single-pair runs for sampled pairs,
+    every status 0, deterministic run to run."""
+    import torch
+    from relativepose_amd import params
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    B, N, S = 32, 200, 15
+    d = synth.make_pairs(B, 2000, "suncg")
+    pts, ptw = synth.make_keypoints(B, N, 2000, "second")
+    net = _net(S, 1, weights.make_state_dict(7, S))
+    Cc = N * 5
+    pipe = RelativePosePipeline(net, "suncg", "second", params.final_params("suncg"), max_edges=min(Cc * (Cc - 1), 1 << 20))
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    pose, status, _ = pipe.run(st)
+    pose2, status2, _ = pipe.run(st)
+    assert torch.equal(pose, pose2) and torch.equal(status, status2)
+    assert (status == 0).all(), status.cpu().tolist()
+    assert torch.isfinite(pose).all()
+    for b in (0, 7, 18, 31):
+        st1 = pipe.prepare(d["rgb"][b:b + 1], d["norm"][b:b + 1], d["depth"][b:b + 1], pts[b:b + 1], ptw[b:b + 1], dev)
+        p1, s1, _ = pipe.run(st1)
+        assert torch.equal(p1[0], pose[b]) and int(s1[0]) == 0, b
+    R = pose[:, :3, :3]
+    orth = (R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device=dev)).abs().max().item()
+    log("config1_batch32", orthogonality=orth)
+    assert orth < 1e-9

@@ -1,0 +1,177 @@
+"""The PyTorch custom-op surface (torch.ops.relpose.*, relativepose_amd/ops.py) and the reference-named host shims
+(rputil.getPixel / interpolate, rpmodule.getMatchingPrimitive / RelativePoseEstimation /
+RelativePoseEstimationViaCompletion) against the ctypes -> C-ABI path the other GPU tests pin to the oracle: every
+operator and shim must return the same bits."""
+import copy
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from cases import GEOM_CASES
+from relativepose_amd import synth, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import relativepose_amd.ops  # noqa: F401  (registers torch.ops.relpose)
+    from relativepose_amd.model import SCNet
+    S = 15
+    net = SCNet(SimpleNamespace(batchnorm=1, useTanh=1, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+    net.load_state_dict(weights.make_state_dict(5, S))
+    return SimpleNamespace(torch=torch, dev=torch.device("cuda:0"), net=net, S=S)
+
+
+def _inputs(ctx, ds="suncg", mm="second", B=2, seed=640):
+    torch, dev = ctx.torch, ctx.dev
+    d = synth.make_pairs(B, seed, ds)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    h = d["rgb"].shape[3]
+    return t(d["rgb"].reshape(2 * B, 3, h, 4 * h)), t(d["norm"].reshape(2 * B, 3, h, 4 * h)), t(d["depth"].reshape(2 * B, h, 4 * h)), d
+
+
+@pytest.mark.parametrize("ds,mm,seed", GEOM_CASES)
+def test_geometry_ops_equal_cabi(ctx, ds, mm, seed):
+    torch, dev = ctx.torch, ctx.dev
+    from relativepose_amd import util
+    ops = torch.ops.relpose
+    rgb, nrm, dep, d = _inputs(ctx, ds, mm, 2, seed)
+    did, mid = util.dataset_id(ds), util.MASKS[mm]
+    view = util.build_view_dev(rgb, nrm, dep, mm)
+    assert torch.equal(ops.build_view(rgb, nrm, dep, mid), view)
+    comp = torch.cat((rgb, nrm, dep[:, None]), 1).contiguous()
+    xm, m = ops.apply_mask(comp, mid)
+    xm2, m2 = util.apply_mask_dev(comp.clone(), mm)
+    assert torch.equal(xm, xm2) and torch.equal(m, m2) and not torch.equal(comp, xm)      # functional: input untouched
+    rs = np.random.RandomState(seed)
+    poses = torch.from_numpy(np.stack([synth.random_rigid(rs, 1.0, 0.5) for _ in range(4)])).to(dev)
+    assert torch.equal(ops.warp(view, poses, did), util.warping_dev(view, poses, ds))
+    assert torch.equal(ops.pose_inverse(poses), util.pose_inverse_dev(poses))
+    x = torch.zeros(4, 16, 160, 640, device=dev)
+    x[:, :8] = view
+    x2 = x.clone()
+    r = ops.warp_pairs_(x, poses, did)
+    util.warp_pairs_dev(x2, poses, ds)
+    assert r.data_ptr() == x.data_ptr() and torch.equal(x, x2) and x[:, 8:].abs().sum() > 0
+    pc, valid = ops.pano2pc(dep, did)
+    pc2, valid2 = util.pano2pc_dev(dep, ds)
+    assert torch.equal(pc, pc2) and torch.equal(valid, valid2)
+
+
+def test_scnet_and_sampling_ops_equal_cabi(ctx):
+    torch, dev, net, S = ctx.torch, ctx.dev, ctx.net, ctx.S
+    from relativepose_amd import util
+    ops = torch.ops.relpose
+    rgb, nrm, dep, d = _inputs(ctx)
+    view = util.build_view_dev(rgb, nrm, dep, "second")
+    x = torch.cat((view, torch.zeros_like(view)), 1).contiguous()
+    f = ops.scnet_forward(x, net.handle)
+    assert torch.equal(f, net(x)) and f.shape == (4, 7 + S + 32, 160, 640)
+    with pytest.raises(RuntimeError):
+        ops.scnet_forward(x, 12345)
+    pts, ptw = synth.make_keypoints(2, 50, 77, "second")
+    P = torch.from_numpy(pts.reshape(4, 50, 2)).to(dev)
+    npts = torch.full((4,), 50, dtype=torch.int32, device=dev)
+    for compose in (0, 1):
+        a = ops.sample_primitives(f, 7 + S, nrm, dep, P, npts, 0, compose, 0)
+        b = util.sample_primitives_dev(f, 7 + S, nrm, dep, P, npts, "second", "suncg", compose)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+    n0 = util.sample_primitives_dev(f, 7 + S, nrm, dep, P, npts, "second", "suncg", 0)[1]
+    n1 = util.sample_primitives_dev(f, 7 + S, nrm, dep, P, npts, "second", "suncg", 1)[1]
+    assert not torch.equal(n0, n1)                 # the two composition variants really differ (unobserved keypoints)
+
+
+def test_matcher_ops_equal_cabi(ctx):
+    torch, dev = ctx.torch, ctx.dev
+    from relativepose_amd import ops as O
+    from relativepose_amd import rpmodule
+    ops = torch.ops.relpose
+    cases = [synth.make_match_case(n, 300 + n)[:2] for n in (60, 90, 90)]
+    kp = rpmodule.pack_keypoints(cases, dev)
+    para = rpmodule.opts(0.3, 0.25, 0.04, 0.009)
+    for method in ("irls+sm", "horn87", "irls", "spectral"):
+        para.method = method
+        want = rpmodule.match_pairs(*kp, para)
+        pose, status = ops.match_pairs(*kp, O.params_list(para), para.topK, rpmodule.METHODS[method], 0)
+        assert torch.equal(pose, want.pose) and torch.equal(status, want.status)
+    wij, cj, cw, keff = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+    got = ops.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], O.params_list(para), para.topK, True)
+    assert all(torch.equal(a, b) for a, b in zip(got, (wij, cj, cw, keff)))
+    with pytest.raises(Exception):
+        ops.match_pairs(*kp, O.params_list(para), para.topK, 9, 0)
+
+
+def test_rputil_shims_equal_reference_goldens(ctx, golden_dir):
+    """rputil.getPixel / rputil.interpolate with the reference's signatures reproduce the reference's own outputs."""
+    torch = ctx.torch
+    from relativepose_amd import rputil
+    g = np.load(os.path.join(golden_dir, "geometry.npz"))
+    for ds, mm, seed in GEOM_CASES:
+        d = synth.make_pairs(1, seed, ds)
+        pts, _ = synth.make_keypoints(1, 64, seed + 5, mm)
+        pts = pts[0, 0]
+        pc, nn = rputil.getPixel(d["depth"][0, 0], d["norm"][0, 0].transpose(1, 2, 0), pts, dataset=ds)
+        assert pc.shape == (3, 64) and np.abs(pc - g[f"getpixel_{ds}_pc"]).max() < 1e-12
+        assert np.abs(nn - g[f"getpixel_{ds}_nn"]).max() < 1e-12
+        feat = np.random.RandomState(seed + 6).randn(32, 160, 640).astype(np.float32)
+        ptn = pts.copy()
+        ptn[:, 0] /= 640
+        ptn[:, 1] /= 160
+        got = rputil.interpolate(torch.from_numpy(feat), torch.from_numpy(ptn).float())
+        assert got.shape == (32, 64) and np.array_equal(got.cpu().numpy(), g[f"interp_{ds}"])
+
+
+def test_rpmodule_shims_equal_pipeline(ctx):
+    """getMatchingPrimitive / RelativePoseEstimation on host-composed dicts == the device pipeline's primitives and pose
+    (evaluation.py composition); RelativePoseEstimationViaCompletion == the pipeline with the library composition."""
+    torch, dev, net, S = ctx.torch, ctx.dev, ctx.net, ctx.S
+    from relativepose_amd import rpmodule, util
+    from relativepose_amd.pipeline import RelativePosePipeline
+    ds, mm, N = "suncg", "second", 70
+    d = synth.make_pairs(1, 910, ds)
+    pts, ptw = synth.make_keypoints(1, N, 910, mm)
+    sig = [[0.3, 0.3, 0.04, 0.01], [0.28, 0.26, 0.04, 0.0095]]
+    pipe = RelativePosePipeline(net, ds, mm, sig, alter_steps=1)
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    keep = []
+    pose, status, _ = pipe.run(st, keep=keep)
+    f = keep[0]["f"].cpu().numpy()
+    # host composition exactly as evaluation.py:246-253
+    m = np.zeros((160, 640, 1), np.float32)
+    m[:, 160:320] = 1
+    dc = []
+    for v in range(2):
+        obs_n = d["norm"][0, v].transpose(1, 2, 0)
+        c = {"normal": ((1 - m) * f[v, 3:6].transpose(1, 2, 0) + m * obs_n) / (np.linalg.norm(obs_n, axis=2, keepdims=True) + 1e-6),
+             "depth": (1 - m[:, :, 0]) * f[v, 6] + m[:, :, 0] * d["depth"][0, v],
+             "rgb": (m * (d["rgb"][0, v].transpose(1, 2, 0) * 255)).astype("uint8"), "feat": keep[0]["f"][v, 7 + S:7 + S + 32]}
+        dc.append(c)
+    old = rpmodule.set_keypoint_provider(None)
+    try:
+        with pytest.raises(RuntimeError):
+            rpmodule.getMatchingPrimitive(dc[0], dc[1], ds, "skybox", 1)
+        rpmodule.set_keypoint_provider(rpmodule.fixed_keypoints(pts[0, 0], ptw[0, 0], pts[0, 1], ptw[0, 1]))
+        p3s, p3t, ns_, nt_, des, det, ws, wt = rpmodule.getMatchingPrimitive(dc[0], dc[1], ds, "skybox", 1)
+        assert np.array_equal(p3s.T, keep[0]["pc"][0, 0].cpu().numpy()) and np.array_equal(p3t.T, keep[0]["pc"][0, 1].cpu().numpy())
+        assert np.array_equal(ns_, keep[0]["nn"][0, 0].cpu().numpy()) and np.array_equal(det, keep[0]["ft"][0, 1].cpu().numpy())
+        para = rpmodule.opts(*sig[0])
+        R = rpmodule.RelativePoseEstimation(dc[0], dc[1], para, ds, "skybox", mm)
+        assert np.array_equal(R, pose[0].cpu().numpy())
+        # doCompletion = 0 keeps the observed-region keypoints only (rpmodule.py:534-537)
+        q = rpmodule.getMatchingPrimitive(dc[0], dc[1], ds, "skybox", 0)
+        assert q[0].shape[1] == int((ptw[0, 0] == 1).sum()) and (q[6] == 1).all()
+        # the library loop (two alternations, library composition)
+        args = SimpleNamespace(snumclass=S, featureDim=32, outputType="rgbdnsf", maskMethod=mm, alterStep=2, dataset=ds, representation="skybox",
+                               completion=1, para=rpmodule.opts())
+        args.para.sigmaAngle1, args.para.sigmaAngle2, args.para.sigmaDist, args.para.sigmaFeat = (list(c) for c in zip(*sig))
+        data = [{"rgb": d["rgb"][0, v].transpose(1, 2, 0), "norm": d["norm"][0, v].transpose(1, 2, 0), "depth": d["depth"][0, v]} for v in range(2)]
+        R2 = rpmodule.RelativePoseEstimationViaCompletion(net, data[0], data[1], args)
+        pipe2 = RelativePosePipeline(net, ds, mm, sig, alter_steps=2, compose=1)
+        want, st2, _ = pipe2.run(pipe2.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev))
+        assert np.array_equal(R2, want[0].cpu().numpy()) and args.idx_f_start == 7 + S and args.idx_f_end == 7 + S + 32
+    finally:
+        rpmodule.set_keypoint_provider(old)

@@ -145,3 +145,36 @@ def test_scnet_split_precision_options_close_to_f32_and_reversible(hw, mode, bou
     assert float(d.max()) > 0                                   # the option really ran a different kernel
     assert torch.equal(y16_single, y16[2:4])                    # batch-invariant
     assert torch.equal(y32b, y32)                               # fp32 path untouched
+
+
+def test_scnet_reload_state_dict_rebuilds_launch_plans():
+    """load_state_dict twice on ONE net (after a forward has cached launch plans that hold absolute weight pointers):
+    each result must equal a fresh net with that state dict (plans were not invalidated by finalize)."""
+    import torch
+    tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
+    x = torch.from_numpy(oracle_scnet_input(610, ds, mm)).cuda()
+    netA, sdA = make_net(S, tanh, seed)
+    netB, sdB = make_net(S, tanh, seed + 50)
+    yA, yB = netA(x).clone(), netB(x).clone()
+    assert not torch.equal(yA, yB)
+    netA.load_state_dict(sdB)                 # same object, same workspace, new weights
+    assert torch.equal(netA(x), yB)
+    netA.load_state_dict({"module." + k: v for k, v in sdA.items()})       # DataParallel-prefixed keys
+    assert torch.equal(netA(x), yA)
+
+
+@pytest.mark.parametrize("hw", [(56, 224), (80, 320), (64, 250)])
+def test_scnet_small_panoramas_resize_out_generic_path(hw):
+    """W < 560: the 64-pixel output segments of resize_out span more source pixels than its LDS staging holds (ADVICE r1:
+    silent overrun); the kernel now gathers directly for such shapes.  Whole forward vs the fp32 oracle."""
+    import torch
+    tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
+    net, sd = make_net(S, tanh, seed)
+    H, W = hw
+    rs = np.random.RandomState(H)
+    x = rs.randn(2, 16, H, W).astype(np.float32)
+    want = SCNetOracle(sd, S, tanh).forward_pairs(x).numpy()
+    got = net(torch.from_numpy(x).cuda()).cpu().numpy()
+    err = float(np.abs(got - want).max())
+    log("scnet_small_pano", hw=list(hw), max_abs_err=err)
+    assert got.shape == want.shape and err < 5e-4

@@ -141,6 +141,27 @@ def test_e2e_loop_matches_reference(ge, gm, ci):
         assert np.abs(trace[step] - ge[f"e2e_{ci}_R{step}"]).max() < 1e-4, (ci, step)
 
 
+def test_e2e_well_conditioned_free_running_matches_reference(golden_dir):
+    """The oracle loop, FREE-RUNNING (its own pose fed back), on a well-conditioned fixture equals the reference's poses
+    after every level far inside the 1e-4 bar; the stored perturbation envelopes of the reference are << 1e-5 on these
+    fixtures and O(1) on the random-weight ones (which is why those are compared teacher-forced above)."""
+    from cases import ENV_AMP, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED
+    g = np.load(os.path.join(golden_dir, "e2e_wc.npz"))
+    env = np.load(os.path.join(golden_dir, "e2e_env.npz"))
+    assert float(g["amp"]) == ENV_AMP == float(env["amp"])
+    for ci in range(len(WC_CASES)):
+        assert g[f"wc_env_{ci}"].shape == (int(g["n_seeds"]), 3) and g[f"wc_env_{ci}"].max() < 1e-5
+    assert max(env[f"env_{ci}"][:, 1:].max() for ci in range(len(E2E_CASES))) > 1.0        # random weights: chaotic after level 0
+    ci = 2
+    d, pts, ptw, T = synth.make_wc_pair(WC_CASES[ci], **WC_KW)
+    net = SCNetOracle(weights.make_descriptor_state_dict(WC_WEIGHT_SEED, WC_S), WC_S, 1)
+    _, trace = P.run_pair(net, d["rgb"][0], d["norm"][0], d["depth"][0], pts[0], ptw[0], np.tile(np.array([WC_SIGMAS]), (3, 1)),
+                          "suncg", "second", WC_S)
+    for step in range(3):
+        assert np.linalg.norm(trace[step][:3, :3] - g[f"wc_{ci}_R{step}"][:3, :3]) < 1e-6, step
+        assert np.linalg.norm(trace[step][:3, :3] - T[:3, :3]) < 2e-2          # and it is the true relative motion, roughly
+
+
 @pytest.mark.parametrize("ds,mm,seed", GEOM_CASES)
 def test_overlap_stats_match_reference(golden_dir, ds, mm, seed):
     from oracle import stats_oracle as S
