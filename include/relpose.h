@@ -46,7 +46,9 @@ enum {
     RELPOSE_DIST_FILTER = 2,   /* <3 pairs pass the distance test          rpmodule.py:406 */
     RELPOSE_ANGLE_FILTER = 3,  /* <3 pairs pass the angle test             rpmodule.py:440 */
     RELPOSE_ZERO_WEIGHT = 4,   /* every pair weight is 0                   rpmodule.py:469 */
-    RELPOSE_EDGE_OVERFLOW = 5  /* more surviving pairs than the workspace was sized for */
+    RELPOSE_EDGE_OVERFLOW = 5, /* more surviving pairs than the workspace was sized for */
+    RELPOSE_NOT_CONVERGED = 6  /* a leading-eigenvector solve (rpmodule.py:273, ARPACK there) did not reach its residual
+                                  tolerance within the restart budget; the pose is computed from the last iterate */
 };
 
 enum { RELPOSE_SUNCG = 0, RELPOSE_MATTERPORT = 1, RELPOSE_SCANNET = 2 };   /* dataset conventions */

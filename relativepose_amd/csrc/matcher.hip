@@ -20,6 +20,7 @@
 #include "common.h"
 #include "rp_math.h"
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define RP_MAXK 8
@@ -49,6 +50,7 @@ struct Graph {                 // per-batch device arrays of the pair-compatibil
     double* state;             // [B, 4, Cmax]  deg, gP, gN, rsum
     double* geo;               // [B, Cmax, 12]  sp, tp, sn, tn of every correspondence (gathered once per fit)
     int32_t* pairC;            // [B] number of correspondences of a pair whose fit is running, 0 otherwise
+    int32_t pack_rows;         // col[] holds (row << 16 | column): the single-workgroup fit (fit_pair_kernel) reads both from one word
 };
 
 __device__ __forceinline__ int pair_C(const RelposeKeypoints& kp, const Graph& g, int b) {
@@ -56,6 +58,16 @@ __device__ __forceinline__ int pair_C(const RelposeKeypoints& kp, const Graph& g
     if (ns < 3 || nt < 3) return 0;
     return ns * g.keff[b];
 }
+
+// DPP lane exchanges (no LDS): bound_ctrl on, lanes without a source read 0
+template <int CTRL>
+__device__ __forceinline__ int rp_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ double rp_dpp_d(double v) {
+    return __hiloint2double(rp_dpp<CTRL>(__double2hiint(v)), rp_dpp<CTRL>(__double2loint(v)));
+}
+#define RP_ROW_SHR(n) (0x110 + (n))
+#define RP_ROW_SHL(n) (0x100 + (n))
 
 struct Corr { double ps[3], ns[3], pt[3], nt[3]; double f, ws, wt; };
 
@@ -177,6 +189,165 @@ __global__ __launch_bounds__(256) void affinity_topk_kernel(RelposeKeypoints kp,
     }
 }
 
+// ---- register-resident variant (the default for nt_max <= 512) -----------------------------------------------------
+// A lane OWNS up to T targets (j = t*64 + lane) with their scaled 32-float descriptors in VGPRs; a wave walks over
+// `rows_per_wave` source rows, broadcasting the row's descriptor through SGPRs (v_readlane), so an entry costs no LDS
+// traffic at all: only the 32 x {sub, mul, add} of the numpy-order float32 distance, as packed fp32 math over two target
+// slots.  Per row: e = -d/den (float64 division replaced by Markstein's exact q + fma(rem, 1/den, q) sequence; den takes
+// two values), the K winners by K rounds of {per-lane best, DPP wave maximum, owner pops}, exp() only in the target slots
+// where some lane is within 110 of the row maximum (everything below is < 2^-150 relative: exactly 0 in the float32 wij and
+// invisible in the float64 row norm), the norm, the K outputs (exp + divide on K lanes in parallel) and, if wanted, wij.
+struct AffConsts { double den[2], rden[2]; int exact_div; };        // [0] = other, [1] = both observed
+
+__device__ __forceinline__ double rp_wave_max_d(double v) {
+    // butterfly inside every row of 16 lanes (DPP), then the four row results through SGPRs
+    v = fmax(v, rp_dpp_d<0xB1>(v));          // quad_perm [1,0,3,2]
+    v = fmax(v, rp_dpp_d<0x4E>(v));          // quad_perm [2,3,0,1]
+    v = fmax(v, rp_dpp_d<0x141>(v));         // row_half_mirror
+    v = fmax(v, rp_dpp_d<0x140>(v));         // row_mirror
+    const double a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+    const double b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
+    const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
+    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
+    return fmax(fmax(a, b), fmax(c, d));
+}
+
+template <int TP, bool WRITE_WIJ>       // TP = pairs of target slots per lane (targets <= 128 * TP)
+__global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp, AffConsts ac, int topK, int rows_per_wave,
+                                                             float* __restrict__ wij, int32_t* __restrict__ corres_j,
+                                                             double* __restrict__ corres_w, int32_t* __restrict__ keff_out) {
+    constexpr int T = 2 * TP;
+    const int b = blockIdx.y;
+    const int ns = kp.ns[b], nt = kp.nt[b];
+    const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
+    if (keff == 0) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+    if (row0 >= ns) return;
+    // ---- this lane's targets: descriptors / 100 (float32 division like numpy), weights
+    rp_v2f ft[TP][RP_FEAT];
+    double wt[T];
+    const float* ftg = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
+#pragma unroll
+    for (int p = 0; p < TP; ++p) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int j = (2 * p + h2) * 64 + lane;
+            const bool ok = j < nt;
+            const float* src = ftg + (size_t)(ok ? j : 0) * RP_FEAT;
+            wt[2 * p + h2] = ok ? kp.weight_t[(size_t)b * kp.nt_max + j] : 0.0;
+#pragma unroll
+            for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
+                const float4 v = rp_ldg4(src + 4 * c4);
+                const float q0 = ok ? v.x / 100.0f : 0.0f, q1 = ok ? v.y / 100.0f : 0.0f, q2 = ok ? v.z / 100.0f : 0.0f, q3 = ok ? v.w / 100.0f : 0.0f;
+                if (h2 == 0) { ft[p][4 * c4].x = q0; ft[p][4 * c4 + 1].x = q1; ft[p][4 * c4 + 2].x = q2; ft[p][4 * c4 + 3].x = q3; }
+                else { ft[p][4 * c4].y = q0; ft[p][4 * c4 + 1].y = q1; ft[p][4 * c4 + 2].y = q2; ft[p][4 * c4 + 3].y = q3; }
+            }
+        }
+    }
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int i = row0 + rr;
+        if (i >= ns) break;
+        const size_t si = (size_t)b * kp.ns_max + i;
+        const float fsl = kp.feat_s[si * RP_FEAT + (lane & 31)] / 100.0f;
+        const double wsi = kp.weight_s[si];
+        // ---- numpy-order float32 squared distances (8 strided partial sums + fixed tree), two target slots per packed op
+        double e[T];
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            rp_v2f r8[8];
+#pragma unroll
+            for (int c = 0; c < RP_FEAT; ++c) {
+                const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fsl), c));
+                const rp_v2f sv = {sc, sc};
+                const rp_v2f df = sv - ft[p][c];
+                const rp_v2f sq = df * df;
+                if (c < 8) r8[c] = sq; else r8[c & 7] = r8[c & 7] + sq;
+            }
+            const rp_v2f d2 = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int t = 2 * p + h2;
+                const double x = (double)(h2 ? d2.y : d2.x);
+                const int cls = (wsi * wt[t] == 1.0) ? 1 : 0;
+                const double den = cls ? ac.den[1] : ac.den[0], rd = cls ? ac.rden[1] : ac.rden[0];
+                double q;
+                if (ac.exact_div) {
+                    q = x * rd;                                   // Markstein: rd = RN(1/den), one correction step = RN(x/den)
+                    const double rem = __builtin_fma(-q, den, x);
+                    q = __builtin_fma(rem, rd, q);
+                } else q = x / den;
+                e[t] = (t * 64 + lane < nt) ? -q : -INFINITY;
+            }
+        }
+        // ---- K winners: largest e, ties to the smaller j
+        double ek[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) ek[t] = e[t];
+        double be[RP_MAXK];
+        int bj[RP_MAXK];
+        for (int k = 0; k < keff; ++k) {
+            double lb = ek[0];
+            int lt = 0;
+#pragma unroll
+            for (int t = 1; t < T; ++t) if (ek[t] > lb) { lb = ek[t]; lt = t; }
+            const double mx = rp_wave_max_d(lb);
+            const unsigned long long cand = __ballot(lb == mx);
+            const int jl = lt * 64 + lane;
+            int owner = __ffsll((long long)cand) - 1;
+            int jwin = __builtin_amdgcn_readlane(jl, owner);
+            if (cand & (cand - 1)) {                              // several lanes hold the same e: the smallest j wins
+                unsigned long long rest = cand & (cand - 1);
+                while (rest) {
+                    const int l2 = __ffsll((long long)rest) - 1;
+                    const int j2 = __builtin_amdgcn_readlane(jl, l2);
+                    if (j2 < jwin) { jwin = j2; owner = l2; }
+                    rest &= rest - 1;
+                }
+            }
+            be[k] = mx; bj[k] = (mx == -INFINITY) ? INT_MAX : jwin;
+            if (lane == owner) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) if (t == lt) ek[t] = -INFINITY;
+            }
+        }
+        // ---- exp only where it can matter, row norm
+        const double emax = be[0];
+        double w[T];
+        double sumsq = 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const bool need = e[t] >= emax - 110.0;               // false for the padding (-inf)
+            w[t] = 0.0;
+            if (__ballot(need)) {
+                const double v = exp(e[t]);
+                w[t] = need ? v : 0.0;
+            }
+            sumsq += w[t] * w[t];
+        }
+        const double nm = sqrt(rp_wave_sum(sumsq));
+        if (lane < keff) {
+            double mybe = be[0];
+            int mybj = bj[0];
+#pragma unroll
+            for (int k = 1; k < RP_MAXK; ++k) if (k == lane) { mybe = be[k]; mybj = bj[k]; }
+            const bool ok = mybj >= 0 && mybj < nt;
+            corres_j[si * topK + lane] = ok ? mybj : 0;
+            corres_w[si * topK + lane] = (ok && nm != 0.0) ? exp(mybe) / nm : 0.0;
+        }
+        if (WRITE_WIJ) {
+            float* row = wij + si * kp.nt_max;
+            const double inm = (nm != 0.0) ? 1.0 / nm : 0.0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = t * 64 + lane;
+                if (j < nt) row[j] = (float)(w[t] * inm);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ pair consistency
 __global__ __launch_bounds__(256) void pair_flags_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK) {
     const int b = blockIdx.y;
@@ -277,7 +448,7 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Gra
         const unsigned long long m = __ballot(bit);
         if (bit) {
             const int pos = run + __popcll(m & lt);
-            g.col[eoff + pos] = r;
+            g.col[eoff + pos] = g.pack_rows ? (r | (c << 16)) : r;
             g.wv[eoff + pos] = w;
         }
         run += __popcll(m);
@@ -298,7 +469,7 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Gra
         }
         if (bit) {
             const int pos = run + __popcll(word & lt);
-            g.col[eoff + pos] = c2;
+            g.col[eoff + pos] = g.pack_rows ? (c2 | (c << 16)) : c2;
             g.wv[eoff + pos] = w;
         }
         run += __popcll(word);
@@ -323,7 +494,7 @@ __device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, do
 }
 
 // centre with position weights, Horn, residuals; optionally IRLS-reweight (rpmodule.py:236-255).
-__device__ void fit_solve(const FitCtx& f, bool reweight, double R[3][3], double t[3]) {
+__device__ __attribute__((noinline)) void fit_solve(const FitCtx& f, bool reweight, double R[3][3], double t[3]) {
     double s7[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
         double sp[3], tp[3], sn[3], tn[3];
@@ -618,6 +789,336 @@ __global__ __launch_bounds__(256) void eig_finish_kernel(RelposeKeypoints kp, Gr
     if (gl == 0) g.state[((size_t)b * 4 + 0) * g.Cmax + c] = s;
 }
 
+// ------------------------------------------------------------------ single-workgroup fit (the default path)
+// One 1024-thread workgroup per scan pair runs the WHOLE fit of rpmodule.py:212-315 in one launch: status
+// finalisation, geometry gather, degrees, the IRLS iterations and the five spectral rounds.  The pair's
+// compatibility graph (symmetric CSR, ~36 k directed edges at N = 200) is streamed from L2 once per
+// matrix-vector product as contiguous, fully coalesced edge ranges; every vector the products gather from
+// (the Lanczos vector, h) lives in LDS.  The leading eigenvector comes from a Lanczos iteration with full
+// re-orthogonalisation (two classical Gram-Schmidt passes against the whole basis, kept in global scratch),
+// restarted from the Ritz vector until the residual estimate beta_m |s_m| <= RP_LZ_TOL * theta -- i.e. a
+// CONVERGED eigenvector like the reference's ARPACK call (rpmodule.py:273), where round 1 ran a capped power
+// iteration.  A pair that is still not converged after RP_LZ_CYCLES restarts gets RELPOSE_NOT_CONVERGED.
+// All reductions have a fixed order: results are bitwise reproducible and independent of the batch.
+#define RP_FIT1_THREADS 1024
+#define RP_LZ_M 24              // Lanczos steps per cycle
+#define RP_LZ_CYCLES 8          // restarts before giving up (RP_LZ_M * RP_LZ_CYCLES products at most)
+#define RP_LZ_TOL 1e-13
+#define RP_FIT1_MAXC 5000       // LDS: 3 vectors of C doubles + (C + 1) row pointers
+
+
+struct Fit1 {                   // LDS layout + per-pair pointers of the single-workgroup fit
+    double* vec;                // [C] current Lanczos vector / eigenvector (gather source of the products)
+    double* hh;                 // [C] h = relu(50 - r)
+    double* yy;                 // [C] product output
+    int32_t* rp;                // [C + 1]
+    int32_t* split;             // [65] row range of every 16-lane group (balanced by edge count)
+    double* red;                // [160] reduction scratch
+    double* cbuf;               // [RP_LZ_M + 1] Gram-Schmidt coefficients
+    double* tri;                // [4 * (RP_LZ_M + 1)] alpha, beta, s, scratch of the tridiagonal solve
+    const int32_t* col; const double* wv; double* xe;      // this pair's edges (global)
+    double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
+    int C, Cmax;
+};
+
+// One pass over the pair's edges.  16-lane group g owns the contiguous rows [split[g], split[g+1]) and streams
+// their contiguous edge range, 16 edges per step (4 steps in flight); equal-row runs inside a step are summed by a
+// segmented DPP scan and the run's last lane adds the sum to out[row] (rows never straddle groups; steps of a group
+// are sequential: fixed summation order).  col packs (row << 16 | column).
+//   MODE 0: val = w                                   (weighted degrees)
+//   MODE 1: val = (base * (h[r] + h[cc])) * u[cc]      (rpmodule.py:262-267; base = w, or mu * xe for 'spectral' rounds > 0)
+//   MODE 2: val = x = relu(u[r] * u[cc]) * w           (rpmodule.py:277-280); x is stored to xe when store_x
+template <int MODE>
+__device__ __forceinline__ void edge_pass(const Fit1& f, double* out, double mu_xe, bool store_x) {
+    for (int c = threadIdx.x; c < f.C; c += blockDim.x) out[c] = 0.0;
+    __syncthreads();
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int e0 = f.rp[f.split[g]], e1 = f.rp[f.split[g + 1]];
+    const double* base = (MODE == 1 && mu_xe != 0.0) ? f.xe : f.wv;
+    for (int eb = e0; eb < e1; eb += 64) {
+        int rc[4]; double w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = eb + q * 16 + l;
+            const bool ok = e < e1;
+            rc[q] = ok ? f.col[e] : -1;
+            w[q] = ok ? base[e] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = rc[q] >= 0;
+            const int r = ok ? (rc[q] >> 16) : 0, cc = ok ? (rc[q] & 0xffff) : 0;
+            const int key = ok ? r + 1 : 0;
+            double val;
+            if (MODE == 0) val = w[q];
+            else if (MODE == 1) {
+                const double b = (mu_xe != 0.0) ? mu_xe * w[q] : w[q];
+                val = (b * (f.hh[r] + f.hh[cc])) * f.vec[cc];
+            } else {
+                double x = f.vec[r] * f.vec[cc];
+                x = (x < 0.0 ? 0.0 : x) * w[q];
+                if (store_x && ok) f.xe[eb + q * 16 + l] = x;
+                val = x;
+            }
+            if (!ok) val = 0.0;
+#define RP_SEG_STEP(n)                                                    \
+            {                                                             \
+                const int ok_ = rp_dpp<RP_ROW_SHR(n)>(key);               \
+                const double ov_ = rp_dpp_d<RP_ROW_SHR(n)>(val);          \
+                if (ok_ == key) val += ov_;                               \
+            }
+            RP_SEG_STEP(1) RP_SEG_STEP(2) RP_SEG_STEP(4) RP_SEG_STEP(8)
+#undef RP_SEG_STEP
+            const int nxt = rp_dpp<RP_ROW_SHL(1)>(key);
+            if (key != 0 && nxt != key) out[r] += val;
+        }
+    }
+    __syncthreads();
+}
+
+// Largest eigenpair of the symmetric tridiagonal T (alpha[0..m), beta[0..m-1)) on ONE wave: eigenvalue by 64-way
+// multisection on Sturm counts, eigenvector by two steps of inverse iteration with theta shifted just above the
+// spectrum (theta I - T is then positive definite: LDL^T without pivoting).  s is normalised.  Returns theta.
+__device__ double tridiag_top(const double* alpha, const double* beta, int m, double* s, double* dscr) {
+    const int lane = threadIdx.x & 63;
+    double lo = -INFINITY, hi = -INFINITY, scale = 0.0;
+    for (int k = 0; k < m; ++k) {
+        const double bl = k > 0 ? fabs(beta[k - 1]) : 0.0, br = k < m - 1 ? fabs(beta[k]) : 0.0;
+        lo = fmax(lo, alpha[k]);                                       // lambda_max >= every diagonal entry
+        hi = fmax(hi, alpha[k] + bl + br);                              // Gershgorin
+        scale = fmax(scale, fabs(alpha[k]) + bl + br);
+    }
+    if (!(scale > 0.0)) { for (int k = lane; k < m; k += 64) s[k] = (k == 0) ? 1.0 : 0.0; return 0.0; }
+    const double tiny = scale * 1e-300 + 1e-300;
+    lo -= scale * 1e-15; hi += scale * 1e-15;
+    for (int round = 0; round < 10; ++round) {
+        const double x = lo + (hi - lo) * ((double)(lane + 1) / 64.0);          // lane 63 tests hi itself
+        int cnt = 0;
+        double q = alpha[0] - x;
+        if (q == 0.0) q = -tiny;
+        cnt += q < 0.0;
+        for (int k = 1; k < m; ++k) {
+            q = (alpha[k] - x) - (beta[k - 1] * beta[k - 1]) / q;
+            if (q == 0.0) q = -tiny;
+            cnt += q < 0.0;
+        }
+        const unsigned long long all = __ballot(cnt == m);                     // x is above the whole spectrum
+        const int first = all ? __ffsll((long long)all) - 1 : 63;
+        const double nlo = (first == 0) ? lo : lo + (hi - lo) * ((double)first / 64.0);
+        const double nhi = lo + (hi - lo) * ((double)(first + 1) / 64.0);
+        lo = nlo; hi = nhi;
+    }
+    const double theta = hi;                                                    // >= lambda_max, within ~1e-16 relative
+    if (lane == 0) {
+        const double sh = theta + scale * 4e-16;
+        double* d = dscr;                       // pivots of theta I - T
+        d[0] = sh - alpha[0];
+        if (!(d[0] > tiny)) d[0] = tiny;
+        for (int k = 1; k < m; ++k) {
+            d[k] = (sh - alpha[k]) - (beta[k - 1] * beta[k - 1]) / d[k - 1];
+            if (!(d[k] > scale * 1e-18)) d[k] = scale * 1e-18;
+        }
+        for (int k = 0; k < m; ++k) s[k] = 1.0;
+        for (int it = 0; it < 3; ++it) {
+            // (theta I - T) = L D L^T with L unit lower bidiagonal, l_k = -beta_k / d_k
+            for (int k = 1; k < m; ++k) s[k] = s[k] + (beta[k - 1] / d[k - 1]) * s[k - 1];      // L z = b
+            for (int k = 0; k < m; ++k) s[k] = s[k] / d[k];                                     // D
+            for (int k = m - 2; k >= 0; --k) s[k] = s[k] + (beta[k] / d[k]) * s[k + 1];         // L^T
+            double nn = 0.0;
+            for (int k = 0; k < m; ++k) nn += s[k] * s[k];
+            nn = 1.0 / sqrt(nn);
+            for (int k = 0; k < m; ++k) s[k] *= nn;
+        }
+    }
+    return theta;
+}
+
+// Leading eigenvector of the pair's matrix (see edge_pass MODE 1) into f.vec; returns the number of products.
+// *converged = 0 when the residual estimate stays above tolerance after RP_LZ_CYCLES cycles.
+__device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
+    const int C = f.C, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const double u0 = 1.0 / sqrt((double)C);
+    for (int c = tid; c < C; c += blockDim.x) f.vec[c] = u0;
+    __syncthreads();
+    int nprod = 0;
+    *converged = 1;
+    for (int cycle = 0; cycle < RP_LZ_CYCLES; ++cycle) {
+        for (int c = tid; c < C; c += blockDim.x) f.V[c] = f.vec[c];
+        int m = 0;
+        double beta_last = 0.0;
+        for (int j = 0; j < RP_LZ_M; ++j) {
+            edge_pass<1>(f, f.yy, mu_xe, false);                                   // yy = A v_j   (barriers inside)
+            ++nprod;
+            // two classical Gram-Schmidt passes against v_0..v_j; the first one's coefficient of v_j is alpha_j
+            double alpha = 0.0;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int i = wave; i <= j; i += nw) {
+                    const double* vi = f.V + (size_t)i * f.Cmax;
+                    double d = 0.0;
+                    for (int c = lane; c < C; c += 64) d += vi[c] * f.yy[c];
+                    d = rp_wave_sum(d);
+                    if (lane == 0) f.cbuf[i] = d;
+                }
+                __syncthreads();
+                alpha += f.cbuf[j];
+                for (int c = tid; c < C; c += blockDim.x) {
+                    double acc = f.yy[c];
+                    for (int i = 0; i <= j; ++i) acc -= f.cbuf[i] * f.V[(size_t)i * f.Cmax + c];
+                    f.yy[c] = acc;
+                }
+                __syncthreads();
+            }
+            double nn[1] = {0.0};
+            for (int c = tid; c < C; c += blockDim.x) nn[0] += f.yy[c] * f.yy[c];
+            rp_block_sum<1>(nn, f.red);
+            const double beta = sqrt(nn[0]);
+            if (tid == 0) { f.tri[j] = alpha; f.tri[(RP_LZ_M + 1) + j] = beta; }
+            m = j + 1;
+            beta_last = beta;
+            const double anorm = fabs(alpha) + beta;
+            if (!(beta > 1e-14 * anorm)) { beta_last = 0.0; break; }               // invariant subspace (or the zero matrix): exact
+            if (j + 1 < RP_LZ_M) {
+                const double inv = 1.0 / beta;
+                double* vn = f.V + (size_t)(j + 1) * f.Cmax;
+                for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; vn[c] = v; f.vec[c] = v; }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        // Ritz pair of the m x m tridiagonal matrix
+        double theta = 0.0;
+        if (wave == 0) {
+            theta = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri + 3 * (RP_LZ_M + 1));
+            if (lane == 0) f.red[159] = theta;
+        }
+        __syncthreads();
+        theta = f.red[159];
+        const double* sv = f.tri + 2 * (RP_LZ_M + 1);
+        const double resid = beta_last * fabs(sv[m - 1]);
+        if (!(theta > 0.0) && m == 1) {
+            // A v0 = 0 (zero matrix / no active edges): keep the start vector, like the round-1 solver
+            for (int c = tid; c < C; c += blockDim.x) f.vec[c] = f.V[c];
+            __syncthreads();
+            return nprod;
+        }
+        // u = sum_i s_i v_i, normalised
+        double nn[1] = {0.0};
+        for (int c = tid; c < C; c += blockDim.x) {
+            double acc = 0.0;
+            for (int i = 0; i < m; ++i) acc += sv[i] * f.V[(size_t)i * f.Cmax + c];
+            f.yy[c] = acc;
+            nn[0] += acc * acc;
+        }
+        rp_block_sum<1>(nn, f.red);
+        const double inv = 1.0 / sqrt(nn[0]);
+        for (int c = tid; c < C; c += blockDim.x) f.vec[c] = f.yy[c] * inv;
+        __syncthreads();
+        if (resid <= RP_LZ_TOL * fabs(theta)) return nprod;
+    }
+    *converged = 0;
+    return nprod;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK, int method,
+                                                                    double* __restrict__ lz_basis, int32_t* __restrict__ status,
+                                                                    double* __restrict__ pose, double* __restrict__ trace,
+                                                                    int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[160];
+    __shared__ int st_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int C = pair_C(kp, g, b);
+    if (tid == 0) {
+        int st = status[b];
+        if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
+        st_s = st;
+        if (counts_out) {
+            counts_out[b * 4 + 0] = g.counters[b * 4 + 0];
+            counts_out[b * 4 + 1] = g.counters[b * 4 + 1];
+            counts_out[b * 4 + 2] = g.counters[b * 4 + 2] / 2;
+            counts_out[b * 4 + 3] = (kp.ns[b] >= 3 && kp.nt[b] >= 3) ? g.keff[b] : 0;
+        }
+    }
+    __syncthreads();
+    if (st_s != RELPOSE_OK) {                             // identity, like the reference's early returns
+        if (tid == 0) status[b] = st_s;
+        if (tid < 16) pose[(size_t)b * 16 + tid] = (tid % 5 == 0) ? 1.0 : 0.0;
+        if (trace && tid < 96) trace[(size_t)b * 96 + tid] = ((tid % 16) % 5 == 0) ? 1.0 : 0.0;
+        if (eig_iters_out && tid < 5) eig_iters_out[b * 5 + tid] = 0;
+        return;
+    }
+    Fit1 f;
+    f.C = C; f.Cmax = g.Cmax;
+    f.vec = (double*)smem; f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
+    f.tri = f.yy + g.Cmax; f.cbuf = f.tri + 4 * (RP_LZ_M + 1);
+    f.rp = (int32_t*)(f.cbuf + (RP_LZ_M + 1)); f.split = f.rp + (g.Cmax + 1);
+    f.red = red;
+    const size_t eoff = (size_t)b * g.max_edges;
+    f.col = g.col + eoff; f.wv = g.wv + eoff; f.xe = g.xe + eoff;
+    f.V = lz_basis + (size_t)b * (RP_LZ_M + 1) * g.Cmax;
+    const int32_t* rpg = g.rowptr + (size_t)b * (g.Cmax + 1);
+    for (int c = tid; c <= C; c += blockDim.x) f.rp[c] = rpg[c];
+    __syncthreads();
+    const int ngroups = THREADS / 16;
+    if (tid <= ngroups) {                                 // row ranges with ~E/ngroups edges each (first row whose start >= g E / ngroups)
+        const long long E = f.rp[C];
+        const int target = (int)((E * tid) / ngroups);
+        int lo = 0, hi = C;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (f.rp[mid] < target) lo = mid + 1; else hi = mid; }
+        f.split[tid] = (tid == ngroups) ? C : lo;
+    }
+    __syncthreads();
+    FitCtx fc;
+    fc.b = b; fc.C = C; fc.mu = kc.mu;
+    fc.deg = g.state + ((size_t)b * 4 + 0) * g.Cmax; fc.gP = g.state + ((size_t)b * 4 + 1) * g.Cmax;
+    fc.gN = g.state + ((size_t)b * 4 + 2) * g.Cmax; fc.rsum = g.state + ((size_t)b * 4 + 3) * g.Cmax;
+    fc.red = red;
+    fc.geo = g.geo + (size_t)b * g.Cmax * 12;
+    {   // geometry of every correspondence (gathered once), weighted degrees of the raw pair weights
+        const int keff = g.keff[b];
+        double* geo = g.geo + (size_t)b * g.Cmax * 12;
+        for (int idx = tid; idx < C * 12; idx += blockDim.x) {
+            const int c = idx / 12, gl = idx - c * 12;
+            const int i = c / keff, kk = c - i * keff;
+            const size_t si = (size_t)b * kp.ns_max + i;
+            const int j = g.corres_j[si * topK + kk];
+            const size_t ti = (size_t)b * kp.nt_max + j;
+            const int a = gl % 3, what = gl / 3;
+            geo[idx] = what == 0 ? kp.pc_s[si * 3 + a] : what == 1 ? kp.pc_t[ti * 3 + a] : what == 2 ? kp.normal_s[si * 3 + a] : kp.normal_t[ti * 3 + a];
+        }
+        edge_pass<0>(f, f.yy, 0.0, false);
+        for (int c = tid; c < C; c += blockDim.x) { fc.deg[c] = f.yy[c]; fc.gP[c] = 1.0; fc.gN[c] = 1.0; fc.rsum[c] = 0.0; }
+        __syncthreads();
+    }
+    const bool irls0 = (method == RELPOSE_FIT_IRLS_SM || method == RELPOSE_FIT_IRLS);
+    double R[3][3], t[3];
+    for (int it = 0; it < (irls0 ? 5 : 1); ++it) fit_solve(fc, irls0, R, t);
+    write_pose(pose + (size_t)b * 16, R, t);
+    if (trace) write_pose(trace + (size_t)b * 96, R, t);
+    int all_converged = 1;
+    if (method == RELPOSE_FIT_IRLS_SM || method == RELPOSE_FIT_SPECTRAL) {
+        const bool sm = (method == RELPOSE_FIT_IRLS_SM);
+        for (int round = 0; round < 5; ++round) {
+            for (int c = tid; c < C; c += blockDim.x) { const double v = RP_OFFSET - fc.rsum[c]; f.hh[c] = v < 0.0 ? 0.0 : v; }
+            __syncthreads();
+            int conv = 1;
+            const int np = lanczos_top(f, (!sm && round > 0) ? kc.mu : 0.0, &conv);
+            all_converged &= conv;
+            if (eig_iters_out && tid == 0) eig_iters_out[b * 5 + round] = np;
+            edge_pass<2>(f, f.yy, 0.0, !sm);                                   // x per edge, new weighted degrees
+            for (int c = tid; c < C; c += blockDim.x) { fc.deg[c] = f.yy[c]; fc.gP[c] = 1.0; fc.gN[c] = 1.0; }
+            __syncthreads();
+            for (int it = 0; it < (sm ? 5 : 1); ++it) fit_solve(fc, sm, R, t);
+            write_pose(pose + (size_t)b * 16, R, t);
+            if (trace) write_pose(trace + (size_t)b * 96 + (round + 1) * 16, R, t);
+        }
+    } else if (trace) {
+        for (int q = 1; q < 6; ++q) write_pose(trace + (size_t)b * 96 + q * 16, R, t);
+    }
+    if (tid == 0) status[b] = all_converged ? RELPOSE_OK : RELPOSE_NOT_CONVERGED;
+}
+
 RpPairConsts make_consts(const RelposeParams& p) {
     RpPairConsts k;
     k.dist_thre2 = p.distThre * p.distThre;
@@ -639,7 +1140,39 @@ bool kp_ok(const RelposeKeypoints* kp, const RelposeParams* p) {
            kp->weight_s && kp->weight_t;
 }
 
+template <int TP>
+int launch_affinity_rows(const RelposeKeypoints& kp, const AffConsts& ac, int topK, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
+    // ~2 waves per SIMD over the whole chip, between 2 and 32 rows per wave (the per-wave target staging costs ~2 rows' worth)
+    const long long rows = (long long)kp.B * kp.ns_max;
+    int rpw = (int)((rows + 2047) / 2048);
+    rpw = rpw < 2 ? 2 : (rpw > 32 ? 32 : rpw);
+    dim3 grid((kp.ns_max + 4 * rpw - 1) / (4 * rpw), kp.B);
+    if (wij) hipLaunchKernelGGL((affinity_rows_kernel<TP, true>), grid, dim3(256), 0, s, kp, ac, topK, rpw, wij, cj, cw, keff);
+    else hipLaunchKernelGGL((affinity_rows_kernel<TP, false>), grid, dim3(256), 0, s, kp, ac, topK, rpw, wij, cj, cw, keff);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
+    if (kp.nt_max <= 512 && !getenv("RELPOSE_LEGACY_AFFINITY")) {
+        const RpPairConsts kc0 = make_consts(p);
+        AffConsts ac;
+        ac.den[0] = kc0.den_other; ac.den[1] = kc0.den_both;
+        ac.exact_div = 1;
+        for (int q = 0; q < 2; ++q) {
+            ac.rden[q] = 1.0 / ac.den[q];
+            uint64_t bits; memcpy(&bits, &ac.den[q], 8);
+            // Markstein's theorem needs RN(1/den) and excludes an all-ones significand; fall back to the hardware division otherwise
+            if (!(ac.den[q] > 1e-290 && ac.den[q] < 1e290) || (bits & 0xfffffffffffffull) == 0xfffffffffffffull) ac.exact_div = 0;
+        }
+        const int tp = (kp.nt_max + 127) / 128;
+        switch (tp) {
+            case 1: return launch_affinity_rows<1>(kp, ac, p.topK, wij, cj, cw, keff, s);
+            case 2: return launch_affinity_rows<2>(kp, ac, p.topK, wij, cj, cw, keff, s);
+            case 3: return launch_affinity_rows<3>(kp, ac, p.topK, wij, cj, cw, keff, s);
+            default: return launch_affinity_rows<4>(kp, ac, p.topK, wij, cj, cw, keff, s);
+        }
+    }
     const int ntp = (kp.nt_max + 63) & ~63;
     const size_t lds = (size_t)ntp * 8 + (size_t)RP_FEAT * (ntp + 1) * 4;
     if (lds > 160 * 1024) return RELPOSE_EINVAL;
@@ -657,8 +1190,12 @@ int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* w
     return 0;
 }
 
+// the single-workgroup fit keeps 3 vectors + the row pointers of a pair in LDS and packs (row, column) into 32 bits
+static bool fit1_ok(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && !getenv("RELPOSE_LEGACY_FIT"); }
+static size_t fit1_lds(int32_t Cmax) { return (size_t)Cmax * 24 + (size_t)(5 * (RP_LZ_M + 1)) * 8 + (size_t)(Cmax + 1) * 4 + 65 * 4 + 16; }
+
 struct WsLayout {
-    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, eig, pairC, total;
+    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, eig, pairC, lz, total;
     int32_t Cmax, Wmax;
     int64_t max_edges;
 };
@@ -687,6 +1224,7 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.geo = take((size_t)B * L.Cmax * 12 * 8);
     L.pairC = take((size_t)B * 4);
     L.eig = take((size_t)B * (4 * (size_t)L.Cmax + (L.Cmax + RP_SPMV_ROWS - 1) / RP_SPMV_ROWS) * 8 + (size_t)B * 2 * 4);
+    L.lz = take(fit1_ok(L.Cmax) ? (size_t)B * (RP_LZ_M + 1) * L.Cmax * 8 : 0);      // Lanczos basis of the single-workgroup fit
     L.total = o;
     return L;
 }
@@ -733,6 +1271,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     g.upcnt = (int32_t*)(ws + L.upcnt); g.lowcnt = (int32_t*)(ws + L.lowcnt); g.counters = (int32_t*)(ws + L.counters);
     g.rowptr = (int32_t*)(ws + L.rowptr); g.col = (int32_t*)(ws + L.col);
     g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state); g.geo = (double*)(ws + L.geo); g.pairC = (int32_t*)(ws + L.pairC);
+    g.pack_rows = fit1_ok(L.Cmax) ? 1 : 0;
     RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
     int rc = launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
     if (rc) return rc;
@@ -753,11 +1292,27 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     fs.done = (int32_t*)(fs.part + (size_t)kp->B * fs.nblk); fs.iters = fs.done + kp->B;
     double* trace = dbg ? dbg->trace : nullptr;
     int32_t* eig_iters = dbg ? dbg->eig_iters : nullptr;
+    const int m = p->method;
+    if (g.pack_rows) {
+        // ---- fit: ONE launch, one 1024-thread workgroup per pair (fit_pair_kernel)
+        const size_t lds = fit1_lds(L.Cmax);
+        static const int fit_threads = getenv("RELPOSE_FIT_THREADS") ? atoi(getenv("RELPOSE_FIT_THREADS")) : RP_FIT1_THREADS;     // experiment switch
+        if (fit_threads == 512) {
+            RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fit_pair_kernel<512>, dim3(kp->B), dim3(512), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
+                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters);
+        } else {
+            RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fit_pair_kernel<1024>, dim3(kp->B), dim3(1024), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
+                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters);
+        }
+        RP_CHECK_LAUNCH();
+    } else {
+    // ---- legacy fit for > RP_FIT1_MAXC correspondences per pair: launch sequence over the whole GPU (see fit_begin_kernel)
     dim3 grid16((L.Cmax + 15) / 16, kp->B);
-    hipLaunchKernelGGL(fit_begin_kernel, grid16, dim3(256), 0, s, *kp, g, p->topK, status, pose, trace, dbg ? dbg->counts : nullptr);
+    hipLaunchKernelGGL(fit_begin_kernel, dim3((L.Cmax + 15) / 16, kp->B), dim3(256), 0, s, *kp, g, p->topK, status, pose, trace, dbg ? dbg->counts : nullptr);
     hipLaunchKernelGGL(fit_commit_status_kernel, dim3((kp->B + 63) / 64), dim3(64), 0, s, *kp, g, status, kp->B);
     RP_CHECK_LAUNCH();
-    const int m = p->method;
     const bool irls0 = (m == RELPOSE_FIT_IRLS_SM || m == RELPOSE_FIT_IRLS);
     hipLaunchKernelGGL(fit_irls_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), 0, s, *kp, g, kc, irls0 ? 5 : 1, irls0 ? 1 : 0, 0, status, pose,
                        trace);
@@ -784,6 +1339,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
         for (int q = 1; q < 6; ++q)
             RP_HIP(hipMemcpy2DAsync(trace + q * 16, 96 * sizeof(double), pose, 16 * sizeof(double), 16 * sizeof(double), kp->B,
                                     hipMemcpyDeviceToDevice, s));
+    }
     }
     if (dbg && dbg->corres_j)
         RP_HIP(hipMemcpyAsync(dbg->corres_j, cj, (size_t)kp->B * kp->ns_max * p->topK * 4, hipMemcpyDeviceToDevice, s));

@@ -3,7 +3,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from relativepose_amd import synth, rpmodule
-from bench import SUNCG_SIGMAS
+from relativepose_amd.params import FINAL_PARAMS
+SUNCG_SIGMAS = FINAL_PARAMS["suncg"]
 dev = torch.device("cuda", 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 base = [synth.make_match_case(N, 5000 + b)[:2] for b in range(32)]

@@ -6,7 +6,8 @@ import numpy as np, torch
 from relativepose_amd import synth, weights, rpmodule
 from relativepose_amd.model import SCNet
 from relativepose_amd.pipeline import RelativePosePipeline
-from bench import SUNCG_SIGMAS
+from relativepose_amd.params import FINAL_PARAMS
+SUNCG_SIGMAS = FINAL_PARAMS["suncg"]
 B, N, S = 16, 200, 15
 dev = torch.device("cuda", 0)
 data = synth.make_pairs(B, 2000, "suncg"); pts, ptw = synth.make_keypoints(B, N, 2000, "second")
