@@ -49,11 +49,28 @@ __device__ __forceinline__ double rp_shfl_d(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// Fixed-order butterfly sum over the 64 lanes of a wave (deterministic).
+// DPP lane exchanges (no LDS): bound_ctrl on, lanes without a source read 0
+template <int CTRL>
+__device__ __forceinline__ int rp_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ double rp_dpp_d(double v) {
+    return __hiloint2double(rp_dpp<CTRL>(__double2hiint(v)), rp_dpp<CTRL>(__double2loint(v)));
+}
+#define RP_ROW_SHR(n) (0x110 + (n))
+#define RP_ROW_SHL(n) (0x100 + (n))
+__device__ __forceinline__ double rp_readlane_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// Fixed-order sum over the 64 lanes of a wave (deterministic), result in every lane, without LDS traffic: butterfly inside
+// every row of 16 lanes with DPP (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then ((r0 + r1) + (r2 + r3)) of the
+// four row sums through SGPRs.  (The ds_bpermute butterfly this replaces cost ~1.2 k cycles of LDS latency per double.)
 __device__ __forceinline__ double rp_wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += rp_shfl_xor_d(v, m);
-    return v;
+    v += rp_dpp_d<0xB1>(v);
+    v += rp_dpp_d<0x4E>(v);
+    v += rp_dpp_d<0x141>(v);
+    v += rp_dpp_d<0x140>(v);
+    return (rp_readlane_d(v, 0) + rp_readlane_d(v, 16)) + (rp_readlane_d(v, 32) + rp_readlane_d(v, 48));
 }
 __device__ __forceinline__ int rp_wave_sum_i(int v) {
 #pragma unroll

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "rp_math.h"
 #include <limits.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -50,24 +51,25 @@ struct Graph {                 // per-batch device arrays of the pair-compatibil
     double* state;             // [B, 4, Cmax]  deg, gP, gN, rsum
     double* geo;               // [B, Cmax, 12]  sp, tp, sn, tn of every correspondence (gathered once per fit)
     int32_t* pairC;            // [B] number of correspondences of a pair whose fit is running, 0 otherwise
-    int32_t pack_rows;         // col[] holds (row << 16 | column): the single-workgroup fit (fit_pair_kernel) reads both from one word
+    // Edge storage.  seg_layout == 0 (legacy launch-sequence fit): plain CSR, edge k of row c at rowptr[c] + k.
+    // seg_layout == 1 (single-workgroup fit): every row is cut into SEGMENTS of <= 32 edges; segment s = segptr[c] + k / 32
+    // lives in slot s % 64 of wave-slice s / 64, edge k % 32 of it at ((s >> 6) << 11) + ((k & 31) << 6) + (s & 63): the 64
+    // lanes of a wave, each walking its own segment, read 64 consecutive entries per step (SELL-64 over segments).
+    int32_t seg_layout;
+    int32_t seg_cap;           // segments per pair the edge arrays are sized for (multiple of 64)
+    int64_t estride;           // entries of col / wv / xe per pair
+    int32_t* segptr;           // [B, Cmax+1] first segment of every row
+    int32_t* segrow;           // [B, seg_cap] row of every segment
+    double* part;              // [B, seg_cap] per-segment partial sums of the edge passes
 };
+#define RP_SEG 32
+__device__ __forceinline__ size_t seg_edge_index(int seg, int k) { return ((size_t)(seg >> 6) << 11) + ((size_t)(k & 31) << 6) + (seg & 63); }
 
 __device__ __forceinline__ int pair_C(const RelposeKeypoints& kp, const Graph& g, int b) {
     int ns = kp.ns[b], nt = kp.nt[b];
     if (ns < 3 || nt < 3) return 0;
     return ns * g.keff[b];
 }
-
-// DPP lane exchanges (no LDS): bound_ctrl on, lanes without a source read 0
-template <int CTRL>
-__device__ __forceinline__ int rp_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-template <int CTRL>
-__device__ __forceinline__ double rp_dpp_d(double v) {
-    return __hiloint2double(rp_dpp<CTRL>(__double2hiint(v)), rp_dpp<CTRL>(__double2loint(v)));
-}
-#define RP_ROW_SHR(n) (0x110 + (n))
-#define RP_ROW_SHL(n) (0x100 + (n))
 
 struct Corr { double ps[3], ns[3], pt[3], nt[3]; double f, ws, wt; };
 
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
     if (row0 >= ns) return;
-    // ---- this lane's targets: descriptors / 100 (float32 division like numpy), weights
+    // ---- this lane's targets: descriptors / 100 (float32 division like numpy), observed-weight flags
     rp_v2f ft[TP][RP_FEAT];
     double wt[T];
     const float* ftg = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
@@ -252,6 +254,9 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
         const size_t si = (size_t)b * kp.ns_max + i;
         const float fsl = kp.feat_s[si * RP_FEAT + (lane & 31)] / 100.0f;
         const double wsi = kp.weight_s[si];
+        float sc[RP_FEAT];                       // the row's descriptor, wave-uniform (SGPRs)
+#pragma unroll
+        for (int c = 0; c < RP_FEAT; ++c) sc[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fsl), c));
         // ---- numpy-order float32 squared distances (8 strided partial sums + fixed tree), two target slots per packed op
         double e[T];
 #pragma unroll
@@ -259,8 +264,7 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
             rp_v2f r8[8];
 #pragma unroll
             for (int c = 0; c < RP_FEAT; ++c) {
-                const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fsl), c));
-                const rp_v2f sv = {sc, sc};
+                const rp_v2f sv = {sc[c], sc[c]};
                 const rp_v2f df = sv - ft[p][c];
                 const rp_v2f sq = df * df;
                 if (c < 8) r8[c] = sq; else r8[c & 7] = r8[c & 7] + sq;
@@ -270,14 +274,11 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int t = 2 * p + h2;
                 const double x = (double)(h2 ? d2.y : d2.x);
-                const int cls = (wsi * wt[t] == 1.0) ? 1 : 0;
+                const bool cls = (wsi * wt[t] == 1.0);
                 const double den = cls ? ac.den[1] : ac.den[0], rd = cls ? ac.rden[1] : ac.rden[0];
-                double q;
-                if (ac.exact_div) {
-                    q = x * rd;                                   // Markstein: rd = RN(1/den), one correction step = RN(x/den)
-                    const double rem = __builtin_fma(-q, den, x);
-                    q = __builtin_fma(rem, rd, q);
-                } else q = x / den;
+                double q = x * rd;                                    // Markstein: rd = RN(1/den), one correction step = RN(x/den)
+                const double rem = __builtin_fma(-q, den, x);
+                q = __builtin_fma(rem, rd, q);
                 e[t] = (t * 64 + lane < nt) ? -q : -INFINITY;
             }
         }
@@ -287,29 +288,33 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
         for (int t = 0; t < T; ++t) ek[t] = e[t];
         double be[RP_MAXK];
         int bj[RP_MAXK];
-        for (int k = 0; k < keff; ++k) {
-            double lb = ek[0];
-            int lt = 0;
 #pragma unroll
-            for (int t = 1; t < T; ++t) if (ek[t] > lb) { lb = ek[t]; lt = t; }
-            const double mx = rp_wave_max_d(lb);
-            const unsigned long long cand = __ballot(lb == mx);
-            const int jl = lt * 64 + lane;
-            int owner = __ffsll((long long)cand) - 1;
-            int jwin = __builtin_amdgcn_readlane(jl, owner);
-            if (cand & (cand - 1)) {                              // several lanes hold the same e: the smallest j wins
-                unsigned long long rest = cand & (cand - 1);
-                while (rest) {
-                    const int l2 = __ffsll((long long)rest) - 1;
-                    const int j2 = __builtin_amdgcn_readlane(jl, l2);
-                    if (j2 < jwin) { jwin = j2; owner = l2; }
-                    rest &= rest - 1;
+        for (int k = 0; k < RP_MAXK; ++k) {
+            be[k] = -INFINITY; bj[k] = INT_MAX;
+            if (k < keff) {
+                double lb = ek[0];
+                int lt = 0;
+#pragma unroll
+                for (int t = 1; t < T; ++t) if (ek[t] > lb) { lb = ek[t]; lt = t; }
+                const double mx = rp_wave_max_d(lb);
+                const unsigned long long cand = __ballot(lb == mx);
+                const int jl = lt * 64 + lane;
+                int owner = __ffsll((long long)cand) - 1;
+                int jwin = __builtin_amdgcn_readlane(jl, owner);
+                if (cand & (cand - 1)) {                              // several lanes hold the same e: the smallest j wins
+                    unsigned long long rest = cand & (cand - 1);
+                    while (rest) {
+                        const int l2 = __ffsll((long long)rest) - 1;
+                        const int j2 = __builtin_amdgcn_readlane(jl, l2);
+                        if (j2 < jwin) { jwin = j2; owner = l2; }
+                        rest &= rest - 1;
+                    }
                 }
-            }
-            be[k] = mx; bj[k] = (mx == -INFINITY) ? INT_MAX : jwin;
-            if (lane == owner) {
+                be[k] = mx; bj[k] = (mx == -INFINITY) ? INT_MAX : jwin;
+                if (lane == owner) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) if (t == lt) ek[t] = -INFINITY;
+                    for (int t = 0; t < T; ++t) if (t == lt) ek[t] = -INFINITY;
+                }
             }
         }
         // ---- exp only where it can matter, row norm
@@ -327,18 +332,20 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
             sumsq += w[t] * w[t];
         }
         const double nm = sqrt(rp_wave_sum(sumsq));
-        if (lane < keff) {
-            double mybe = be[0];
-            int mybj = bj[0];
+        const double inm = (nm != 0.0) ? 1.0 / nm : 0.0;
+        {   // the K outputs: lane k takes winner k (exp + one division per lane, all K in parallel)
+            double mybe = -INFINITY;
+            int mybj = INT_MAX;
 #pragma unroll
-            for (int k = 1; k < RP_MAXK; ++k) if (k == lane) { mybe = be[k]; mybj = bj[k]; }
-            const bool ok = mybj >= 0 && mybj < nt;
-            corres_j[si * topK + lane] = ok ? mybj : 0;
-            corres_w[si * topK + lane] = (ok && nm != 0.0) ? exp(mybe) / nm : 0.0;
+            for (int k = 0; k < RP_MAXK; ++k) if (k == lane) { mybe = be[k]; mybj = bj[k]; }
+            if (lane < keff) {
+                const bool ok = mybj >= 0 && mybj < nt;
+                corres_j[si * topK + lane] = ok ? mybj : 0;
+                corres_w[si * topK + lane] = (ok && nm != 0.0) ? exp(mybe) / nm : 0.0;
+            }
         }
         if (WRITE_WIJ) {
             float* row = wij + si * kp.nt_max;
-            const double inm = (nm != 0.0) ? 1.0 / nm : 0.0;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int j = t * 64 + lane;
@@ -406,8 +413,37 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Gr
         if (threadIdx.x == 1023) carry_s = pre + inc;
         __syncthreads();
     }
+    const int total_edges = carry_s;
+    __syncthreads();
+    if (g.seg_layout) {          // first segment of every row + the row of every segment
+        int32_t* sp = g.segptr + (size_t)b * (g.Cmax + 1);
+        int32_t* sr = g.segrow + (size_t)b * g.seg_cap;
+        if (threadIdx.x == 0) carry_s = 0;
+        __syncthreads();
+        for (int base = 0; base < C; base += 1024) {
+            const int c = base + threadIdx.x;
+            const int deg = (c < C) ? g.upcnt[(size_t)b * g.Cmax + c] + g.lowcnt[(size_t)b * g.Cmax + c] : 0;
+            const int v = (deg + RP_SEG - 1) / RP_SEG;
+            int inc = v;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) { int t = __shfl_up(inc, m, 64); if (lane >= m) inc += t; }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            int pre = carry_s;
+            for (int w = 0; w < wave; ++w) pre += wsum[w];
+            if (c < C) {
+                const int first = pre + inc - v;
+                sp[c] = first;
+                if (first + v <= g.seg_cap) for (int i = 0; i < v; ++i) sr[first + i] = c;
+            }
+            __syncthreads();
+            if (threadIdx.x == 1023) carry_s = pre + inc;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sp[C] = carry_s;
+    }
     if (threadIdx.x == 0) {
-        const int total = carry_s;
+        const int total = total_edges;
         rp[C] = total;
         int st = RELPOSE_OK;
         if (C < 3) st = RELPOSE_FEW_KEYPOINTS;
@@ -429,9 +465,17 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Gra
     const int keff = g.keff[b];
     Corr me;
     load_corr(kp, g, b, topK, keff, c, me);
-    const size_t eoff = (size_t)b * g.max_edges;
-    int run = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
+    const size_t eoff = (size_t)b * g.estride;
+    const int row_start = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
+    const int seg0 = g.seg_layout ? g.segptr[(size_t)b * (g.Cmax + 1) + c] : 0;
+    int run = row_start;
     int nz = 0;
+    // position of the k-th edge of this row in the edge arrays
+    auto edge_pos = [&](int pos) -> size_t {
+        if (!g.seg_layout) return (size_t)pos;
+        const int k = pos - row_start;
+        return seg_edge_index(seg0 + (k >> 5), k);
+    };
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // lower part: pairs (r, c), r < c  -- canonical orientation "1" = r, "2" = c
     for (int ch = 0; ch * 64 < c; ++ch) {
@@ -447,8 +491,8 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Gra
         }
         const unsigned long long m = __ballot(bit);
         if (bit) {
-            const int pos = run + __popcll(m & lt);
-            g.col[eoff + pos] = g.pack_rows ? (r | (c << 16)) : r;
+            const size_t pos = edge_pos(run + __popcll(m & lt));
+            g.col[eoff + pos] = r;
             g.wv[eoff + pos] = w;
         }
         run += __popcll(m);
@@ -468,8 +512,8 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Gra
             w = rp_pair_weight(ev, me.f, o.f, me.ws, o.ws, me.wt, o.wt, kc);
         }
         if (bit) {
-            const int pos = run + __popcll(word & lt);
-            g.col[eoff + pos] = g.pack_rows ? (c2 | (c << 16)) : c2;
+            const size_t pos = edge_pos(run + __popcll(word & lt));
+            g.col[eoff + pos] = c2;
             g.wv[eoff + pos] = w;
         }
         run += __popcll(word);
@@ -494,7 +538,7 @@ __device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, do
 }
 
 // centre with position weights, Horn, residuals; optionally IRLS-reweight (rpmodule.py:236-255).
-__device__ __attribute__((noinline)) void fit_solve(const FitCtx& f, bool reweight, double R[3][3], double t[3]) {
+__device__ void fit_solve(const FitCtx& f, bool reweight, double R[3][3], double t[3]) {
     double s7[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
         double sp[3], tp[3], sn[3], tn[3];
@@ -617,7 +661,7 @@ __global__ __launch_bounds__(256) void fit_begin_kernel(RelposeKeypoints kp, Gra
     }
     if (st != RELPOSE_OK) return;
     const int keff = g.keff[b];
-    const size_t eoff = (size_t)b * g.max_edges;
+    const size_t eoff = (size_t)b * g.estride;
     const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
     double* geo = g.geo + (size_t)b * g.Cmax * 12;
     double* st4 = g.state + (size_t)b * 4 * g.Cmax;
@@ -698,7 +742,7 @@ __global__ __launch_bounds__(RP_SPMV_THREADS) void eig_spmv_kernel(RelposeKeypoi
     const int C = g.pairC[b];
     if (C == 0 || fs.done[b]) return;
     if (blockIdx.x * RP_SPMV_ROWS >= C) return;
-    const size_t eoff = (size_t)b * g.max_edges;
+    const size_t eoff = (size_t)b * g.estride;
     const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
     // buffers: 0 = u (unit vector, kept for the convergence test), 1 = y2, 2 = y (the one eig_norm reads)
     const double* u = (src_sel == 0 ? fs.u : src_sel == 1 ? fs.y2 : fs.y) + (size_t)b * g.Cmax;
@@ -769,7 +813,7 @@ __global__ __launch_bounds__(256) void eig_finish_kernel(RelposeKeypoints kp, Gr
     const int b = blockIdx.y;
     const int C = g.pairC[b];
     if (C == 0) return;
-    const size_t eoff = (size_t)b * g.max_edges;
+    const size_t eoff = (size_t)b * g.estride;
     const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
     const double* u = fs.u + (size_t)b * g.Cmax;
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
@@ -792,93 +836,119 @@ __global__ __launch_bounds__(256) void eig_finish_kernel(RelposeKeypoints kp, Gr
 // ------------------------------------------------------------------ single-workgroup fit (the default path)
 // One 1024-thread workgroup per scan pair runs the WHOLE fit of rpmodule.py:212-315 in one launch: status
 // finalisation, geometry gather, degrees, the IRLS iterations and the five spectral rounds.  The pair's
-// compatibility graph (symmetric CSR, ~36 k directed edges at N = 200) is streamed from L2 once per
-// matrix-vector product as contiguous, fully coalesced edge ranges; every vector the products gather from
-// (the Lanczos vector, h) lives in LDS.  The leading eigenvector comes from a Lanczos iteration with full
-// re-orthogonalisation (two classical Gram-Schmidt passes against the whole basis, kept in global scratch),
-// restarted from the Ritz vector until the residual estimate beta_m |s_m| <= RP_LZ_TOL * theta -- i.e. a
-// CONVERGED eigenvector like the reference's ARPACK call (rpmodule.py:273), where round 1 ran a capped power
-// iteration.  A pair that is still not converged after RP_LZ_CYCLES restarts gets RELPOSE_NOT_CONVERGED.
+// compatibility graph (~31 k directed edges at N = 200) is streamed from L2 once per matrix-vector product in the
+// segment layout (see Graph): a lane walks one segment of <= 32 edges of one row, a wave reads 64 consecutive entries
+// per step, no cross-lane reduction; every vector the products gather from lives in LDS.  The leading eigenvector
+// comes from a Lanczos iteration with full re-orthogonalisation (classical Gram-Schmidt against the whole basis, a
+// second pass whenever the first one cancelled more than half of the vector; basis in global scratch), checked for
+// convergence every RP_LZ_CHECK steps and restarted from the Ritz vector until the residual estimate
+// beta_m |s_m| <= RP_LZ_TOL * theta -- i.e. a CONVERGED eigenvector like the reference's ARPACK call
+// (rpmodule.py:273), where round 1 ran a capped power iteration.  Rounds 2..5 start from the previous round's
+// eigenvector.  A pair that is still not converged after RP_LZ_MAXPROD products gets RELPOSE_NOT_CONVERGED.
 // All reductions have a fixed order: results are bitwise reproducible and independent of the batch.
 #define RP_FIT1_THREADS 1024
-#define RP_LZ_M 24              // Lanczos steps per cycle
-#define RP_LZ_CYCLES 8          // restarts before giving up (RP_LZ_M * RP_LZ_CYCLES products at most)
+#define RP_LZ_M 24              // Lanczos steps per cycle (basis size)
+#define RP_LZ_CHECK 8           // convergence test every 8 steps
+#define RP_LZ_MAXPROD 192       // products per eigen-solve before giving up
 #define RP_LZ_TOL 1e-13
-#define RP_FIT1_MAXC 5000       // LDS: 3 vectors of C doubles + (C + 1) row pointers
-
+#ifndef RP_TRI_ROUNDS
+#define RP_TRI_ROUNDS 10        // 64-way multisection rounds of the tridiagonal eigenvalue (6 bits each)
+#endif
+#define RP_FIT1_MAXC 4500       // LDS: 3 vectors of C doubles + 2 x (C + 1) ints
 
 struct Fit1 {                   // LDS layout + per-pair pointers of the single-workgroup fit
+    long long* prof;            // optional [8] cycle counters of block 0 (RELPOSE_FIT_PROF=1)
     double* vec;                // [C] current Lanczos vector / eigenvector (gather source of the products)
     double* hh;                 // [C] h = relu(50 - r)
     double* yy;                 // [C] product output
-    int32_t* rp;                // [C + 1]
-    int32_t* split;             // [65] row range of every 16-lane group (balanced by edge count)
+    int32_t* rp;                // [C + 1] CSR row pointers (row lengths)
+    int32_t* sp;                // [C + 1] first segment of every row
     double* red;                // [160] reduction scratch
     double* cbuf;               // [RP_LZ_M + 1] Gram-Schmidt coefficients
     double* tri;                // [4 * (RP_LZ_M + 1)] alpha, beta, s, scratch of the tridiagonal solve
-    const int32_t* col; const double* wv; double* xe;      // this pair's edges (global)
+    const int32_t* col; const double* wv; double* xe;      // this pair's edges (global, segment layout)
+    const int32_t* segrow; double* part;
     double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
-    int C, Cmax;
+    int C, Cmax, nseg;
 };
 
-// One pass over the pair's edges.  16-lane group g owns the contiguous rows [split[g], split[g+1]) and streams
-// their contiguous edge range, 16 edges per step (4 steps in flight); equal-row runs inside a step are summed by a
-// segmented DPP scan and the run's last lane adds the sum to out[row] (rows never straddle groups; steps of a group
-// are sequential: fixed summation order).  col packs (row << 16 | column).
+// One pass over the pair's edges: thread <-> segment (<= 32 edges of one row, read with stride 64 so that a wave's loads
+// are 64 consecutive entries), sequential accumulation per segment, then every row adds up its segments in order.
 //   MODE 0: val = w                                   (weighted degrees)
 //   MODE 1: val = (base * (h[r] + h[cc])) * u[cc]      (rpmodule.py:262-267; base = w, or mu * xe for 'spectral' rounds > 0)
 //   MODE 2: val = x = relu(u[r] * u[cc]) * w           (rpmodule.py:277-280); x is stored to xe when store_x
 template <int MODE>
-__device__ __forceinline__ void edge_pass(const Fit1& f, double* out, double mu_xe, bool store_x) {
-    for (int c = threadIdx.x; c < f.C; c += blockDim.x) out[c] = 0.0;
-    __syncthreads();
-    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int e0 = f.rp[f.split[g]], e1 = f.rp[f.split[g + 1]];
+__device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_xe, bool store_x) {
     const double* base = (MODE == 1 && mu_xe != 0.0) ? f.xe : f.wv;
-    for (int eb = e0; eb < e1; eb += 64) {
-        int rc[4]; double w[4];
+    constexpr int U = 8;                                  // edges per register batch; two batches in flight
+    for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) {
+        const int r = f.segrow[sgm];
+        const int k0 = (sgm - f.sp[r]) * RP_SEG;
+        const int len = min(RP_SEG, (f.rp[r + 1] - f.rp[r]) - k0);
+        const size_t e0 = seg_edge_index(sgm, 0);
+        const double hr = (MODE == 1) ? f.hh[r] : 0.0, ur = (MODE == 2) ? f.vec[r] : 0.0;
+        double acc = 0.0;
+        int cc[2][U]; double w[2][U];
+        // per-lane predication throughout: lanes whose segment is shorter issue neither the loads nor the LDS gathers of the
+        // dead slots (gating whole batches with a ballot, or processing all 32 slots branch-free, measured 20-30 % slower)
+        auto load = [&](int buf, int kb) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = eb + q * 16 + l;
-            const bool ok = e < e1;
-            rc[q] = ok ? f.col[e] : -1;
-            w[q] = ok ? base[e] : 0.0;
-        }
+            for (int q = 0; q < U; ++q) {
+                const bool ok = kb + q < len;
+                const size_t e = e0 + (size_t)(ok ? kb + q : 0) * 64;      // clamped: stays inside this segment's slots
+                cc[buf][q] = *(RP_GLOBAL const int*)(f.col + e);
+                w[buf][q] = *(RP_GLOBAL const double*)(base + e);
+            }
+        };
+        auto consume = [&](int buf, int kb) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = rc[q] >= 0;
-            const int r = ok ? (rc[q] >> 16) : 0, cc = ok ? (rc[q] & 0xffff) : 0;
-            const int key = ok ? r + 1 : 0;
-            double val;
-            if (MODE == 0) val = w[q];
-            else if (MODE == 1) {
-                const double b = (mu_xe != 0.0) ? mu_xe * w[q] : w[q];
-                val = (b * (f.hh[r] + f.hh[cc])) * f.vec[cc];
-            } else {
-                double x = f.vec[r] * f.vec[cc];
-                x = (x < 0.0 ? 0.0 : x) * w[q];
-                if (store_x && ok) f.xe[eb + q * 16 + l] = x;
-                val = x;
+            for (int q = 0; q < U; ++q) {
+                if (kb + q < len) {
+                    double val;
+                    if (MODE == 0) val = w[buf][q];
+                    else if (MODE == 1) {
+                        const double bb = (mu_xe != 0.0) ? mu_xe * w[buf][q] : w[buf][q];
+                        val = (bb * (hr + f.hh[cc[buf][q]])) * f.vec[cc[buf][q]];
+                    } else {
+                        double x = ur * f.vec[cc[buf][q]];
+                        x = (x < 0.0 ? 0.0 : x) * w[buf][q];
+                        if (store_x) *(RP_GLOBAL double*)(f.xe + e0 + (size_t)(kb + q) * 64) = x;
+                        val = x;
+                    }
+                    acc += val;
+                }
             }
-            if (!ok) val = 0.0;
-#define RP_SEG_STEP(n)                                                    \
-            {                                                             \
-                const int ok_ = rp_dpp<RP_ROW_SHR(n)>(key);               \
-                const double ov_ = rp_dpp_d<RP_ROW_SHR(n)>(val);          \
-                if (ok_ == key) val += ov_;                               \
-            }
-            RP_SEG_STEP(1) RP_SEG_STEP(2) RP_SEG_STEP(4) RP_SEG_STEP(8)
-#undef RP_SEG_STEP
-            const int nxt = rp_dpp<RP_ROW_SHL(1)>(key);
-            if (key != 0 && nxt != key) out[r] += val;
-        }
+        };
+        static_assert(RP_SEG == 4 * U, "seg_pass is unrolled for 4 batches");
+        load(0, 0);
+        if (len > U) load(1, U);
+        consume(0, 0);
+        if (len > 2 * U) load(0, 2 * U);
+        if (len > U) consume(1, U);
+        if (len > 3 * U) load(1, 3 * U);
+        if (len > 2 * U) consume(0, 2 * U);
+        if (len > 3 * U) consume(1, 3 * U);
+        *(RP_GLOBAL double*)(f.part + sgm) = acc;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < f.C; r += blockDim.x) {
+        double acc = 0.0;
+        for (int sgm = f.sp[r]; sgm < f.sp[r + 1]; ++sgm) acc += *(RP_GLOBAL const double*)(f.part + sgm);
+        out[r] = acc;
     }
     __syncthreads();
 }
 
+// fast a / b for the Sturm counts (sign and rough size matter, not the last bits)
+__device__ __forceinline__ double rp_fast_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return a * r;
+}
+
 // Largest eigenpair of the symmetric tridiagonal T (alpha[0..m), beta[0..m-1)) on ONE wave: eigenvalue by 64-way
-// multisection on Sturm counts, eigenvector by two steps of inverse iteration with theta shifted just above the
-// spectrum (theta I - T is then positive definite: LDL^T without pivoting).  s is normalised.  Returns theta.
+// multisection on Sturm counts, eigenvector by inverse iteration with theta shifted just above the spectrum
+// (theta I - T is then positive definite: LDL^T without pivoting).  s is normalised.  Returns theta.
 __device__ double tridiag_top(const double* alpha, const double* beta, int m, double* s, double* dscr) {
     const int lane = threadIdx.x & 63;
     double lo = -INFINITY, hi = -INFINITY, scale = 0.0;
@@ -891,14 +961,14 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
     if (!(scale > 0.0)) { for (int k = lane; k < m; k += 64) s[k] = (k == 0) ? 1.0 : 0.0; return 0.0; }
     const double tiny = scale * 1e-300 + 1e-300;
     lo -= scale * 1e-15; hi += scale * 1e-15;
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < RP_TRI_ROUNDS; ++round) {
         const double x = lo + (hi - lo) * ((double)(lane + 1) / 64.0);          // lane 63 tests hi itself
         int cnt = 0;
         double q = alpha[0] - x;
         if (q == 0.0) q = -tiny;
         cnt += q < 0.0;
         for (int k = 1; k < m; ++k) {
-            q = (alpha[k] - x) - (beta[k - 1] * beta[k - 1]) / q;
+            q = (alpha[k] - x) - rp_fast_div(beta[k - 1] * beta[k - 1], q);
             if (q == 0.0) q = -tiny;
             cnt += q < 0.0;
         }
@@ -908,22 +978,24 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
         const double nhi = lo + (hi - lo) * ((double)(first + 1) / 64.0);
         lo = nlo; hi = nhi;
     }
-    const double theta = hi;                                                    // >= lambda_max, within ~1e-16 relative
+    const double theta = hi;                                                    // >= lambda_max, within ~1e-15 relative
     if (lane == 0) {
         const double sh = theta + scale * 4e-16;
-        double* d = dscr;                       // pivots of theta I - T
-        d[0] = sh - alpha[0];
-        if (!(d[0] > tiny)) d[0] = tiny;
+        double* id = dscr;                      // reciprocal pivots of theta I - T
+        double d = sh - alpha[0];
+        if (!(d > tiny)) d = tiny;
+        id[0] = 1.0 / d;
         for (int k = 1; k < m; ++k) {
-            d[k] = (sh - alpha[k]) - (beta[k - 1] * beta[k - 1]) / d[k - 1];
-            if (!(d[k] > scale * 1e-18)) d[k] = scale * 1e-18;
+            d = (sh - alpha[k]) - (beta[k - 1] * beta[k - 1]) * id[k - 1];
+            if (!(d > scale * 1e-18)) d = scale * 1e-18;
+            id[k] = 1.0 / d;
         }
         for (int k = 0; k < m; ++k) s[k] = 1.0;
         for (int it = 0; it < 3; ++it) {
             // (theta I - T) = L D L^T with L unit lower bidiagonal, l_k = -beta_k / d_k
-            for (int k = 1; k < m; ++k) s[k] = s[k] + (beta[k - 1] / d[k - 1]) * s[k - 1];      // L z = b
-            for (int k = 0; k < m; ++k) s[k] = s[k] / d[k];                                     // D
-            for (int k = m - 2; k >= 0; --k) s[k] = s[k] + (beta[k] / d[k]) * s[k + 1];         // L^T
+            for (int k = 1; k < m; ++k) s[k] = s[k] + (beta[k - 1] * id[k - 1]) * s[k - 1];     // L z = b
+            for (int k = 0; k < m; ++k) s[k] = s[k] * id[k];                                    // D
+            for (int k = m - 2; k >= 0; --k) s[k] = s[k] + (beta[k] * id[k]) * s[k + 1];        // L^T
             double nn = 0.0;
             for (int k = 0; k < m; ++k) nn += s[k] * s[k];
             nn = 1.0 / sqrt(nn);
@@ -933,68 +1005,80 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
     return theta;
 }
 
-// Leading eigenvector of the pair's matrix (see edge_pass MODE 1) into f.vec; returns the number of products.
-// *converged = 0 when the residual estimate stays above tolerance after RP_LZ_CYCLES cycles.
+// Leading eigenvector of the pair's matrix (seg_pass MODE 1) into f.vec, starting from the unit vector already in f.vec;
+// returns the number of products.  *converged = 0 when the residual estimate stays above tolerance.
 __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
     const int C = f.C, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    const double u0 = 1.0 / sqrt((double)C);
-    for (int c = tid; c < C; c += blockDim.x) f.vec[c] = u0;
-    __syncthreads();
     int nprod = 0;
     *converged = 1;
-    for (int cycle = 0; cycle < RP_LZ_CYCLES; ++cycle) {
+    while (true) {
         for (int c = tid; c < C; c += blockDim.x) f.V[c] = f.vec[c];
+        __syncthreads();
         int m = 0;
-        double beta_last = 0.0;
-        for (int j = 0; j < RP_LZ_M; ++j) {
-            edge_pass<1>(f, f.yy, mu_xe, false);                                   // yy = A v_j   (barriers inside)
+        double beta_last = 0.0, theta = 0.0;
+        bool done = false;
+        for (int j = 0; j < RP_LZ_M && !done; ++j) {
+            long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
+            seg_pass<1>(f, f.yy, mu_xe, false);                                    // yy = A v_j   (barriers inside)
             ++nprod;
-            // two classical Gram-Schmidt passes against v_0..v_j; the first one's coefficient of v_j is alpha_j
-            double alpha = 0.0;
+            long long t1_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
+            // classical Gram-Schmidt against v_0..v_j (its coefficient of v_j is alpha_j); a second pass only when the
+            // first one removed more than half of the vector (Daniel-Gragg-Kaufman-Stewart criterion)
+            double alpha = 0.0, nrm_before = 0.0, nrm_after = 0.0;
             for (int pass = 0; pass < 2; ++pass) {
                 for (int i = wave; i <= j; i += nw) {
                     const double* vi = f.V + (size_t)i * f.Cmax;
                     double d = 0.0;
-                    for (int c = lane; c < C; c += 64) d += vi[c] * f.yy[c];
+                    for (int c = lane; c < C; c += 64) d += rp_ldg(vi + c) * f.yy[c];
                     d = rp_wave_sum(d);
                     if (lane == 0) f.cbuf[i] = d;
                 }
+                double nn[2] = {0.0, 0.0};
+                if (pass == 0) for (int c = tid; c < C; c += blockDim.x) nn[0] += f.yy[c] * f.yy[c];
                 __syncthreads();
                 alpha += f.cbuf[j];
                 for (int c = tid; c < C; c += blockDim.x) {
                     double acc = f.yy[c];
-                    for (int i = 0; i <= j; ++i) acc -= f.cbuf[i] * f.V[(size_t)i * f.Cmax + c];
+                    for (int i = 0; i <= j; ++i) acc -= f.cbuf[i] * rp_ldg(f.V + (size_t)i * f.Cmax + c);
                     f.yy[c] = acc;
+                    nn[1] += acc * acc;
                 }
-                __syncthreads();
+                rp_block_sum<2>(nn, f.red);                                        // (barriers inside)
+                if (pass == 0) nrm_before = nn[0];
+                nrm_after = nn[1];
+                if (pass == 0 && nrm_after > 0.25 * nrm_before) break;            // |w'| > |w| / 2: orthogonal enough
             }
-            double nn[1] = {0.0};
-            for (int c = tid; c < C; c += blockDim.x) nn[0] += f.yy[c] * f.yy[c];
-            rp_block_sum<1>(nn, f.red);
-            const double beta = sqrt(nn[0]);
+            const double beta = sqrt(nrm_after);
             if (tid == 0) { f.tri[j] = alpha; f.tri[(RP_LZ_M + 1) + j] = beta; }
+            if (f.prof && tid == 0 && blockIdx.x == 0) { f.prof[0] += t1_ - t0_; f.prof[1] += (long long)__builtin_readcyclecounter() - t1_; f.prof[6] += 1; }
             m = j + 1;
             beta_last = beta;
             const double anorm = fabs(alpha) + beta;
-            if (!(beta > 1e-14 * anorm)) { beta_last = 0.0; break; }               // invariant subspace (or the zero matrix): exact
-            if (j + 1 < RP_LZ_M) {
+            const bool invariant = !(beta > 1e-14 * anorm);                        // invariant subspace (or the zero matrix): exact
+            if (!invariant && j + 1 < RP_LZ_M) {
                 const double inv = 1.0 / beta;
                 double* vn = f.V + (size_t)(j + 1) * f.Cmax;
-                for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; vn[c] = v; f.vec[c] = v; }
+                for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; rp_stg(vn + c, v); f.vec[c] = v; }
             }
             __syncthreads();
+            if (invariant || m == RP_LZ_M || (m % RP_LZ_CHECK) == 0) {
+                // Ritz pair of the m x m tridiagonal matrix, residual estimate beta_m |s_m|
+                long long t2_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
+                if (wave == 0) {
+                    const double th = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri + 3 * (RP_LZ_M + 1));
+                    if (lane == 0) f.red[159] = th;
+                }
+                __syncthreads();
+                theta = f.red[159];
+                if (f.prof && tid == 0 && blockIdx.x == 0) f.prof[2] += (long long)__builtin_readcyclecounter() - t2_;
+                const double resid = invariant ? 0.0 : beta_last * fabs(f.tri[2 * (RP_LZ_M + 1) + m - 1]);
+                if (invariant || m == RP_LZ_M || resid <= RP_LZ_TOL * fabs(theta)) {
+                    done = true;
+                    if (resid <= RP_LZ_TOL * fabs(theta)) beta_last = 0.0;         // flag: converged
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        // Ritz pair of the m x m tridiagonal matrix
-        double theta = 0.0;
-        if (wave == 0) {
-            theta = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri + 3 * (RP_LZ_M + 1));
-            if (lane == 0) f.red[159] = theta;
-        }
-        __syncthreads();
-        theta = f.red[159];
-        const double* sv = f.tri + 2 * (RP_LZ_M + 1);
-        const double resid = beta_last * fabs(sv[m - 1]);
         if (!(theta > 0.0) && m == 1) {
             // A v0 = 0 (zero matrix / no active edges): keep the start vector, like the round-1 solver
             for (int c = tid; c < C; c += blockDim.x) f.vec[c] = f.V[c];
@@ -1002,10 +1086,11 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
             return nprod;
         }
         // u = sum_i s_i v_i, normalised
+        const double* sv = f.tri + 2 * (RP_LZ_M + 1);
         double nn[1] = {0.0};
         for (int c = tid; c < C; c += blockDim.x) {
             double acc = 0.0;
-            for (int i = 0; i < m; ++i) acc += sv[i] * f.V[(size_t)i * f.Cmax + c];
+            for (int i = 0; i < m; ++i) acc += sv[i] * rp_ldg(f.V + (size_t)i * f.Cmax + c);
             f.yy[c] = acc;
             nn[0] += acc * acc;
         }
@@ -1013,19 +1098,146 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
         const double inv = 1.0 / sqrt(nn[0]);
         for (int c = tid; c < C; c += blockDim.x) f.vec[c] = f.yy[c] * inv;
         __syncthreads();
-        if (resid <= RP_LZ_TOL * fabs(theta)) return nprod;
+        if (beta_last == 0.0) return nprod;                                        // converged (or exact)
+        if (nprod + RP_LZ_CHECK > RP_LZ_MAXPROD) break;
     }
     *converged = 0;
     return nprod;
+}
+
+// Horn's quaternion for the single-workgroup fit, operands and result in LDS, out of line so that its temporaries do not
+// set the register budget of the whole kernel: Newton on the characteristic quartic + adjugate eigenvector (rp_math.h),
+// the Jacobi solver only when the leading eigenvalue is not separated.
+__device__ __attribute__((noinline)) void horn_lds(const double* m9, double* r9) {
+    double M[3][3], Rl[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) M[a][bb] = m9[a * 3 + bb];
+    rp_horn_rotation_fast(M, Rl);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) r9[a * 3 + bb] = Rl[a][bb];
+}
+
+// fit_solve for the single-workgroup kernel: same arithmetic and summation order as fit_solve, Horn through horn_lds
+__device__ void fit_solve1(const FitCtx& f, bool reweight, double* Rt /* LDS [12]: R row-major, t */) {
+    // the first correspondence of every thread lives in registers across the three passes (12 doubles each); beyond that
+    // (C > blockDim) the passes re-read them like fit_solve does
+    constexpr int EPT = 1;
+    const int nloc = min(EPT, (f.C - (int)threadIdx.x + (int)blockDim.x - 1) / (int)blockDim.x);
+    double gsp[EPT][3], gtp[EPT][3], gsn[EPT][3], gtn[EPT][3], gdeg[EPT], ggP[EPT], ggN[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int c = threadIdx.x + k * blockDim.x;
+        if (k < nloc) { corr_geom(f, c, gsp[k], gtp[k], gsn[k], gtn[k]); gdeg[k] = f.deg[c]; ggP[k] = f.gP[c]; ggN[k] = f.gN[c]; }
+    }
+    const int cont = threadIdx.x + EPT * blockDim.x;          // first correspondence of this thread that is not cached
+    double s7[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        if (k < nloc) {
+            const double wp = f.mu * gdeg[k] * ggP[k];
+            s7[0] += wp;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { s7[1 + a] += wp * gsp[k][a]; s7[4 + a] += wp * gtp[k][a]; }
+        }
+    }
+    for (int c = cont; c < f.C; c += blockDim.x) {
+        double sp[3], tp[3], sn[3], tn[3];
+        corr_geom(f, c, sp, tp, sn, tn);
+        const double wp = f.mu * f.deg[c] * f.gP[c];
+        s7[0] += wp;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s7[1 + a] += wp * sp[a]; s7[4 + a] += wp * tp[a]; }
+    }
+    rp_block_sum<7>(s7, f.red);
+    const double den = s7[0] + RP_EPS;
+    double ms[3], mt[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ms[a] = s7[1 + a] / den; mt[a] = s7[4 + a] / den; }
+    double m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        if (k < nloc) {
+            const double wp = f.mu * gdeg[k] * ggP[k], wn = gdeg[k] * ggN[k];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb)
+                    m9[a * 3 + bb] += (gsp[k][a] - ms[a]) * ((gtp[k][bb] - mt[bb]) * wp) + gsn[k][a] * (gtn[k][bb] * wn);
+        }
+    }
+    for (int c = cont; c < f.C; c += blockDim.x) {
+        double sp[3], tp[3], sn[3], tn[3];
+        corr_geom(f, c, sp, tp, sn, tn);
+        const double d = f.deg[c];
+        const double wp = f.mu * d * f.gP[c], wn = d * f.gN[c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb)
+                m9[a * 3 + bb] += (sp[a] - ms[a]) * ((tp[bb] - mt[bb]) * wp) + sn[a] * (tn[bb] * wn);
+    }
+    rp_block_sum<9>(m9, f.red);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) f.red[128 + q] = m9[q];
+        horn_lds(f.red + 128, Rt);
+    }
+    __syncthreads();
+    double R[3][3], t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { R[a][0] = Rt[a * 3 + 0]; R[a][1] = Rt[a * 3 + 1]; R[a][2] = Rt[a * 3 + 2]; }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t[a] = -((R[a][0] * ms[0] + R[a][1] * ms[1]) + R[a][2] * ms[2]) + mt[a];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) Rt[9 + a] = t[a];
+    }
+    auto residual = [&](int c, const double* sp, const double* tp, const double* sn, const double* tn, double gP, double gN) {
+        double rP = 0.0, rN = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double x0 = sp[0] - ms[0], x1 = sp[1] - ms[1], x2 = sp[2] - ms[2];
+            const double ep = ((R[a][0] * x0 + R[a][1] * x1) + R[a][2] * x2) - (tp[a] - mt[a]);
+            const double en = ((R[a][0] * sn[0] + R[a][1] * sn[1]) + R[a][2] * sn[2]) - tn[a];
+            rP += ep * ep; rN += en * en;
+        }
+        rP *= f.mu;
+        f.rsum[c] = rP + rN;
+        if (reweight) { f.gP[c] = gP / (1.0 + rP); f.gN[c] = gN / (1.0 + rN); }
+    };
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+        if (k < nloc) residual(threadIdx.x + k * blockDim.x, gsp[k], gtp[k], gsn[k], gtn[k], ggP[k], ggN[k]);
+    for (int c = cont; c < f.C; c += blockDim.x) {
+        double sp[3], tp[3], sn[3], tn[3];
+        corr_geom(f, c, sp, tp, sn, tn);
+        residual(c, sp, tp, sn, tn, f.gP[c], f.gN[c]);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void write_pose_lds(double* out, const double* Rt) {
+    if (threadIdx.x < 16) {
+        const int a = threadIdx.x >> 2, q = threadIdx.x & 3;
+        out[threadIdx.x] = a == 3 ? (q == 3 ? 1.0 : 0.0) : (q == 3 ? Rt[9 + a] : Rt[a * 3 + q]);
+    }
 }
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK, int method,
                                                                     double* __restrict__ lz_basis, int32_t* __restrict__ status,
                                                                     double* __restrict__ pose, double* __restrict__ trace,
-                                                                    int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out) {
+                                                                    int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out,
+                                                                    long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[160];
+    __shared__ double Rt[12];
     __shared__ int st_s;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int C = pair_C(kp, g, b);
@@ -1049,26 +1261,22 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
         return;
     }
     Fit1 f;
+    f.prof = prof;
+    const long long tstart_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     f.C = C; f.Cmax = g.Cmax;
     f.vec = (double*)smem; f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
     f.tri = f.yy + g.Cmax; f.cbuf = f.tri + 4 * (RP_LZ_M + 1);
-    f.rp = (int32_t*)(f.cbuf + (RP_LZ_M + 1)); f.split = f.rp + (g.Cmax + 1);
+    f.rp = (int32_t*)(f.cbuf + (RP_LZ_M + 1)); f.sp = f.rp + (g.Cmax + 1);
     f.red = red;
-    const size_t eoff = (size_t)b * g.max_edges;
+    const size_t eoff = (size_t)b * g.estride;
     f.col = g.col + eoff; f.wv = g.wv + eoff; f.xe = g.xe + eoff;
+    f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
     f.V = lz_basis + (size_t)b * (RP_LZ_M + 1) * g.Cmax;
     const int32_t* rpg = g.rowptr + (size_t)b * (g.Cmax + 1);
-    for (int c = tid; c <= C; c += blockDim.x) f.rp[c] = rpg[c];
+    const int32_t* spg = g.segptr + (size_t)b * (g.Cmax + 1);
+    for (int c = tid; c <= C; c += blockDim.x) { f.rp[c] = rpg[c]; f.sp[c] = spg[c]; }
     __syncthreads();
-    const int ngroups = THREADS / 16;
-    if (tid <= ngroups) {                                 // row ranges with ~E/ngroups edges each (first row whose start >= g E / ngroups)
-        const long long E = f.rp[C];
-        const int target = (int)((E * tid) / ngroups);
-        int lo = 0, hi = C;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (f.rp[mid] < target) lo = mid + 1; else hi = mid; }
-        f.split[tid] = (tid == ngroups) ? C : lo;
-    }
-    __syncthreads();
+    f.nseg = f.sp[C];
     FitCtx fc;
     fc.b = b; fc.C = C; fc.mu = kc.mu;
     fc.deg = g.state + ((size_t)b * 4 + 0) * g.Cmax; fc.gP = g.state + ((size_t)b * 4 + 1) * g.Cmax;
@@ -1087,34 +1295,41 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             const int a = gl % 3, what = gl / 3;
             geo[idx] = what == 0 ? kp.pc_s[si * 3 + a] : what == 1 ? kp.pc_t[ti * 3 + a] : what == 2 ? kp.normal_s[si * 3 + a] : kp.normal_t[ti * 3 + a];
         }
-        edge_pass<0>(f, f.yy, 0.0, false);
+        seg_pass<0>(f, f.yy, 0.0, false);
         for (int c = tid; c < C; c += blockDim.x) { fc.deg[c] = f.yy[c]; fc.gP[c] = 1.0; fc.gN[c] = 1.0; fc.rsum[c] = 0.0; }
         __syncthreads();
     }
     const bool irls0 = (method == RELPOSE_FIT_IRLS_SM || method == RELPOSE_FIT_IRLS);
-    double R[3][3], t[3];
-    for (int it = 0; it < (irls0 ? 5 : 1); ++it) fit_solve(fc, irls0, R, t);
-    write_pose(pose + (size_t)b * 16, R, t);
-    if (trace) write_pose(trace + (size_t)b * 96, R, t);
+    long long ti_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
+    for (int it = 0; it < (irls0 ? 5 : 1); ++it) fit_solve1(fc, irls0, Rt);
+    if (f.prof && tid == 0 && b == 0) { f.prof[4] += (long long)__builtin_readcyclecounter() - ti_; f.prof[7] = ti_ - tstart_; }
+    write_pose_lds(pose + (size_t)b * 16, Rt);
+    if (trace) write_pose_lds(trace + (size_t)b * 96, Rt);
     int all_converged = 1;
     if (method == RELPOSE_FIT_IRLS_SM || method == RELPOSE_FIT_SPECTRAL) {
         const bool sm = (method == RELPOSE_FIT_IRLS_SM);
+        const double u0 = 1.0 / sqrt((double)C);
+        for (int c = tid; c < C; c += blockDim.x) f.vec[c] = u0;          // round 0 starts from the uniform vector
         for (int round = 0; round < 5; ++round) {
             for (int c = tid; c < C; c += blockDim.x) { const double v = RP_OFFSET - fc.rsum[c]; f.hh[c] = v < 0.0 ? 0.0 : v; }
             __syncthreads();
             int conv = 1;
-            const int np = lanczos_top(f, (!sm && round > 0) ? kc.mu : 0.0, &conv);
+            const int np = lanczos_top(f, (!sm && round > 0) ? kc.mu : 0.0, &conv);       // rounds > 0: warm start from f.vec
             all_converged &= conv;
             if (eig_iters_out && tid == 0) eig_iters_out[b * 5 + round] = np;
-            edge_pass<2>(f, f.yy, 0.0, !sm);                                   // x per edge, new weighted degrees
+            long long tf_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
+            seg_pass<2>(f, f.yy, 0.0, !sm);                                    // x per edge, new weighted degrees
+            if (f.prof && tid == 0 && b == 0) f.prof[5] += (long long)__builtin_readcyclecounter() - tf_;
             for (int c = tid; c < C; c += blockDim.x) { fc.deg[c] = f.yy[c]; fc.gP[c] = 1.0; fc.gN[c] = 1.0; }
             __syncthreads();
-            for (int it = 0; it < (sm ? 5 : 1); ++it) fit_solve(fc, sm, R, t);
-            write_pose(pose + (size_t)b * 16, R, t);
-            if (trace) write_pose(trace + (size_t)b * 96 + (round + 1) * 16, R, t);
+            long long tj_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
+            for (int it = 0; it < (sm ? 5 : 1); ++it) fit_solve1(fc, sm, Rt);
+            if (f.prof && tid == 0 && b == 0) f.prof[4] += (long long)__builtin_readcyclecounter() - tj_;
+            write_pose_lds(pose + (size_t)b * 16, Rt);
+            if (trace) write_pose_lds(trace + (size_t)b * 96 + (round + 1) * 16, Rt);
         }
     } else if (trace) {
-        for (int q = 1; q < 6; ++q) write_pose(trace + (size_t)b * 96 + q * 16, R, t);
+        for (int q = 1; q < 6; ++q) write_pose_lds(trace + (size_t)b * 96 + q * 16, Rt);
     }
     if (tid == 0) status[b] = all_converged ? RELPOSE_OK : RELPOSE_NOT_CONVERGED;
 }
@@ -1166,7 +1381,7 @@ int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* w
             if (!(ac.den[q] > 1e-290 && ac.den[q] < 1e290) || (bits & 0xfffffffffffffull) == 0xfffffffffffffull) ac.exact_div = 0;
         }
         const int tp = (kp.nt_max + 127) / 128;
-        switch (tp) {
+        if (ac.exact_div) switch (tp) {
             case 1: return launch_affinity_rows<1>(kp, ac, p.topK, wij, cj, cw, keff, s);
             case 2: return launch_affinity_rows<2>(kp, ac, p.topK, wij, cj, cw, keff, s);
             case 3: return launch_affinity_rows<3>(kp, ac, p.topK, wij, cj, cw, keff, s);
@@ -1192,12 +1407,12 @@ int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* w
 
 // the single-workgroup fit keeps 3 vectors + the row pointers of a pair in LDS and packs (row, column) into 32 bits
 static bool fit1_ok(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && !getenv("RELPOSE_LEGACY_FIT"); }
-static size_t fit1_lds(int32_t Cmax) { return (size_t)Cmax * 24 + (size_t)(5 * (RP_LZ_M + 1)) * 8 + (size_t)(Cmax + 1) * 4 + 65 * 4 + 16; }
+static size_t fit1_lds(int32_t Cmax) { return (size_t)Cmax * 24 + (size_t)(5 * (RP_LZ_M + 1)) * 8 + (size_t)(Cmax + 1) * 8 + 16; }
 
 struct WsLayout {
-    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, eig, pairC, lz, total;
-    int32_t Cmax, Wmax;
-    int64_t max_edges;
+    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, eig, pairC, lz, segptr, segrow, part, total;
+    int32_t Cmax, Wmax, seg_cap;
+    int64_t max_edges, estride;
 };
 
 WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
@@ -1217,9 +1432,16 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.lowcnt = take((size_t)B * L.Cmax * 4);      // lowcnt and counters are contiguous: one memset
     L.counters = take((size_t)B * 4 * 4);
     L.rowptr = take((size_t)B * (L.Cmax + 1) * 4);
-    L.col = take((size_t)B * L.max_edges * 4);
-    L.wv = take((size_t)B * L.max_edges * 8);
-    L.xe = take((size_t)B * L.max_edges * 8);
+    const bool seg = fit1_ok(L.Cmax);
+    // segment layout: every row wastes less than one 32-entry segment; slices of 64 segments
+    L.seg_cap = seg ? (int32_t)(((L.max_edges + RP_SEG - 1) / RP_SEG + L.Cmax + 63) / 64 * 64) : 0;
+    L.estride = seg ? (int64_t)L.seg_cap * RP_SEG : L.max_edges;
+    L.col = take((size_t)B * L.estride * 4);
+    L.wv = take((size_t)B * L.estride * 8);
+    L.xe = take((size_t)B * L.estride * 8);
+    L.segptr = take(seg ? (size_t)B * (L.Cmax + 1) * 4 : 0);
+    L.segrow = take(seg ? (size_t)B * L.seg_cap * 4 : 0);
+    L.part = take(seg ? (size_t)B * L.seg_cap * 8 : 0);
     L.state = take((size_t)B * 4 * L.Cmax * 8);
     L.geo = take((size_t)B * L.Cmax * 12 * 8);
     L.pairC = take((size_t)B * 4);
@@ -1271,7 +1493,9 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     g.upcnt = (int32_t*)(ws + L.upcnt); g.lowcnt = (int32_t*)(ws + L.lowcnt); g.counters = (int32_t*)(ws + L.counters);
     g.rowptr = (int32_t*)(ws + L.rowptr); g.col = (int32_t*)(ws + L.col);
     g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state); g.geo = (double*)(ws + L.geo); g.pairC = (int32_t*)(ws + L.pairC);
-    g.pack_rows = fit1_ok(L.Cmax) ? 1 : 0;
+    g.seg_layout = fit1_ok(L.Cmax) ? 1 : 0;
+    g.seg_cap = L.seg_cap; g.estride = L.estride;
+    g.segptr = (int32_t*)(ws + L.segptr); g.segrow = (int32_t*)(ws + L.segrow); g.part = (double*)(ws + L.part);
     RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
     int rc = launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
     if (rc) return rc;
@@ -1293,20 +1517,31 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     double* trace = dbg ? dbg->trace : nullptr;
     int32_t* eig_iters = dbg ? dbg->eig_iters : nullptr;
     const int m = p->method;
-    if (g.pack_rows) {
+    if (g.seg_layout) {
         // ---- fit: ONE launch, one 1024-thread workgroup per pair (fit_pair_kernel)
         const size_t lds = fit1_lds(L.Cmax);
+        static long long* prof = nullptr;
+        if (getenv("RELPOSE_FIT_PROF")) {
+            if (!prof) RP_HIP(hipMalloc((void**)&prof, 64));
+            RP_HIP(hipMemsetAsync(prof, 0, 64, s));
+        }
         static const int fit_threads = getenv("RELPOSE_FIT_THREADS") ? atoi(getenv("RELPOSE_FIT_THREADS")) : RP_FIT1_THREADS;     // experiment switch
         if (fit_threads == 512) {
             RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(fit_pair_kernel<512>, dim3(kp->B), dim3(512), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
-                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters);
+                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof);
         } else {
             RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(fit_pair_kernel<1024>, dim3(kp->B), dim3(1024), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
-                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters);
+                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof);
         }
         RP_CHECK_LAUNCH();
+        if (prof) {       // debug only: synchronises
+            long long h[8];
+            RP_HIP(hipStreamSynchronize(s));
+            RP_HIP(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[fit prof, pair 0, cycles] products %lld (%lld calls) reorth+norm %lld tridiag %lld irls %lld finish %lld setup %lld\n", h[0], h[6], h[1], h[2], h[4], h[5], h[7]);
+        }
     } else {
     // ---- legacy fit for > RP_FIT1_MAXC correspondences per pair: launch sequence over the whole GPU (see fit_begin_kernel)
     dim3 grid16((L.Cmax + 15) / 16, kp->B);

@@ -104,7 +104,7 @@ RP_HD void rp_sym4_max_eigvec(double N[4][4], double q[4]) {
         const double off = ((N[0][1] * N[0][1] + N[0][2] * N[0][2]) + (N[0][3] * N[0][3] + N[1][2] * N[1][2])) +
                            (N[1][3] * N[1][3] + N[2][3] * N[2][3]);
         const double diag = (N[0][0] * N[0][0] + N[1][1] * N[1][1]) + (N[2][2] * N[2][2] + N[3][3] * N[3][3]);
-        if (off <= 1e-60 || off <= 1e-34 * diag) break;
+        if (off == 0.0 || off <= 1e-34 * diag) break;
         RP_JROT(0, 1) RP_JROT(0, 2) RP_JROT(0, 3) RP_JROT(1, 2) RP_JROT(1, 3) RP_JROT(2, 3)
     }
     double best = N[0][0];
@@ -116,6 +116,73 @@ RP_HD void rp_sym4_max_eigvec(double N[4][4], double q[4]) {
     q[0] = v0 / nrm; q[1] = v1 / nrm; q[2] = v2 / nrm; q[3] = v3 / nrm;
 }
 
+// The same leading eigenvector WITHOUT the Jacobi sweeps (a serial chain of ~50 rotations with a sqrt and three divisions
+// each: ~25 us on one GPU lane, and the IRLS loop calls it 30 times per pair and level): the largest root of the
+// characteristic polynomial by Newton's method from an upper bound (monotone: the quartic is convex and increasing to
+// the right of its largest root -- Horn's own closed-form route, JOSA A 4(4) 1987 section 4.E), then the eigenvector as
+// the best-conditioned column of adj(N - lambda I).  Falls back to the Jacobi solver when the leading eigenvalue is not
+// well separated (|p'(lambda)| small: the adjugate then loses digits).  N is preserved.  Returns 1 if the fast path was taken.
+RP_HD double rp_det3(double a, double b, double c, double d, double e, double f, double g, double h, double i) {
+    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+}
+RP_HD int rp_sym4_max_eigvec_fast(const double N[4][4], double q[4]) {
+    const double n00 = N[0][0], n01 = N[0][1], n02 = N[0][2], n03 = N[0][3], n11 = N[1][1], n12 = N[1][2], n13 = N[1][3],
+                 n22 = N[2][2], n23 = N[2][3], n33 = N[3][3];
+    const double fro2 = ((n00 * n00 + n11 * n11) + (n22 * n22 + n33 * n33)) + 2.0 * (((n01 * n01 + n02 * n02) + (n03 * n03 + n12 * n12)) + (n13 * n13 + n23 * n23));
+    const double scale = sqrt(fro2);
+    if (!(scale > 0.0) || !(scale < 1e150)) return 0;
+    // characteristic polynomial  p(x) = x^4 + a3 x^3 + a2 x^2 + a1 x + a0  of N / scale
+    const double is = 1.0 / scale;
+    const double m00 = n00 * is, m01 = n01 * is, m02 = n02 * is, m03 = n03 * is, m11 = n11 * is, m12 = n12 * is, m13 = n13 * is,
+                 m22 = n22 * is, m23 = n23 * is, m33 = n33 * is;
+    const double tr = (m00 + m11) + (m22 + m33);
+    const double a3 = -tr;
+    const double a2 = 0.5 * (tr * tr - 1.0);                                   // tr(M^2) = 1 after scaling
+    const double p012 = rp_det3(m00, m01, m02, m01, m11, m12, m02, m12, m22), p013 = rp_det3(m00, m01, m03, m01, m11, m13, m03, m13, m33);
+    const double p023 = rp_det3(m00, m02, m03, m02, m22, m23, m03, m23, m33), p123 = rp_det3(m11, m12, m13, m12, m22, m23, m13, m23, m33);
+    const double a1 = -((p012 + p013) + (p023 + p123));
+    const double a0 = m00 * p123 - m01 * rp_det3(m01, m12, m13, m02, m22, m23, m03, m23, m33)
+                    + m02 * rp_det3(m01, m11, m13, m02, m12, m23, m03, m13, m33) - m03 * rp_det3(m01, m11, m12, m02, m12, m22, m03, m13, m23);
+    double x = 1.0 + 1e-12;                                                     // every eigenvalue of M is <= |M|_F = 1
+    double dp = 0.0;
+    for (int it = 0; it < 64; ++it) {
+        const double px = (((x + a3) * x + a2) * x + a1) * x + a0;
+        dp = ((4.0 * x + 3.0 * a3) * x + 2.0 * a2) * x + a1;
+        if (!(dp > 0.0)) return 0;
+        const double step = px / dp;
+        const double xn = x - step;
+        if (!(step > 4e-16 * fabs(x))) { x = (step > 0.0) ? xn : x; break; }
+        x = xn;
+    }
+    if (!(dp > 1e-5)) return 0;                                                 // leading eigenvalue not separated: use Jacobi
+    // adj(M - x I): all ten distinct cofactors, the column with the largest diagonal cofactor
+    const double b00 = m00 - x, b11 = m11 - x, b22 = m22 - x, b33 = m33 - x;
+    const double c00 = rp_det3(b11, m12, m13, m12, b22, m23, m13, m23, b33);
+    const double c11 = rp_det3(b00, m02, m03, m02, b22, m23, m03, m23, b33);
+    const double c22 = rp_det3(b00, m01, m03, m01, b11, m13, m03, m13, b33);
+    const double c33 = rp_det3(b00, m01, m02, m01, b11, m12, m02, m12, b22);
+    const double c01 = -rp_det3(m01, m12, m13, m02, b22, m23, m03, m23, b33);
+    const double c02 = rp_det3(m01, b11, m13, m02, m12, m23, m03, m13, b33);
+    const double c03 = -rp_det3(m01, b11, m12, m02, m12, b22, m03, m13, m23);
+    const double c12 = -rp_det3(b00, m01, m03, m02, m12, m23, m03, m13, b33);
+    const double c13 = rp_det3(b00, m01, m02, m02, m12, b22, m03, m13, m23);
+    const double c23 = -rp_det3(b00, m01, m02, m01, b11, m12, m03, m13, m23);
+    const double d0 = fabs(c00), d1 = fabs(c11), d2 = fabs(c22), d3 = fabs(c33);
+    double v0 = c00, v1 = c01, v2 = c02, v3 = c03, best = d0;
+    if (d1 > best) { best = d1; v0 = c01; v1 = c11; v2 = c12; v3 = c13; }
+    if (d2 > best) { best = d2; v0 = c02; v1 = c12; v2 = c22; v3 = c23; }
+    if (d3 > best) { best = d3; v0 = c03; v1 = c13; v2 = c23; v3 = c33; }
+    if (!(best > 1e-7)) return 0;
+    // one step of inverse-free refinement: v <- normalised (M - x I + I) v would not help; instead polish with one
+    // Rayleigh-quotient correction through the adjugate's own structure: v is already the null vector to O(eps/gap)
+    const double nrm = sqrt((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3));
+    q[0] = v0 / nrm; q[1] = v1 / nrm; q[2] = v2 / nrm; q[3] = v3 / nrm;
+    return 1;
+}
+
+RP_HD void rp_quat_to_rot_impl(const double* q, double R[3][3]);
+RP_HD void rp_quat_to_rot(const double* q, double R[3][3]) { rp_quat_to_rot_impl(q, R); }
+
 // Horn '87: rotation from the 3x3 weighted covariance M = sum_k w_k s_k t_k^T (rpmodule.py:43-56).
 RP_HD void rp_horn_rotation(const double M[3][3], double R[3][3]) {
     double N[4][4] = {
@@ -125,6 +192,22 @@ RP_HD void rp_horn_rotation(const double M[3][3], double R[3][3]) {
         {M[0][1] - M[1][0], M[2][0] + M[0][2], M[1][2] + M[2][1], M[2][2] - M[0][0] - M[1][1]}};
     double q[4];
     rp_sym4_max_eigvec(N, q);
+    rp_quat_to_rot(q, R);
+}
+
+// Horn with the Newton / adjugate eigen-solve (Jacobi only as the fallback for a badly separated leading eigenvalue)
+RP_HD void rp_horn_rotation_fast(const double M[3][3], double R[3][3]) {
+    double N[4][4] = {
+        {M[0][0] + M[1][1] + M[2][2], M[1][2] - M[2][1], M[2][0] - M[0][2], M[0][1] - M[1][0]},
+        {M[1][2] - M[2][1], M[0][0] - M[1][1] - M[2][2], M[0][1] + M[1][0], M[0][2] + M[2][0]},
+        {M[2][0] - M[0][2], M[0][1] + M[1][0], M[1][1] - M[0][0] - M[2][2], M[1][2] + M[2][1]},
+        {M[0][1] - M[1][0], M[2][0] + M[0][2], M[1][2] + M[2][1], M[2][2] - M[0][0] - M[1][1]}};
+    double q[4];
+    if (!rp_sym4_max_eigvec_fast(N, q)) rp_sym4_max_eigvec(N, q);
+    rp_quat_to_rot(q, R);
+}
+
+RP_HD void rp_quat_to_rot_impl(const double* q, double R[3][3]) {
     double a = q[0], b = q[1], c = q[2], d = q[3];
     R[0][0] = a * a + b * b - c * c - d * d; R[0][1] = 2 * (b * c - a * d); R[0][2] = 2 * (b * d + a * c);
     R[1][0] = 2 * (c * b + a * d); R[1][1] = a * a - b * b + c * c - d * d; R[1][2] = 2 * (c * d - a * b);

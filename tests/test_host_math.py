@@ -25,6 +25,9 @@ void t_pair(const double* a, const double* b, const double* k9, double* out) {
 void t_horn(const double* M, double* R) { double m[3][3], r[3][3]; for(int i=0;i<9;++i) m[i/3][i%3]=M[i];
     rp_horn_rotation(m, r); for(int i=0;i<9;++i) R[i]=r[i/3][i%3]; }
 int t_inv4(const double* A, double* o) { return rp_inv4(A, o) ? 1 : 0; }
+void t_horn_fast(const double* M, double* R) { double m[3][3], r[3][3]; for(int i=0;i<9;++i) m[i/3][i%3]=M[i];
+    rp_horn_rotation_fast(m, r); for(int i=0;i<9;++i) R[i]=r[i/3][i%3]; }
+int t_eig4_fast(const double* N, double* q) { double n[4][4]; for(int i=0;i<16;++i) n[i/4][i%4]=N[i]; return rp_sym4_max_eigvec_fast(n, q); }
 }
 '''
 
@@ -90,3 +93,53 @@ def test_inv4(shim):
         o = np.zeros(16)
         assert shim.t_inv4(_dp(A), _dp(o)) == 1
         assert np.allclose(o.reshape(4, 4), np.linalg.inv(A), atol=1e-14)
+
+
+def test_horn_fast_path_matches_jacobi_and_oracle(shim):
+    """rp_horn_rotation_fast (Newton on the characteristic quartic + adjugate eigenvector; what the single-workgroup fit
+    uses) against the Jacobi solver and the numpy oracle: random weighted covariances, nearly planar / nearly collinear
+    point sets, pure rotations (rank-deficient N - lambda I), tiny and huge scales, and nearly degenerate leading
+    eigenvalues (where it must fall back to Jacobi)."""
+    rs = np.random.RandomState(7)
+    worst, n_fast = 0.0, 0
+    cases = []
+    for _ in range(200):
+        n = rs.randint(3, 40)
+        src, tgt, w = rs.randn(3, n), rs.randn(3, n), rs.rand(n)
+        cases.append(src @ (tgt * w[None]).T)
+    for _ in range(100):                                   # a true rigid motion + noise (what IRLS sees near convergence)
+        n = rs.randint(4, 60)
+        src = rs.randn(3, n) * rs.uniform(0.1, 3)
+        T = synth.random_rigid(rs)
+        tgt = T[:3, :3] @ src + rs.randn(3, n) * 10 ** rs.uniform(-9, -1)
+        cases.append(src @ (tgt * rs.rand(n)[None]).T)
+    for _ in range(50):                                    # planar and collinear clouds
+        n = 20
+        src = rs.randn(3, n)
+        src[2] *= 10 ** rs.uniform(-12, -2)
+        if rs.rand() < 0.5:
+            src[1] *= 10 ** rs.uniform(-12, -2)
+        T = synth.random_rigid(rs)
+        cases.append(src @ ((T[:3, :3] @ src) * rs.rand(n)[None]).T)
+    for sc in (1e-30, 1e-8, 1e8, 1e30):
+        cases.append(cases[3] * sc)
+    for Mx in cases:
+        Mx = np.ascontiguousarray(Mx)
+        R0, R1 = np.zeros(9), np.zeros(9)
+        shim.t_horn(_dp(Mx), _dp(R0))
+        shim.t_horn_fast(_dp(Mx), _dp(R1))
+        # conditioning of the leading eigenvector: compare through the oracle's eigen-decomposition
+        Nm = np.array([[Mx[0, 0] + Mx[1, 1] + Mx[2, 2], Mx[1, 2] - Mx[2, 1], Mx[2, 0] - Mx[0, 2], Mx[0, 1] - Mx[1, 0]],
+                       [Mx[1, 2] - Mx[2, 1], Mx[0, 0] - Mx[1, 1] - Mx[2, 2], Mx[0, 1] + Mx[1, 0], Mx[0, 2] + Mx[2, 0]],
+                       [Mx[2, 0] - Mx[0, 2], Mx[0, 1] + Mx[1, 0], Mx[1, 1] - Mx[0, 0] - Mx[2, 2], Mx[1, 2] + Mx[2, 1]],
+                       [Mx[0, 1] - Mx[1, 0], Mx[2, 0] + Mx[0, 2], Mx[1, 2] + Mx[2, 1], Mx[2, 2] - Mx[0, 0] - Mx[1, 1]]])
+        ev = np.linalg.eigvalsh(Nm)
+        gap = (ev[3] - ev[2]) / max(np.abs(ev).max(), 1e-300)
+        q = np.zeros(4)
+        fast = shim.t_eig4_fast(_dp(np.ascontiguousarray(Nm)), _dp(q))
+        n_fast += fast
+        err = np.abs(R0 - R1).max()
+        assert err < 1e-11 / max(gap, 1e-6), (err, gap, fast)
+        if gap > 1e-3:
+            worst = max(worst, err)
+    assert worst < 5e-13 and n_fast > 250
