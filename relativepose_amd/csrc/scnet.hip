@@ -49,6 +49,12 @@ typedef float rp_f4v __attribute__((ext_vector_type(4)));
 #ifndef RP_BK
 #define RP_BK 32
 #endif
+#ifndef RP_STAGGER
+#define RP_STAGGER 0            // 0 = off; n = workgroups (blockIdx.x / n) % 3 get a start offset (see the k-loop prologue)
+#endif
+#ifndef RP_STAGGER_SLEEP
+#define RP_STAGGER_SLEEP 64     // s_sleep units of 64 cycles
+#endif
 constexpr int BK = RP_BK;       // K-tile (floats): 16 (double-buffered LDS) or 32 (whole 128-B lines per row, single LDS buffer)
 constexpr int LDK = BK + 4;     // LDS row stride in floats (80 / 144 B: 16-B aligned, conflict-free b128 reads)
 constexpr int KQ = BK / 4;      // float4 slots per tile row
@@ -177,6 +183,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#if RP_STAGGER
+    // Phase-stagger the workgroups that share a CU (experiment): identical blocks launched together run their k loops in
+    // lockstep, so their MFMA-free phases (transform + LDS store + barriers) coincide on every SIMD and the matrix pipe
+    // idles; a one-time offset of 1/3 and 2/3 of a k-tile period de-phases the three resident blocks.
+    {
+        const int ph = (blockIdx.x / RP_STAGGER) % 3;
+        if (ph >= 1) __builtin_amdgcn_s_sleep(RP_STAGGER_SLEEP);
+        if (ph >= 2) __builtin_amdgcn_s_sleep(RP_STAGGER_SLEEP);
+    }
+#endif
 
     // B rows of this thread (BN < 64: rows are clamped, the extra threads re-load row BN-1 and never store)
     const float* b_src[B_IT];
