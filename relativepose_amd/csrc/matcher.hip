@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void eig_finish_kernel(RelposeKeypoints kp, Gr
 #define RP_LZ_MAXPROD 192       // products per eigen-solve before giving up
 #define RP_LZ_TOL 1e-13
 #ifndef RP_TRI_ROUNDS
-#define RP_TRI_ROUNDS 10        // 64-way multisection rounds of the tridiagonal eigenvalue (6 bits each)
+#define RP_TRI_ROUNDS 4         // 64-way multisection rounds of the tridiagonal eigenvalue (6 bits each) before the Newton polish (>= 9: no polish)
 #endif
 #define RP_FIT1_MAXC 4500       // LDS: 3 vectors of C doubles + 2 x (C + 1) ints
 
@@ -869,7 +869,7 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     const int32_t* col; const double* wv; double* xe;      // this pair's edges (global, segment layout)
     const int32_t* segrow; double* part;
     double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
-    int C, Cmax, nseg;
+    int C, Cmax, nseg, tri_rounds;
 };
 
 // One pass over the pair's edges: thread <-> segment (<= 32 edges of one row, read with stride 64 so that a wave's loads
@@ -949,7 +949,7 @@ __device__ __forceinline__ double rp_fast_div(double a, double b) {
 // Largest eigenpair of the symmetric tridiagonal T (alpha[0..m), beta[0..m-1)) on ONE wave: eigenvalue by 64-way
 // multisection on Sturm counts, eigenvector by inverse iteration with theta shifted just above the spectrum
 // (theta I - T is then positive definite: LDL^T without pivoting).  s is normalised.  Returns theta.
-__device__ double tridiag_top(const double* alpha, const double* beta, int m, double* s, double* dscr) {
+__device__ double tridiag_top(const double* alpha, const double* beta, int m, double* s, double* dscr, int rounds) {
     const int lane = threadIdx.x & 63;
     double lo = -INFINITY, hi = -INFINITY, scale = 0.0;
     for (int k = 0; k < m; ++k) {
@@ -961,7 +961,7 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
     if (!(scale > 0.0)) { for (int k = lane; k < m; k += 64) s[k] = (k == 0) ? 1.0 : 0.0; return 0.0; }
     const double tiny = scale * 1e-300 + 1e-300;
     lo -= scale * 1e-15; hi += scale * 1e-15;
-    for (int round = 0; round < RP_TRI_ROUNDS; ++round) {
+    for (int round = 0; round < rounds; ++round) {
         const double x = lo + (hi - lo) * ((double)(lane + 1) / 64.0);          // lane 63 tests hi itself
         int cnt = 0;
         double q = alpha[0] - x;
@@ -978,7 +978,29 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
         const double nhi = lo + (hi - lo) * ((double)(first + 1) / 64.0);
         lo = nlo; hi = nhi;
     }
-    const double theta = hi;                                                    // >= lambda_max, within ~1e-15 relative
+    // polish: lambda_max is the largest root of the last pivot d_m(x) of x I - T, which is increasing and concave to the right of
+    // lambda_max(T_{m-1}); Newton from the LEFT end of the bracket therefore climbs monotonically to the root.  d and d' by the
+    // pivot recurrence d_k = (x - alpha_k) - beta_{k-1}^2 / d_{k-1}.  (All lanes compute the same numbers.)
+    double theta = hi;
+    if (rounds < 9) {
+        double x = lo;
+        for (int it = 0; it < 8; ++it) {
+            double d = x - alpha[0], dd = 1.0;
+            bool ok = d > 0.0;
+            for (int k = 1; k < m && ok; ++k) {
+                const double b2 = beta[k - 1] * beta[k - 1], id = 1.0 / d;
+                dd = 1.0 + b2 * dd * id * id;
+                d = (x - alpha[k]) - b2 * id;
+                ok = (k == m - 1) || d > 0.0;                                  // inner pivots must stay positive (x > lambda_max(T_{m-1}))
+            }
+            if (!ok) break;                                                     // bracket end below lambda_max(T_{m-1}): keep the multisection result
+            const double xn = x - d / dd;
+            if (!(xn > x) || !(xn <= hi)) { if (xn == x) theta = x; break; }
+            x = xn; theta = x;
+            if (fabs(d) <= 4e-16 * scale * dd) break;
+        }
+        if (!(theta >= lo && theta <= hi)) theta = hi;
+    }
     if (lane == 0) {
         const double sh = theta + scale * 4e-16;
         double* id = dscr;                      // reciprocal pivots of theta I - T
@@ -1029,7 +1051,13 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 for (int i = wave; i <= j; i += nw) {
                     const double* vi = f.V + (size_t)i * f.Cmax;
                     double d = 0.0;
-                    for (int c = lane; c < C; c += 64) d += rp_ldg(vi + c) * f.yy[c];
+                    for (int c0 = lane; c0 < C; c0 += 64 * 8) {           // 8 loads in flight, then accumulated in order
+                        double v8[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v8[q] = (c0 + 64 * q < C) ? rp_ldg(vi + c0 + 64 * q) : 0.0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if (c0 + 64 * q < C) d += v8[q] * f.yy[c0 + 64 * q];
+                    }
                     d = rp_wave_sum(d);
                     if (lane == 0) f.cbuf[i] = d;
                 }
@@ -1039,7 +1067,13 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 alpha += f.cbuf[j];
                 for (int c = tid; c < C; c += blockDim.x) {
                     double acc = f.yy[c];
-                    for (int i = 0; i <= j; ++i) acc -= f.cbuf[i] * rp_ldg(f.V + (size_t)i * f.Cmax + c);
+                    for (int i0 = 0; i0 <= j; i0 += 8) {                   // 8 basis vectors' entries in flight
+                        double v8[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v8[q] = (i0 + q <= j) ? rp_ldg(f.V + (size_t)(i0 + q) * f.Cmax + c) : 0.0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if (i0 + q <= j) acc -= f.cbuf[i0 + q] * v8[q];
+                    }
                     f.yy[c] = acc;
                     nn[1] += acc * acc;
                 }
@@ -1065,7 +1099,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 // Ritz pair of the m x m tridiagonal matrix, residual estimate beta_m |s_m|
                 long long t2_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
                 if (wave == 0) {
-                    const double th = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri + 3 * (RP_LZ_M + 1));
+                    const double th = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri + 3 * (RP_LZ_M + 1), f.tri_rounds);
                     if (lane == 0) f.red[159] = th;
                 }
                 __syncthreads();
@@ -1090,7 +1124,13 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
         double nn[1] = {0.0};
         for (int c = tid; c < C; c += blockDim.x) {
             double acc = 0.0;
-            for (int i = 0; i < m; ++i) acc += sv[i] * rp_ldg(f.V + (size_t)i * f.Cmax + c);
+            for (int i0 = 0; i0 < m; i0 += 8) {
+                double v8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v8[q] = (i0 + q < m) ? rp_ldg(f.V + (size_t)(i0 + q) * f.Cmax + c) : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (i0 + q < m) acc += sv[i0 + q] * v8[q];
+            }
             f.yy[c] = acc;
             nn[0] += acc * acc;
         }
@@ -1234,7 +1274,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
                                                                     double* __restrict__ lz_basis, int32_t* __restrict__ status,
                                                                     double* __restrict__ pose, double* __restrict__ trace,
                                                                     int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out,
-                                                                    long long* __restrict__ prof) {
+                                                                    long long* __restrict__ prof, int tri_rounds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[160];
     __shared__ double Rt[12];
@@ -1262,6 +1302,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     }
     Fit1 f;
     f.prof = prof;
+    f.tri_rounds = tri_rounds;
     const long long tstart_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     f.C = C; f.Cmax = g.Cmax;
     f.vec = (double*)smem; f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
@@ -1525,15 +1566,22 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
             if (!prof) RP_HIP(hipMalloc((void**)&prof, 64));
             RP_HIP(hipMemsetAsync(prof, 0, 64, s));
         }
-        static const int fit_threads = getenv("RELPOSE_FIT_THREADS") ? atoi(getenv("RELPOSE_FIT_THREADS")) : RP_FIT1_THREADS;     // experiment switch
-        if (fit_threads == 512) {
+        static const int tri_rounds = getenv("RELPOSE_TRI_ROUNDS") ? atoi(getenv("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS;
+        // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences,
+        // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 768 | 1024 overrides (experiments).
+        const int fit_threads = getenv("RELPOSE_FIT_THREADS") ? atoi(getenv("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);
+        if (fit_threads == 768) {
+            RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fit_pair_kernel<768>, dim3(kp->B), dim3(768), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
+                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds);
+        } else if (fit_threads == 512) {
             RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(fit_pair_kernel<512>, dim3(kp->B), dim3(512), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
-                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof);
+                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds);
         } else {
             RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(fit_pair_kernel<1024>, dim3(kp->B), dim3(1024), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
-                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof);
+                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds);
         }
         RP_CHECK_LAUNCH();
         if (prof) {       // debug only: synchronises

@@ -49,6 +49,9 @@ typedef float rp_f4v __attribute__((ext_vector_type(4)));
 #ifndef RP_BK
 #define RP_BK 32
 #endif
+#ifndef RP_AGPR
+#define RP_AGPR 0               // 1 = fp32 MFMA accumulators in AccVGPRs through inline asm (experiment)
+#endif
 #ifndef RP_STAGGER
 #define RP_STAGGER 0            // 0 = off; n = workgroups (blockIdx.x / n) % 3 get a start offset (see the k-loop prologue)
 #endif
@@ -351,6 +354,31 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
                     }
             }
         } else
+#if RP_AGPR
+        {   // experiment: accumulators pinned to AccVGPRs (the compiler picks the ArchVGPR form of the MFMA); fragments of step
+            // kc + 1 are read from LDS before the MFMAs of step kc are issued; k-major MFMA order (4 accumulators in rotation)
+            float4 a[2][MI], b[2][NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[0][i] = *reinterpret_cast<const float4*>(&As[buf][arow + i * 32 * LDK]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[0][j] = *reinterpret_cast<const float4*>(&Bs[buf][brow + j * 32 * LDK]);
+#pragma unroll
+            for (int kc = 0; kc < BK / 8; ++kc) {
+                const int cur = kc & 1, nxt = cur ^ 1;
+                if (kc + 1 < BK / 8) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[nxt][i] = *reinterpret_cast<const float4*>(&As[buf][arow + i * 32 * LDK + (kc + 1) * 8]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) b[nxt][j] = *reinterpret_cast<const float4*>(&Bs[buf][brow + j * 32 * LDK + (kc + 1) * 8]);
+                }
+#define RP_MFMA_A(C_) \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[cur][i].C_), "v"(b[cur][j].C_));
+                RP_MFMA_A(x) RP_MFMA_A(y) RP_MFMA_A(z) RP_MFMA_A(w)
+#undef RP_MFMA_A
+            }
+        }
+#else
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             float4 a[MI], b[NI];
@@ -379,6 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
 #endif
                 }
         }
+#endif
 #if RP_ABLATE != 5
         if (NBUF == 1) __syncthreads();                 // single buffer: every wave is done reading tile kt
         if (kt + 1 < nkt) RP_STORE_TILE(NBUF == 2 ? (buf ^ 1) : 0)
