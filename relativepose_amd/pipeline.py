@@ -119,7 +119,11 @@ class RelativePosePipeline:
         # (measured: matcher phase 16 ms vs 29 ms under a concurrent forward, profiles/r01_overlap.txt)
         import torch
         if self._net_stream is None:
-            self._net_stream = torch.cuda.Stream()
+            # RELPOSE_NET_PRIO: HIP stream priority of the SCNet stream (experiment; -1 = high: conv workgroups are dispatched
+            # ahead of the matcher / geometry kernels of the batches in flight)
+            import os
+            prio = int(os.environ.get("RELPOSE_NET_PRIO", "0"))
+            self._net_stream = torch.cuda.Stream(priority=prio)
         self._net_stream.wait_stream(torch.cuda.current_stream())
 
     def run_pipelined(self, states, steps, on_result=None, depth=None, before_batch=None):

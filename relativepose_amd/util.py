@@ -216,3 +216,38 @@ def depth2pc(depth, dataList):
     pc, valid = depth2pc_dev(torch.from_numpy(pano).to(dev), dataList)
     m = valid[0].cpu().numpy().astype(bool)
     return pc[0].cpu().numpy()[m], m
+
+
+def parse_data(depth, rgb, norm, dataList, method):
+    """util.py:42-92, same signature and 8-tuple: the observed block of both scans as point clouds (+ colours, normals).
+    depth [1,2,160,640], rgb uint8 [1,2,3,160,640], norm [1,2,3,160,640] numpy.  Built for the configurations the hot path
+    evaluates: suncg / matterport (face [160,320)) and scannet with method 'ours' (the 66x88 kinect crop)."""
+    if 'suncg' in dataList or 'matterport' in dataList:
+        ys, xs = slice(None), slice(160, 320)
+    elif 'scannet' in dataList:
+        if 'ours' not in method:
+            raise NotImplementedError("parse_data: the full-resolution scannet branch (baselines) is outside the hot path")
+        ys, xs = slice(80 - 33, 80 + 33), slice(160 + 80 - 44, 160 + 80 + 44)
+    else:
+        raise ValueError(f"unknown dataset {dataList}")
+    out = {}
+    for v, tag in ((0, "src"), (1, "tgt")):
+        d = depth[0, v, ys, xs]
+        col = rgb[0, v, :, ys, xs].transpose(1, 2, 0)
+        nrm = norm[0, v, :, ys, xs].copy().transpose(1, 2, 0)
+        pc, mask = depth2pc(d, dataList)
+        col = col.reshape(-1, 3)[mask] / 255.
+        nrm = nrm.reshape(-1, 3)[mask]
+        if 'scannet' in dataList:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+            nrm[np.isnan(nrm.sum(1))] = 0
+        out[tag] = (d, nrm, col, pc)
+    s, t = out["src"], out["tgt"]
+    return s[0], t[0], s[1], t[1], s[2], t[2], s[3], t[3]
+
+
+def angular_distance_np(R_hat, R):
+    """util.py:176-187 (lives in relativepose_amd.evaluation; re-exported under the reference's module name)."""
+    from .evaluation import angular_distance_np as f
+    return f(R_hat, R)

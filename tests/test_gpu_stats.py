@@ -34,3 +34,37 @@ def test_depth2pc_and_overlap(golden_dir, ds, mm, seed):
     log("overlap", ds=ds, got=[float(x) for x in got], want=[float(x) for x in want], reference=gst[f"stats_{ds}_overlap"].tolist())
     assert np.allclose(got, want, rtol=1e-9, atol=1e-12)
     assert np.allclose(got, gst[f"stats_{ds}_overlap"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("ds,mm,seed", GEOM_CASES)
+def test_parse_data_and_evaluate_pairs_records(golden_dir, tmp_path, ds, mm, seed):
+    """util.parse_data with the reference's signature reproduces the reference's clouds (golden head + counts), and the
+    batched evaluation harness writes result records with the reference's keys whose overlap statistics equal the golden."""
+    import torch
+    from types import SimpleNamespace
+    from relativepose_amd import evaluation as E
+    from relativepose_amd import util, weights
+    from relativepose_amd.model import SCNet
+    from relativepose_amd.pipeline import RelativePosePipeline
+    gst = np.load(os.path.join(golden_dir, "stats.npz"))
+    d = synth.make_pairs(1, seed + 40, ds)
+    rgb_u8 = (d["rgb"] * 255).clip(0, 255).astype("uint8")
+    res = util.parse_data(d["depth"], rgb_u8, d["norm"], ds, "ours")
+    pc_src, pc_tgt = res[6], res[7]
+    assert [len(pc_src), len(pc_tgt)] == gst[f"stats_{ds}_n"].tolist()
+    assert np.array_equal(pc_src[:128], gst[f"stats_{ds}_pc_head"])
+    assert res[4].shape == pc_src.shape and res[2].shape == pc_src.shape and res[4].max() <= 1.0
+    # harness: one pair, one level is enough for the bookkeeping
+    S = 15
+    net = SCNet(SimpleNamespace(batchnorm=1, useTanh=1, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+    net.load_state_dict(weights.make_state_dict(7, S))
+    pipe = RelativePosePipeline(net, ds, mm, alter_steps=1)
+    pts, ptw = synth.make_keypoints(1, 40, seed, mm)
+    batch = dict(d, pts=pts, ptw=ptw)
+    out = str(tmp_path / "exp.result")
+    stats = E.evaluate_pairs(pipe, [batch], torch.device("cuda:0"), result_path=out)
+    assert len(stats) == 1 and os.path.exists(out + ".npy")
+    rec = E.load_results(out + ".npy")[0]
+    want = gst[f"stats_{ds}_overlap"]
+    assert np.allclose([rec["overlap"], rec["cam_dist"], rec["pc_dist"], rec["pc_nearest"]], want, rtol=1e-9, atol=1e-12)
+    assert np.allclose(rec["R_gt"], gst[f"stats_{ds}_Rgt"]) and rec["R_pred_44"].shape == (4, 4) and rec["err_ad"] >= 0
