@@ -50,3 +50,12 @@ for name, env in (("single-workgroup Lanczos fit (default)", {}), ("round-1 laun
 a, b = list(out.values())
 print("rotation difference between the two fits (Frobenius): max %.3e median %.3e" % (np.linalg.norm((a - b)[:, :3, :3], axis=(1, 2)).max(),
       np.median(np.linalg.norm((a - b)[:, :3, :3], axis=(1, 2)))))
+# which fit is right where they differ most?  the CPU oracle (scipy ARPACK like the reference) on that pair
+from oracle import rp_oracle as M
+worst = int(np.argmax(np.linalg.norm((a - b)[:, :3, :3], axis=(1, 2))))
+cpu = lambda t: t.cpu().numpy()
+S_ = {"pc": cpu(args[0][worst]), "normal": cpu(args[1][worst]), "feat": cpu(args[2][worst]), "weight": cpu(args[3][worst])}
+T_ = {"pc": cpu(args[4][worst]), "normal": cpu(args[5][worst]), "feat": cpu(args[6][worst]), "weight": cpu(args[7][worst])}
+ref = M.relative_pose_helper(S_, T_, M.Params(*sig[0]))
+print("pair %d (largest difference): rotation error vs the oracle (ARPACK): Lanczos fit %.3e, launch-sequence (64-step power iteration) fit %.3e"
+      % (worst, np.linalg.norm(a[worst, :3, :3] - ref[:3, :3]), np.linalg.norm(b[worst, :3, :3] - ref[:3, :3])))
