@@ -869,7 +869,7 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     const int32_t* col; const double* wv; double* xe;      // this pair's edges (global, segment layout)
     const int32_t* segrow; double* part;
     double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
-    int C, Cmax, nseg, tri_rounds;
+    int C, Cmax, nseg, tri_rounds, max_prod;
 };
 
 // One pass over the pair's edges: thread <-> segment (<= 32 edges of one row, read with stride 64 so that a wave's loads
@@ -1139,7 +1139,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
         for (int c = tid; c < C; c += blockDim.x) f.vec[c] = f.yy[c] * inv;
         __syncthreads();
         if (beta_last == 0.0) return nprod;                                        // converged (or exact)
-        if (nprod + RP_LZ_CHECK > RP_LZ_MAXPROD) break;
+        if (nprod + RP_LZ_CHECK > f.max_prod) break;
     }
     *converged = 0;
     return nprod;
@@ -1302,7 +1302,8 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     }
     Fit1 f;
     f.prof = prof;
-    f.tri_rounds = tri_rounds;
+    f.tri_rounds = tri_rounds & 0xff;
+    f.max_prod = tri_rounds >> 8;
     const long long tstart_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     f.C = C; f.Cmax = g.Cmax;
     f.vec = (double*)smem; f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
@@ -1566,7 +1567,9 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
             if (!prof) RP_HIP(hipMalloc((void**)&prof, 64));
             RP_HIP(hipMemsetAsync(prof, 0, 64, s));
         }
-        static const int tri_rounds = getenv("RELPOSE_TRI_ROUNDS") ? atoi(getenv("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS;
+        // (multisection rounds | product budget << 8); RELPOSE_LZ_MAXPROD is a test hook: a tiny budget forces RELPOSE_NOT_CONVERGED
+        const int tri_rounds = (getenv("RELPOSE_TRI_ROUNDS") ? atoi(getenv("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS) |
+                               ((getenv("RELPOSE_LZ_MAXPROD") ? atoi(getenv("RELPOSE_LZ_MAXPROD")) : RP_LZ_MAXPROD) << 8);
         // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences,
         // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 768 | 1024 overrides (experiments).
         const int fit_threads = getenv("RELPOSE_FIT_THREADS") ? atoi(getenv("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);

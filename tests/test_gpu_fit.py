@@ -86,3 +86,51 @@ def test_not_converged_is_reported_not_hidden():
     if st == 0:
         # converged: it must then be one of the two planted motions' fits, like ARPACK's answer, up to which cluster wins
         assert np.allclose(res.pose[0].cpu().numpy()[3], [0, 0, 0, 1])
+
+
+def test_exhausted_product_budget_sets_not_converged_status():
+    """RELPOSE_LZ_MAXPROD (test hook) = 8 products: no eigen-solve of a 60 %-inlier pair can reach 1e-13 in one 8-step cycle, so
+    the pair must come back with RELPOSE_NOT_CONVERGED (6) and a finite pose close to (but not claimed equal to) the converged one."""
+    from relativepose_amd import rpmodule
+    S, T, _ = synth.make_match_case(200, 14)
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.009)
+    good = _run([(S, T)], para, debug=True)
+    os.environ["RELPOSE_LZ_MAXPROD"] = "8"
+    try:
+        bad = _run([(S, T)], para, debug=True)
+    finally:
+        del os.environ["RELPOSE_LZ_MAXPROD"]
+    assert int(good.status[0]) == 0 and int(bad.status[0]) == 6
+    assert bad.eig_iters[0].max().item() <= 8 and good.eig_iters[0].max().item() > 8
+    pb = bad.pose[0].cpu().numpy()
+    assert np.isfinite(pb).all() and np.allclose(pb[:3, :3] @ pb[:3, :3].T, np.eye(3), atol=1e-9)
+    log("fit_forced_not_converged", rot_diff_vs_converged=float(np.linalg.norm(pb[:3, :3] - good.pose[0].cpu().numpy()[:3, :3])))
+
+
+def test_register_affinity_kernel_equals_lds_kernel():
+    """The register-resident affinity kernel (nt_max <= 512) against the round-1 LDS kernel it replaces (kept for larger target sets):
+    identical correspondences (the float32 distance and the top-K tie rule are bit-for-bit the same), weights to round-off."""
+    import torch
+    from relativepose_amd import rpmodule
+    dev = torch.device("cuda:0")
+    cases = [synth.make_match_case(n, 40 + n, inlier=i, Nt=nt)[:2] for n, nt, i in ((400, 400, 0.6), (200, 130, 0.3), (64, 65, 0.6), (7, 6, 0.6), (3, 3, 0.6))]
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.0095)
+    kp = rpmodule.pack_keypoints(cases, dev)
+    new = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+    os.environ["RELPOSE_LEGACY_AFFINITY"] = "1"
+    try:
+        old = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+    finally:
+        del os.environ["RELPOSE_LEGACY_AFFINITY"]
+    assert torch.equal(new[1], old[1]) and torch.equal(new[3], old[3])                  # corres_j, k_eff
+    assert torch.allclose(new[2], old[2], rtol=1e-12, atol=0)                           # corres_w (f64)
+    assert torch.allclose(new[0], old[0], rtol=2e-6, atol=1e-44)                        # wij (f32 copy)
+    # a target set larger than the register kernel takes (nt_max > 512) still goes through the LDS kernel
+    big = [synth.make_match_case(40, 77, Nt=600)[:2]]
+    kb = rpmodule.pack_keypoints(big, dev)
+    wij, cj, cw, keff = rpmodule.affinity_topk(kb[2], kb[3], kb[6], kb[7], kb[8], kb[9], para)
+    d = M.affinity(big[0][0]["feat"], big[0][1]["feat"], big[0][0]["weight"], big[0][1]["weight"], para.sigmaFeat)
+    ref = M.topk(d[2], 5)[1].reshape(40, 5)
+    for i in range(40):
+        pos = d[2][i, ref[i]] > 0
+        assert set(ref[i][pos].tolist()) <= set(cj[0, i].cpu().tolist())
