@@ -1106,7 +1106,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 theta = f.red[159];
                 if (f.prof && tid == 0 && blockIdx.x == 0) f.prof[2] += (long long)__builtin_readcyclecounter() - t2_;
                 const double resid = invariant ? 0.0 : beta_last * fabs(f.tri[2 * (RP_LZ_M + 1) + m - 1]);
-                if (invariant || m == RP_LZ_M || resid <= RP_LZ_TOL * fabs(theta)) {
+                if (invariant || m == RP_LZ_M || resid <= RP_LZ_TOL * fabs(theta) || nprod >= f.max_prod) {
                     done = true;
                     if (resid <= RP_LZ_TOL * fabs(theta)) beta_last = 0.0;         // flag: converged
                 }
