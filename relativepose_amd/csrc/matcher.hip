@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
 #define RP_MAXK 8
 #define RP_FEAT 32
 #define RP_FIT_THREADS 512
@@ -199,7 +201,10 @@ __global__ __launch_bounds__(256) void affinity_topk_kernel(RelposeKeypoints kp,
 // two values), the K winners by K rounds of {per-lane best, DPP wave maximum, owner pops}, exp() only in the target slots
 // where some lane is within 110 of the row maximum (everything below is < 2^-150 relative: exactly 0 in the float32 wij and
 // invisible in the float64 row norm), the norm, the K outputs (exp + divide on K lanes in parallel) and, if wanted, wij.
-struct AffConsts { double den[2], rden[2]; int exact_div; };        // [0] = other, [1] = both observed
+struct AffConsts { double den[2], rden[2]; int exact_div; };
+// wij entries more than RP_AFF_WINDOW below the row's best exponent (< e^-75 = 2.7e-33 of the row maximum) are written as exact zeros and
+// left out of the float64 row norm (they change it by < 1e-65 relative): exp() is evaluated only inside the window
+#define RP_AFF_WINDOW 75.0        // [0] = other, [1] = both observed
 
 __device__ __forceinline__ double rp_wave_max_d(double v) {
     // butterfly inside every row of 16 lanes (DPP), then the four row results through SGPRs
@@ -214,7 +219,10 @@ __device__ __forceinline__ double rp_wave_max_d(double v) {
     return fmax(fmax(a, b), fmax(c, d));
 }
 
-template <int TP, bool WRITE_WIJ>       // TP = pairs of target slots per lane (targets <= 128 * TP)
+// FIXUP: only the rows that affinity_gram_kernel marked (corres_j[row][0] == RP_AFF_REDO: more candidates than its per-lane
+// stack holds) are processed; a wave without marked rows exits before staging anything.
+#define RP_AFF_REDO (-1)
+template <int TP, bool WRITE_WIJ, bool FIXUP = false>       // TP = pairs of target slots per lane (targets <= 128 * TP)
 __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp, AffConsts ac, int topK, int rows_per_wave,
                                                              float* __restrict__ wij, int32_t* __restrict__ corres_j,
                                                              double* __restrict__ corres_w, int32_t* __restrict__ keff_out) {
@@ -222,11 +230,17 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
     const int b = blockIdx.y;
     const int ns = kp.ns[b], nt = kp.nt[b];
     const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
+    if (!FIXUP && blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
     if (keff == 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
     if (row0 >= ns) return;
+    if (FIXUP) {
+        bool any = false;
+        for (int rr = 0; rr < rows_per_wave && row0 + rr < ns; ++rr)
+            any = any || corres_j[((size_t)b * kp.ns_max + row0 + rr) * topK] == RP_AFF_REDO;
+        if (!any) return;
+    }
     // ---- this lane's targets: descriptors / 100 (float32 division like numpy), observed-weight flags
     rp_v2f ft[TP][RP_FEAT];
     double wt[T];
@@ -252,6 +266,7 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
         const int i = row0 + rr;
         if (i >= ns) break;
         const size_t si = (size_t)b * kp.ns_max + i;
+        if (FIXUP && corres_j[si * topK] != RP_AFF_REDO) continue;
         const float fsl = kp.feat_s[si * RP_FEAT + (lane & 31)] / 100.0f;
         const double wsi = kp.weight_s[si];
         float sc[RP_FEAT];                       // the row's descriptor, wave-uniform (SGPRs)
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
         double sumsq = 0.0;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const bool need = e[t] >= emax - 110.0;               // false for the padding (-inf)
+            const bool need = e[t] >= emax - RP_AFF_WINDOW;       // false for the padding (-inf)
             w[t] = 0.0;
             if (__ballot(need)) {
                 const double v = exp(e[t]);
@@ -351,6 +366,286 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
                 const int j = t * 64 + lane;
                 if (j < nt) row[j] = (float)(w[t] * inm);
             }
+        }
+    }
+}
+
+// ---- Gram (MFMA) variant: exact work only for candidates ------------------------------------------------------------------
+// The numpy-order float32 distance costs 95 separately rounded operations per entry and the row top-K costs K cross-lane
+// reductions per row -- but only a handful of entries per row matter: the K winners and whatever lies within 110 of the
+// row maximum (everything else is exactly 0 in the float32 wij and invisible in the float64 norm).  This kernel finds those
+// entries from an APPROXIMATE distance and spends exact arithmetic only on them:
+//   1. approximate squared distances |s|^2 + |t|^2 - 2 s.t from v_mfma_f32_32x32x2_f32 with the TARGETS as the M dimension
+//      and 32 source rows as the N dimension: in the C layout lane l then holds, for ITS source row (l & 31), 16 targets per
+//      32-target tile (lanes l and l ^ 32 share a row).  Row-wise selection becomes in-lane work: every lane keeps the K
+//      largest approximate exponents of its half row (one v_max + K-1 v_med3 per entry, no cross-lane traffic), the two
+//      halves are merged with K exchanges.
+//   2. with err bounding |approximate - exact| exponent, every true winner satisfies e~ >= e~_(K) - 2 err, and every entry
+//      that can contribute to the norm or to wij satisfies e~ >= e~_max - 110 - 2 err: a second MFMA pass pushes the entries
+//      above min(those two thresholds) on a per-lane stack (LDS);
+//   3. the stack entries get the exact treatment of affinity_rows_kernel: numpy-order distance (packed over feature pairs),
+//      Markstein division, float64 exp, exact (e, smaller j) ordering, norm.  A row with more candidates than the stack
+//      holds is marked RP_AFF_REDO and redone by affinity_rows_kernel<FIXUP> (launched right behind, normally a no-op).
+// Results are identical to affinity_rows_kernel's (same exact arithmetic on a superset of the entries that matter).
+#define AG_WAVES 8             // waves per workgroup = tiles of 32 source rows
+#define AG_LDT 36              // LDS row stride of the target descriptors (floats): conflict-free b128 reads
+#define AG_CAP 48              // candidate stack entries per lane (half a row), uint16 target indices
+
+template <bool WRITE_WIJ, int KL>       // KL = length of the per-lane winner lists (>= topK): 5 or RP_MAXK
+__global__ __launch_bounds__(AG_WAVES * 64) void affinity_gram_kernel(RelposeKeypoints kp, AffConsts ac, int topK, int ntp,
+                                                                       float* __restrict__ wij, int32_t* __restrict__ corres_j,
+                                                                       double* __restrict__ corres_w, int32_t* __restrict__ keff_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NT = blockDim.x, rows_per_block = (NT >> 6) * 32;      // 2, 4 or 8 waves: small batches use smaller workgroups
+    const int b = blockIdx.y;
+    const int ns = kp.ns[b], nt = kp.nt[b];
+    const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
+    if (keff == 0) return;
+    if (blockIdx.x * rows_per_block >= ns) return;
+    float* ftT = (float*)smem;                                   // [ntp][AG_LDT] scaled target descriptors
+    double* wts = (double*)(ftT + (size_t)ntp * AG_LDT);         // [ntp] target weights
+    float* ntn = (float*)(wts + ntp);                            // [ntp] |t|^2 (+inf beyond nt: such entries get e~ = -inf)
+    float* ntmax_s = ntn + ntp;                                  // [4]
+    unsigned short* stk = (unsigned short*)(ntmax_s + 4);         // [AG_CAP][NT] candidate target indices (nt <= 512)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, n = lane & 31;
+    {   // ---- stage the pair's targets: descriptors / 100 (float32 division like numpy), squared norms, weights
+        const float* ftg = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
+        for (int idx = tid; idx < ntp * (RP_FEAT / 4); idx += NT) {
+            const int j = idx >> 3, c4 = idx & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < nt) { v = rp_ldg4(ftg + (size_t)j * RP_FEAT + 4 * c4); v.x /= 100.0f; v.y /= 100.0f; v.z /= 100.0f; v.w /= 100.0f; }
+            *reinterpret_cast<float4*>(&ftT[j * AG_LDT + 4 * c4]) = v;
+        }
+        for (int j = tid; j < ntp; j += NT) wts[j] = (j < nt) ? kp.weight_t[(size_t)b * kp.nt_max + j] : 0.0;
+        if (tid == 0) ntmax_s[0] = 0.f;
+        __syncthreads();
+        float mx = 0.f;
+        for (int j = tid; j < ntp; j += NT) {
+            float a = 0.f;
+            for (int c = 0; c < RP_FEAT; ++c) a += ftT[j * AG_LDT + c] * ftT[j * AG_LDT + c];
+            ntn[j] = (j < nt) ? a : INFINITY;
+            if (j < nt) mx = fmaxf(mx, a);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0) atomicMax((int*)&ntmax_s[0], __float_as_int(mx));       // non-negative floats order like ints
+        __syncthreads();
+    }
+    const float ntmax = ntmax_s[0];
+    const int i = blockIdx.x * rows_per_block + wave * 32 + n;                   // this lane's source row (both halves of a wave share it)
+    const bool rowok = i < ns;
+    const size_t si = (size_t)b * kp.ns_max + (rowok ? i : 0);
+    // ---- the source row: all 32 scaled features (exact distances) + the half this lane feeds to the MFMA
+    float fs[RP_FEAT];
+#pragma unroll
+    for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
+        float4 v = rowok ? rp_ldg4(kp.feat_s + si * RP_FEAT + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        fs[4 * c4] = v.x / 100.0f; fs[4 * c4 + 1] = v.y / 100.0f; fs[4 * c4 + 2] = v.z / 100.0f; fs[4 * c4 + 3] = v.w / 100.0f;
+    }
+    float sb[16], nsq = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sb[q] = h ? fs[16 + q] : fs[q];
+#pragma unroll
+    for (int c = 0; c < RP_FEAT; ++c) nsq += fs[c] * fs[c];
+    const double wsi = rowok ? kp.weight_s[si] : 0.0;
+    const float rdf0 = (float)ac.rden[0], rdf1 = (float)ac.rden[1];
+    const int ntiles = ntp / 32;                                                // even: ntp is a multiple of 64
+
+    // approximate exponents of TWO 32-target tiles (two independent MFMA accumulator chains) for this lane's row:
+    // et[u][r] belongs to target j0 + 32 u + 8 (r >> 2) + 4 h + (r & 3)
+    auto tile_exponents = [&](int j0, float (&et)[2][16]) {
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const float4* ar0 = reinterpret_cast<const float4*>(&ftT[(j0 + n) * AG_LDT + 16 * h]);
+        const float4* ar1 = reinterpret_cast<const float4*>(&ftT[(j0 + 32 + n) * AG_LDT + 16 * h]);
+        const float4 a0 = ar0[0], a1 = ar0[1], a2 = ar0[2], a3 = ar0[3], b0 = ar1[0], b1 = ar1[1], b2 = ar1[2], b3 = ar1[3];
+        const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+        const float bv[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], sb[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[q], sb[q], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int jb = j0 + 32 * u + 8 * r4 + 4 * h;
+                const float4 tn = *reinterpret_cast<const float4*>(&ntn[jb]);
+                const double2 w01 = *reinterpret_cast<const double2*>(&wts[jb]), w23 = *reinterpret_cast<const double2*>(&wts[jb + 2]);
+                const float tnv[4] = {tn.x, tn.y, tn.z, tn.w};
+                const double wv[4] = {w01.x, w01.y, w23.x, w23.y};
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float g = u ? acc1[4 * r4 + rr] : acc0[4 * r4 + rr];
+                    const float dt = __builtin_fmaf(-2.0f, g, nsq + tnv[rr]);
+                    const float rd = (wsi * wv[rr] == 1.0) ? rdf1 : rdf0;
+                    et[u][4 * r4 + rr] = -(dt * rd);
+                }
+            }
+    };
+
+    // ---- pass 1: the KL largest approximate exponents of the half row (sorted, te[0] = max)
+    float te[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) te[k] = -INFINITY;
+    for (int t = 0; t < ntiles; t += 2) {
+        float et[2][16];
+        tile_exponents(t * 32, et);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = et[u][r];
+                float prev = te[0];
+                te[0] = fmaxf(prev, x);
+#pragma unroll
+                for (int k = 1; k < KL; ++k) { const float cur = te[k]; te[k] = __builtin_amdgcn_fmed3f(prev, cur, x); prev = cur; }
+            }
+    }
+    {   // merge with the other half of the row (lane ^ 32)
+        float ot[KL];
+#pragma unroll
+        for (int k = 0; k < KL; ++k) ot[k] = __shfl_xor(te[k], 32, 64);
+#pragma unroll
+        for (int kk = 0; kk < KL; ++kk) {
+            const float x = ot[kk];
+            float prev = te[0];
+            te[0] = fmaxf(prev, x);
+#pragma unroll
+            for (int k = 1; k < KL; ++k) { const float cur = te[k]; te[k] = __builtin_amdgcn_fmed3f(prev, cur, x); prev = cur; }
+        }
+    }
+    float kth = te[0];
+#pragma unroll
+    for (int k = 1; k < KL; ++k) if (k == keff - 1) kth = te[k];
+    const float emax_a = te[0];
+    // |e~ - e| <= (distance error) / den_min + float32 rounding of e~ itself; generous constants
+    const float rdmax = fmaxf(rdf0, rdf1);
+    const float err = 1.52587890625e-5f * (nsq + ntmax) * rdmax + 4.76837158203125e-7f * fmaxf(fabsf(kth), fabsf(emax_a)) + 1e-30f;
+    const float thr = fminf(kth, emax_a - (float)RP_AFF_WINDOW) - 2.0f * err;
+    const double need_lo = (double)emax_a - RP_AFF_WINDOW - 3.0 * (double)err;
+    // wij entries are staged relative to exp(emax_a) so that a row whose best exponent is -300 still fits float32
+    const double sup = (emax_a > -700.0f) ? exp(-(double)emax_a) : 0.0;
+
+    if (WRITE_WIJ) {   // zero-fill the wave's rows of wij (coalesced); the few non-zero entries are scattered below
+        const int r0 = blockIdx.x * rows_per_block + wave * 32;
+        for (int rr = 0; rr < 32 && r0 + rr < ns; ++rr) {
+            float* row = wij + ((size_t)b * kp.ns_max + r0 + rr) * kp.nt_max;
+            for (int j = lane; j < nt; j += 64) row[j] = 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ---- pass 2: candidates onto the lane's stack
+    int cnt = 0;
+    for (int t = 0; t < ntiles; t += 2) {
+        float et[2][16];
+        tile_exponents(t * 32, et);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (et[u][r] >= thr) {
+                    const int jc = (t + u) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (jc < nt) {
+                        if (cnt < AG_CAP) stk[cnt * NT + tid] = (unsigned short)jc;
+                        ++cnt;
+                    }
+                }
+            }
+    }
+    const bool over = cnt > AG_CAP;
+    const int ncand = min(cnt, AG_CAP);
+
+    // ---- exact treatment of the candidates: sorted list of the KL best by (e descending, j ascending), norm
+    double le[KL];
+    int lj[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) { le[k] = -INFINITY; lj[k] = INT_MAX; }
+    double sumsq = 0.0;
+    float* wrow = WRITE_WIJ ? wij + si * kp.nt_max : nullptr;
+    for (int c = 0; __ballot(c < ncand); ++c) {
+        if (c < ncand) {
+            const int j = stk[c * NT + tid];
+            // numpy-order float32 squared distance: 8 strided partial sums + fixed tree, packed over feature pairs
+            const rp_v2f* tv = reinterpret_cast<const rp_v2f*>(&ftT[j * AG_LDT]);
+            rp_v2f r8[4];
+#pragma unroll
+            for (int c2 = 0; c2 < 16; ++c2) {
+                const rp_v2f sv = {fs[2 * c2], fs[2 * c2 + 1]};
+                const rp_v2f df = sv - tv[c2];
+                const rp_v2f sq = df * df;
+                if (c2 < 4) r8[c2] = sq; else r8[c2 & 3] = r8[c2 & 3] + sq;
+            }
+            const float d = ((r8[0].x + r8[0].y) + (r8[1].x + r8[1].y)) + ((r8[2].x + r8[2].y) + (r8[3].x + r8[3].y));
+            const bool cls = (wsi * wts[j] == 1.0);
+            const double den = cls ? ac.den[1] : ac.den[0], rd = cls ? ac.rden[1] : ac.rden[0];
+            const double x = (double)d;
+            double q = x * rd;
+            const double rem = __builtin_fma(-q, den, x);
+            q = __builtin_fma(rem, rd, q);
+            double e = -q;
+            int jj = j;
+            if (e >= need_lo) {
+                const double w = exp(e);
+                sumsq += w * w;
+                if (WRITE_WIJ && rowok) wrow[j] = (float)(w * sup);
+            }
+            // insert (e, jj) into the sorted list
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
+                const bool better = (e > le[k]) || (e == le[k] && jj < lj[k]);
+                const double te_ = le[k]; const int tj_ = lj[k];
+                le[k] = better ? e : te_; lj[k] = better ? jj : tj_;
+                e = better ? te_ : e; jj = better ? tj_ : jj;
+            }
+        }
+    }
+    {   // merge the two halves of the row: the partner's list, the partner's share of the norm, the partner's overflow flag
+        double oe[KL]; int oj[KL];
+#pragma unroll
+        for (int k = 0; k < KL; ++k) { oe[k] = rp_shfl_xor_d(le[k], 32); oj[k] = __shfl_xor(lj[k], 32, 64); }
+#pragma unroll
+        for (int kk = 0; kk < KL; ++kk) {
+            double e = oe[kk]; int jj = oj[kk];
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
+                const bool better = (e > le[k]) || (e == le[k] && jj < lj[k]);
+                const double te_ = le[k]; const int tj_ = lj[k];
+                le[k] = better ? e : te_; lj[k] = better ? jj : tj_;
+                e = better ? te_ : e; jj = better ? tj_ : jj;
+            }
+        }
+    }
+    // fixed order: (half 0) + (half 1)
+    const double s_other = rp_shfl_xor_d(sumsq, 32);
+    const double nm = sqrt(h == 0 ? sumsq + s_other : s_other + sumsq);
+    const int partner_over = __shfl_xor((int)over, 32, 64);       // unconditionally: a short-circuited shuffle would read inactive lanes
+    const bool redo = over || partner_over != 0;
+    if (rowok && h == 0) {
+        if (redo) corres_j[si * topK] = RP_AFF_REDO;
+        else {
+#pragma unroll
+            for (int k = 0; k < KL; ++k) {
+                if (k < keff) {
+                    const bool ok = lj[k] >= 0 && lj[k] < nt;
+                    corres_j[si * topK + k] = ok ? lj[k] : 0;
+                    corres_w[si * topK + k] = (ok && nm != 0.0) ? exp(le[k]) / nm : 0.0;
+                }
+            }
+        }
+    }
+    if (WRITE_WIJ && rowok && !redo) {
+        // normalise the staged entries in place (this lane wrote them; make its own stores visible first)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const double scale = (nm != 0.0 && sup != 0.0) ? 1.0 / (sup * nm) : 0.0;
+        for (int c = 0; c < ncand; ++c) {
+            const int j = stk[c * NT + tid];
+            const float v = *(volatile float*)(wrow + j);
+            if (v != 0.f || scale == 0.0) wrow[j] = (float)((double)v * scale);
         }
     }
 }
@@ -1423,6 +1718,41 @@ int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* w
             if (!(ac.den[q] > 1e-290 && ac.den[q] < 1e290) || (bits & 0xfffffffffffffull) == 0xfffffffffffffull) ac.exact_div = 0;
         }
         const int tp = (kp.nt_max + 127) / 128;
+        // small batches: the register kernel (one wave per few rows) has the lower latency; the Gram kernel pays from ~1000 row tiles on
+        const bool use_gram = getenv("RELPOSE_AFFINITY_GRAM") || (!getenv("RELPOSE_AFFINITY_ROWS") && (long long)kp.B * ((kp.ns_max + 31) / 32) >= 1024);
+        if (ac.exact_div && use_gram) {
+            // Gram kernel + (normally idle) exact redo of the rows whose candidate stacks overflowed
+            const int ntp = (kp.nt_max + 63) & ~63;
+            // waves (32-row tiles) per workgroup: 8 when the batch fills the chip anyway, fewer for small batches (the per-workgroup target
+            // staging is then paid more often, but more CUs work)
+            const long long tiles32 = (long long)kp.B * ((kp.ns_max + 31) / 32);
+            const int agw = tiles32 >= 4096 ? AG_WAVES : (tiles32 >= 1024 ? 4 : 2);
+            const size_t lds = (size_t)ntp * AG_LDT * 4 + (size_t)ntp * 8 + (size_t)ntp * 4 + 16 + (size_t)AG_CAP * agw * 64 * 2;
+            dim3 grid((kp.ns_max + agw * 32 - 1) / (agw * 32), kp.B);
+#define RP_GRAM_LAUNCH(W_, KL_)                                                                                                       \
+            {                                                                                                                          \
+                RP_HIP(hipFuncSetAttribute((const void*)affinity_gram_kernel<W_, KL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL((affinity_gram_kernel<W_, KL_>), grid, dim3(agw * 64), lds, s, kp, ac, p.topK, ntp, wij, cj, cw, keff); \
+            }
+            if (wij) { if (p.topK <= 5) RP_GRAM_LAUNCH(true, 5) else RP_GRAM_LAUNCH(true, RP_MAXK) }
+            else { if (p.topK <= 5) RP_GRAM_LAUNCH(false, 5) else RP_GRAM_LAUNCH(false, RP_MAXK) }
+#undef RP_GRAM_LAUNCH
+            RP_CHECK_LAUNCH();
+            const int rpw = 8;
+            dim3 grid2((kp.ns_max + 4 * rpw - 1) / (4 * rpw), kp.B);
+#define RP_FIXUP_LAUNCH(TP_)                                                                                                             \
+            if (wij) hipLaunchKernelGGL((affinity_rows_kernel<TP_, true, true>), grid2, dim3(256), 0, s, kp, ac, p.topK, rpw, wij, cj, cw, keff);   \
+            else hipLaunchKernelGGL((affinity_rows_kernel<TP_, false, true>), grid2, dim3(256), 0, s, kp, ac, p.topK, rpw, wij, cj, cw, keff);
+            switch (tp) {
+                case 1: RP_FIXUP_LAUNCH(1) break;
+                case 2: RP_FIXUP_LAUNCH(2) break;
+                case 3: RP_FIXUP_LAUNCH(3) break;
+                default: RP_FIXUP_LAUNCH(4) break;
+            }
+#undef RP_FIXUP_LAUNCH
+            RP_CHECK_LAUNCH();
+            return 0;
+        }
         if (ac.exact_div) switch (tp) {
             case 1: return launch_affinity_rows<1>(kp, ac, p.topK, wij, cj, cw, keff, s);
             case 2: return launch_affinity_rows<2>(kp, ac, p.topK, wij, cj, cw, keff, s);

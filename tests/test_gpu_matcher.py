@@ -43,13 +43,20 @@ def _params(gm, ds, row, method="irls+sm"):
 
 
 @pytest.mark.parametrize("ci", range(len(MATCH_CASES)))
-def test_matcher_stages_vs_oracle(gm, dev, ci):
+@pytest.mark.parametrize("aff_kernel", ["rows", "gram"])
+def test_matcher_stages_vs_oracle(gm, dev, ci, aff_kernel):
+    """aff_kernel: the register-resident affinity kernel (small batches) / the Gram (MFMA candidate) kernel (large batches), forced."""
     from relativepose_amd import rpmodule
     N, Nt, seed, ds, row, inl = MATCH_CASES[ci]
     S, T, _ = synth.make_match_case(N, seed, inlier=inl, Nt=Nt)
     para, p = _params(gm, ds, row)
     pose_o, d = _oracle(S, T, p)
-    res = rpmodule.match_pairs(*rpmodule.pack_keypoints([(S, T)], dev), para, debug=True, want_wij=True)
+    key = {"rows": "RELPOSE_AFFINITY_ROWS", "gram": "RELPOSE_AFFINITY_GRAM"}[aff_kernel]
+    os.environ[key] = "1"
+    try:
+        res = rpmodule.match_pairs(*rpmodule.pack_keypoints([(S, T)], dev), para, debug=True, want_wij=True)
+    finally:
+        del os.environ[key]
     status = int(res.status[0].item())
     assert status == d["status"], (status, d["status"])
     pose_g = res.pose[0].cpu().numpy()
