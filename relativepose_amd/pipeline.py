@@ -116,7 +116,9 @@ class RelativePosePipeline:
     def _ensure_net_stream(self):
         # created BEFORE the per-batch streams: on this runtime the tiny kernels of a later-created stream are
         # dispatched promptly next to an earlier-created stream's big grids, but not the other way round
-        # (measured: matcher phase 16 ms vs 29 ms under a concurrent forward, profiles/r01_overlap.txt)
+        # (measured: matcher phase 16 ms vs 29 ms under a concurrent forward, profiles/r01_overlap.txt).  Round-2 experiments on the
+        # scheduling of this stream, both worse: high stream priority (the matcher starves and becomes critical: 394 -> 365-377
+        # pairs/s) and two SCNet streams whose forwards may overlap (394 -> 358-360: the two working sets fight over L2)
         import torch
         if self._net_stream is None:
             # RELPOSE_NET_PRIO: HIP stream priority of the SCNet stream (experiment; -1 = high: conv workgroups are dispatched
