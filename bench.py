@@ -256,6 +256,7 @@ def worker(args):
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
+        D.barrier(world)                 # rank 0 is still taking its roofline side measurements: leave the group together
         dist.destroy_process_group()
 
 

@@ -106,7 +106,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, s
 // latency hides under 64 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false, int SPLIT = 0>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLDS ? 3 : 2)) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
+__global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI == 1) ? 4 : (SSLDS ? 3 : 2))) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
     // ninner == 4 (the sub-pixel phases of one transposed conv, which gather from the SAME input tile):
@@ -207,8 +207,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
 
     int r_base[A_IT], r_mg[UNI ? (A_IT + 1) / 2 : A_IT];     // UNI: no group field, two 16-bit tap masks per register
     float4 ra[A_IT], q0[SSLDS ? 1 : A_IT], q1[SSLDS ? 1 : A_IT];
-    float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
-    static_assert(B_IT <= 4 && (B_IT <= 2 || BN % RPI == 0), "B loader layout");
+    float4 rb[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(B_IT <= 8 && (B_IT <= 2 || BN % RPI == 0), "B loader layout");
     int okm = 0, cst = 0;
     const float slope = d.src[0].slope;                 // both sources of a skip concatenation use LeakyReLU(0.1)
     const int kt_begin = ks * d.kt_per;
@@ -256,10 +258,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
             qu0 = rp_ldg4(q); qu1 = rp_ldg4(q + 4);                                                               \
         }                                                                                                         \
         const int kof_ = tap * d.Cin + c0;                                                                        \
-        rb0 = rp_ldg4(b_src[0] + kof_);                                                                           \
-        if (B_IT > 1) rb1 = rp_ldg4(b_src[B_IT > 1 ? 1 : 0] + kof_);                                                \
-        if (B_IT > 2) rb2 = rp_ldg4(b_src[B_IT > 2 ? 2 : 0] + kof_);                                                \
-        if (B_IT > 3) rb3 = rp_ldg4(b_src[B_IT > 3 ? 3 : 0] + kof_);                                                \
+        _Pragma("unroll") for (int it = 0; it < B_IT; ++it) rb[it] = rp_ldg4(b_src[it] + kof_);                    \
         if (d.tap_inner) { ++tap; if (tap == d.ntaps) { tap = 0; c0 += BK; } }                                    \
         else { c0 += BK; if (c0 == d.Cin) { c0 = 0; ++tap; } }                                                    \
     }
@@ -302,10 +301,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 8 || MI == 1) ? 4 : (SSLD
                 ar_[kq] = hi_; ar_[8 + kq] = lo_;                                                                 \
             }                                                                                                     \
         }                                                                                                         \
-        if (BN >= RPI || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb0;              \
-        if (B_IT > 1) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + RPI) * LDK + kq * 4]) = rb1;                     \
-        if (B_IT > 2) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + 2 * RPI) * LDK + kq * 4]) = rb2;                 \
-        if (B_IT > 3) *reinterpret_cast<float4*>(&Bs[BUF][(lrow + 3 * RPI) * LDK + kq * 4]) = rb3;                 \
+        if (BN >= RPI || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb[0];            \
+        _Pragma("unroll") for (int it = 1; it < B_IT; ++it)                                                       \
+            *reinterpret_cast<float4*>(&Bs[BUF][(lrow + it * RPI) * LDK + kq * 4]) = rb[it];                        \
     }
 
     // UNI (chosen by the host when the rows of a BatchNorm group are a multiple of BM, i.e. no tile of the
@@ -1323,6 +1321,9 @@ void Builder::end_group() {
     // (3 measured within 1 % of 0 on conv3/conv4/deconv4-6 but needs twice the split-K: off unless RELPOSE_8WAVE is set)
     static const bool tile128 = getenv("RELPOSE_TILE128") != nullptr;      // experiment: 128-row tiles, 4 workgroups per CU
     int cfg = cp >= 128 ? ((big_m >= 8192 && getenv("RELPOSE_8WAVE")) ? 3 : 0) : (cp == 64 ? (tile128 ? 4 : 1) : (tile128 ? 5 : 2));
+    // 6 = 128 x 256 tiles (2 x 2 waves of 64 x 128: 8 accumulators per wave, 2 workgroups per CU) for Cout >= 256 (RELPOSE_TILE256N)
+    static const bool tile256n = getenv("RELPOSE_TILE256N") != nullptr;
+    if (tile256n && cp >= 256 && cp % 256 == 0) cfg = 6;
     {   // 256-row tiles that would straddle BatchNorm groups where 128-row tiles would not: take the 128-row variant
         // (same throughput per tile shape, but it gets the uniform-group loader)
         static const bool no_auto128 = getenv("RELPOSE_NO_AUTO128") != nullptr;
@@ -1333,7 +1334,7 @@ void Builder::end_group() {
         }
         if (!no_auto128 && !u256 && u128 && (cfg == 1 || cfg == 2)) cfg = cfg == 1 ? 4 : 5;
     }
-    const int BMt = (cfg == 0 || cfg >= 4) ? 128 : 256, BNt = (cfg == 0 || cfg == 3) ? 128 : cp;
+    const int BMt = (cfg == 0 || cfg >= 4) ? 128 : 256, BNt = cfg == 6 ? 256 : ((cfg == 0 || cfg == 3) ? 128 : cp);
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
     for (int i = first; i < first + count; ++i) {
@@ -1393,7 +1394,7 @@ void Builder::end_group() {
         const ConvDesc& d = plan->descs[i];
         const int hw = d.Hp * d.Wp;
         const int ng = (BMt - 1) / (2 * hw) + 2;
-        if ((long)ng * d.Cin > ((cfg == 0 || cfg == 3) ? 2048 : 512) || d.src[0].sstride == 0) o.sslds = 0;
+        if ((long)ng * d.Cin > ((cfg == 0 || cfg == 3 || cfg == 6) ? 2048 : 512) || d.src[0].sstride == 0) o.sslds = 0;
         if ((2 * hw) % BMt) o.uni = 0;             // some tile would straddle two BatchNorm groups
     }
     if (!o.sslds) o.uni = 0;
@@ -1695,6 +1696,7 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             else if (op.cfg == 1) RP_LAUNCH_T(4, 1, 2, 2);
             else if (op.cfg == 2) RP_LAUNCH_T(4, 1, 2, 1);
             else if (op.cfg == 4) RP_LAUNCH_T(4, 1, 1, 2);
+            else if (op.cfg == 6) RP_LAUNCH_T(2, 2, 2, 4);
             else RP_LAUNCH_T(4, 1, 1, 1);
 #undef RP_LAUNCH_T
 #undef RP_LAUNCH_V
