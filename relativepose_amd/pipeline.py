@@ -33,6 +33,7 @@ class RelativePosePipeline:
             sigmas = [[o.sigmaAngle1, o.sigmaAngle2, o.sigmaDist, o.sigmaFeat]] * alter_steps
         self.sigmas = np.asarray(sigmas, dtype=np.float64).reshape(-1, 4)
         self.feat_off = 7 + net.snumclass
+        self._slot_streams = []
 
     def prepare(self, rgb, norm, depth, pts, ptw, device, keep_host=False):
         """Host arrays (dataset dict layout: rgb/norm [B,2,3,h,4h], depth [B,2,h,4h] f32; pts [B,2,N,2],
@@ -144,16 +145,28 @@ class RelativePosePipeline:
         depth = nst if depth is None else max(1, min(depth, nst))
         self._chain_nets = depth > 1
         self._ensure_net_stream()
+        # One HIP stream per IN-FLIGHT SLOT, not per prepared batch: the runtime multiplexes streams onto 4 hardware queues, and with
+        # net + default + 4 batch streams two batch streams share a queue -- the input preparation of a new batch then sits behind
+        # the other batch's last matcher (which waits for ITS forward) in that queue, and the SCNet stream idles for a matcher
+        # (4.5 ms per 2 batches, profiles/r02_overlap.txt).  net + default + 2 slots = 4 streams = 4 queues; a new batch is
+        # ordered behind the finished batch of its own slot, whose matcher ran under the other slot's forward long before.
+        while len(self._slot_streams) < depth:
+            self._slot_streams.append(torch.cuda.Stream())
+        for ss in self._slot_streams[:depth]:
+            ss.wait_stream(cur)
         for st in states:
-            if "stream" not in st:
-                st["stream"] = torch.cuda.Stream()
-            st["stream"].wait_stream(cur)
+            if "stream" in st:
+                st["stream"].wait_stream(cur)
         results = [None] * steps
         live, nxt = {}, 0
         while nxt < steps or live:
             for slot in range(depth):
                 if slot not in live and nxt < steps:
                     st = states[nxt % nst]
+                    ss = self._slot_streams[slot]
+                    if st.get("stream") is not None and st["stream"] is not ss:
+                        ss.wait_stream(st["stream"])         # the buffers' previous use (another slot / run_interleaved)
+                    st["stream"] = ss
                     if before_batch is not None:
                         with torch.cuda.stream(st["stream"]):
                             before_batch(nxt, st)
@@ -178,7 +191,8 @@ class RelativePosePipeline:
                     else:
                         results[k] = (pose, status)
         for st in states:
-            cur.wait_stream(st["stream"])
+            if "stream" in st:
+                cur.wait_stream(st["stream"])
         cur.wait_stream(self._net_stream)
         self._chain_nets = False
         return results
