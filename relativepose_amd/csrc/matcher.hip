@@ -58,6 +58,7 @@ struct Graph {                 // per-batch device arrays of the pair-compatibil
     // lives in slot s % 64 of wave-slice s / 64, edge k % 32 of it at ((s >> 6) << 11) + ((k & 31) << 6) + (s & 63): the 64
     // lanes of a wave, each walking its own segment, read 64 consecutive entries per step (SELL-64 over segments).
     int32_t seg_layout;
+    int32_t sym;               // 1: bitmap holds the full symmetric adjacency (pair_tile_kernel); 0: upper triangle + upcnt / lowcnt (legacy)
     int32_t seg_cap;           // segments per pair the edge arrays are sized for (multiple of 64)
     int64_t estride;           // entries of col / wv / xe per pair
     int32_t* segptr;           // [B, Cmax+1] first segment of every row
@@ -695,7 +696,17 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Gr
     __syncthreads();
     for (int base = 0; base < C; base += 1024) {
         const int c = base + threadIdx.x;
-        int v = (c < C) ? g.upcnt[(size_t)b * g.Cmax + c] + g.lowcnt[(size_t)b * g.Cmax + c] : 0;
+        int v = 0;
+        if (c < C) {
+            if (g.sym) {         // degree = set bits of the row; kept in upcnt for the segment pass below
+                const unsigned long long* row = g.bitmap + ((size_t)b * g.Cmax + c) * g.Wmax;
+                const int nw = (C + 63) >> 6;
+                for (int w = 0; w < nw; ++w) v += __popcll(row[w]);
+                g.upcnt[(size_t)b * g.Cmax + c] = v;
+            } else {
+                v = g.upcnt[(size_t)b * g.Cmax + c] + g.lowcnt[(size_t)b * g.Cmax + c];
+            }
+        }
         int inc = v;
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) { int t = __shfl_up(inc, m, 64); if (lane >= m) inc += t; }
@@ -717,7 +728,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Gr
         __syncthreads();
         for (int base = 0; base < C; base += 1024) {
             const int c = base + threadIdx.x;
-            const int deg = (c < C) ? g.upcnt[(size_t)b * g.Cmax + c] + g.lowcnt[(size_t)b * g.Cmax + c] : 0;
+            const int deg = (c < C) ? (g.sym ? g.upcnt[(size_t)b * g.Cmax + c] : g.upcnt[(size_t)b * g.Cmax + c] + g.lowcnt[(size_t)b * g.Cmax + c]) : 0;
             const int v = (deg + RP_SEG - 1) / RP_SEG;
             int inc = v;
 #pragma unroll
@@ -814,6 +825,167 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Gra
         run += __popcll(word);
         nz += __popcll(__ballot(bit && w != 0.0));
     }
+    if (lane == 0 && nz) atomicAdd(&g.counters[b * 4 + 2], nz);
+}
+
+// ---- tiled pair consistency (rpmodule.py:381-451) ------------------------------------------------------------------
+// One workgroup = one 64 x 64 tile (rows tr*64.., columns tc*64.., tr <= tc) of the C x C pair matrix of one scan pair.
+//   1. the 64 + 64 correspondences of the tile are gathered to LDS once (the row-per-wave kernel gathered per pair);
+//   2. every thread SCREENS 16 pairs with the distance test only (two sqrt) and the survivors (a few %) are
+//      compacted into an LDS queue -- the row-per-wave kernel ran the six acos of the angle test on every wave that held one
+//      survivor, i.e. at 3-5 % lane efficiency;
+//   3. the queue is evaluated densely (rp_pair_eval, identical arithmetic), passing pairs set a bit in the tile's row
+//      words AND in its transposed column words (LDS atomics);
+//   4. the tile stores word tc of its rows and word tr of its columns: the bitmap is the full symmetric adjacency
+//      matrix, every (row, word) slot written exactly once (no memset, no global atomics per edge), and the fill
+//      kernel reads a row's neighbours from ONE contiguous run of words instead of a strided column walk.
+__global__ __launch_bounds__(256) void pair_tile_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK) {
+    __shared__ double geo[2][64][12];                  // [rows | columns][slot][ps, ns, pt, nt]
+    __shared__ unsigned long long bm[2][64];           // row words, transposed (column) words
+    __shared__ unsigned short queue[4096];
+    __shared__ int qn;
+    const int b = blockIdx.y;
+    const int C = pair_C(kp, g, b);
+    const int T = g.Wmax;
+    int tr = 0, t = blockIdx.x;
+    while (t >= T - tr) { t -= T - tr; ++tr; }
+    const int tc = tr + t;
+    if (tc * 64 >= C) return;                           // (tr <= tc: the row tile is inside as well)
+    const int keff = g.keff[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // gather: thread = (rows | columns, slot, source | target side)
+        const int which = tid >> 7, slot = (tid >> 1) & 63, side = tid & 1;
+        const int c = (which ? tc : tr) * 64 + slot;
+        double* o = &geo[which][slot][side * 6];
+        if (c < C) {
+            const int i = c / keff, kk = c - i * keff;
+            const size_t si = (size_t)b * kp.ns_max + i;
+            if (side == 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { o[a] = kp.pc_s[si * 3 + a]; o[3 + a] = kp.normal_s[si * 3 + a]; }
+            } else {
+                const size_t ti = (size_t)b * kp.nt_max + g.corres_j[si * topK + kk];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { o[a] = kp.pc_t[ti * 3 + a]; o[3 + a] = kp.normal_t[ti * 3 + a]; }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) o[a] = 0.0;
+        }
+        if (tid < 128) bm[tid >> 6][tid & 63] = 0ull;
+        if (tid == 0) qn = 0;
+    }
+    __syncthreads();
+    {   // screen: this thread's column against 16 rows (the row operands are LDS broadcasts)
+        const int c = tc * 64 + lane;
+        const double cps[3] = {geo[1][lane][0], geo[1][lane][1], geo[1][lane][2]};
+        const double cpt[3] = {geo[1][lane][6], geo[1][lane][7], geo[1][lane][8]};
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int rl = wave * 16 + i;
+            const int r = tr * 64 + rl;
+            bool pd = false;
+            if (c > r && c < C) {
+                double es[3], et[3], ds, dt, d;
+                pd = rp_pair_dist(&geo[0][rl][0], &geo[0][rl][6], cps, cpt, kc, es, et, ds, dt, d);
+            }
+            const unsigned long long m = __ballot(pd);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&qn, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (pd) queue[base + __popcll(m & lt)] = (unsigned short)((rl << 6) | lane);
+            }
+        }
+    }
+    __syncthreads();
+    const int n = qn;
+    for (int q = tid; q < n; q += 256) {
+        const int e = queue[q], rl = e >> 6, cl = e & 63;
+        const double* a = geo[0][rl];
+        const double* o = geo[1][cl];
+        const RpPairEval ev = rp_pair_eval(a, a + 3, a + 6, a + 9, o, o + 3, o + 6, o + 9, kc);
+        if (ev.pass_all) {
+            atomicOr(&bm[0][rl], 1ull << cl);
+            atomicOr(&bm[1][cl], 1ull << rl);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int r = tr * 64 + tid;
+        unsigned long long w = bm[0][tid];
+        const int up = __popcll(w);
+        if (tr == tc) w |= bm[1][tid];
+        if (r < C) g.bitmap[((size_t)b * g.Cmax + r) * g.Wmax + tc] = w;
+        const int m = rp_wave_sum_i(up);
+        if (tid == 0) {
+            if (n) atomicAdd(&g.counters[b * 4 + 0], n);
+            if (m) atomicAdd(&g.counters[b * 4 + 1], m);
+        }
+    } else if (tid < 128 && tr != tc) {
+        const int c = tc * 64 + (tid - 64);
+        if (c < C) g.bitmap[((size_t)b * g.Cmax + c) * g.Wmax + tr] = bm[1][tid - 64];
+    }
+}
+
+// Edge list of one row per wave from the symmetric bitmap: the row's set bits are expanded into an LDS list (ascending
+// column = the reference's order: lower neighbours, then upper), then the edges are evaluated DENSELY, 64 per step.
+__global__ __launch_bounds__(256) void pair_fill_rows_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK,
+                                                              const int32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short fill_lists[];      // [4 waves][Cmax]
+    const int b = blockIdx.y;
+    if (status[b] != RELPOSE_OK) return;
+    const int C = pair_C(kp, g, b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    unsigned short* list = fill_lists + (size_t)wave * g.Cmax;
+    const int keff = g.keff[b];
+    const unsigned long long* row = g.bitmap + ((size_t)b * g.Cmax + c) * g.Wmax;
+    const int nw = (C + 63) >> 6;
+    int deg = 0;
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        unsigned long long word = (w0 + lane < nw) ? row[w0 + lane] : 0ull;
+        const int pc = __popcll(word);
+        int inc = pc;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { const int t = __shfl_up(inc, m, 64); if (lane >= m) inc += t; }
+        int off = deg + inc - pc;
+        while (word) {
+            list[off++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(word));
+            word &= word - 1;
+        }
+        deg += __shfl(inc, 63, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (deg == 0) return;
+    Corr me;
+    load_corr(kp, g, b, topK, keff, c, me);
+    const size_t eoff = (size_t)b * g.estride;
+    const int row_start = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
+    const int seg0 = g.seg_layout ? g.segptr[(size_t)b * (g.Cmax + 1) + c] : 0;
+    int nz = 0;
+    for (int k = lane; k < deg; k += 64) {
+        const int x = list[k];
+        Corr o;
+        load_corr(kp, g, b, topK, keff, x, o);
+        double w;
+        if (x < c) {             // canonical orientation: "1" = the smaller index
+            const RpPairEval ev = rp_pair_eval(o.ps, o.ns, o.pt, o.nt, me.ps, me.ns, me.pt, me.nt, kc);
+            w = rp_pair_weight(ev, o.f, me.f, o.ws, me.ws, o.wt, me.wt, kc);
+        } else {
+            const RpPairEval ev = rp_pair_eval(me.ps, me.ns, me.pt, me.nt, o.ps, o.ns, o.pt, o.nt, kc);
+            w = rp_pair_weight(ev, me.f, o.f, me.ws, o.ws, me.wt, o.wt, kc);
+        }
+        const size_t pos = g.seg_layout ? seg_edge_index(seg0 + (k >> 5), k) : (size_t)(row_start + k);
+        g.col[eoff + pos] = x;
+        g.wv[eoff + pos] = w;
+        nz += (w != 0.0) ? 1 : 0;
+    }
+    nz = rp_wave_sum_i(nz);
     if (lane == 0 && nz) atomicAdd(&g.counters[b * 4 + 2], nz);
 }
 
@@ -1868,16 +2040,22 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     g.seg_layout = fit1_ok(L.Cmax) ? 1 : 0;
     g.seg_cap = L.seg_cap; g.estride = L.estride;
     g.segptr = (int32_t*)(ws + L.segptr); g.segrow = (int32_t*)(ws + L.segrow); g.part = (double*)(ws + L.part);
-    RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
+    // tiled pair kernels (symmetric bitmap); RELPOSE_LEGACY_PAIRS = the row-per-wave kernels of round 1 (upper-triangle bitmap).
+    // The fill kernel's row lists are uint16: C <= 65536; its LDS need is 8 * Cmax bytes.
+    g.sym = (!getenv("RELPOSE_LEGACY_PAIRS") && L.Cmax <= 8192) ? 1 : 0;
+    if (g.sym) RP_HIP(hipMemsetAsync(ws + L.counters, 0, (size_t)kp->B * 16, s));
+    else RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
     int rc = launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
     if (rc) return rc;
     const RpPairConsts kc = make_consts(*p);
     dim3 grid_rows((L.Cmax + 3) / 4, kp->B);
-    hipLaunchKernelGGL(pair_flags_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK);
+    if (g.sym) hipLaunchKernelGGL(pair_tile_kernel, dim3((unsigned)(L.Wmax * (L.Wmax + 1) / 2), kp->B), dim3(256), 0, s, *kp, g, kc, p->topK);
+    else hipLaunchKernelGGL(pair_flags_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK);
     RP_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_scan_kernel, dim3(kp->B), dim3(1024), 0, s, *kp, g, status);
     RP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pair_fill_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK, status);
+    if (g.sym) hipLaunchKernelGGL(pair_fill_rows_kernel, grid_rows, dim3(256), (size_t)4 * L.Cmax * sizeof(unsigned short), s, *kp, g, kc, p->topK, status);
+    else hipLaunchKernelGGL(pair_fill_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK, status);
     RP_CHECK_LAUNCH();
     // ---- fit: launch sequence (see fit_begin_kernel)
     FitState fs;

@@ -35,18 +35,26 @@ struct RpPairEval { double d, alpha, beta, gamma; int pass_dist, pass_all; };
 
 // One correspondence pair: "1" = (ps1,ns1 -> pt1,nt1), "2" = (ps2,ns2 -> pt2,nt2).
 // rpmodule.py:399-404 (distance test) and :424-436 (angle test).
+// The distance test alone (rpmodule.py:399-404): edge vectors, their lengths, d = (|es| - |et|)^2.  rp_pair_eval starts with
+// exactly this, so a kernel that screens pairs with rp_pair_dist and evaluates the survivors with rp_pair_eval sees the same bits.
+RP_HD bool rp_pair_dist(const double* ps1, const double* pt1, const double* ps2, const double* pt2, const RpPairConsts& k,
+                        double* es, double* et, double& dis_s, double& dis_t, double& d) {
+    es[0] = ps1[0] - ps2[0]; es[1] = ps1[1] - ps2[1]; es[2] = ps1[2] - ps2[2];
+    et[0] = pt1[0] - pt2[0]; et[1] = pt1[1] - pt2[1]; et[2] = pt1[2] - pt2[2];
+    dis_s = rp_norm3(es[0], es[1], es[2]);
+    dis_t = rp_norm3(et[0], et[1], et[2]);
+    const double dd = dis_s - dis_t;
+    d = dd * dd;
+    const double mn = dis_s < dis_t ? dis_s : dis_t;     // np.minimum (NaN-propagation irrelevant: compare below is false)
+    return (d < k.dist_thre2) && (mn > k.sep_thre);
+}
+
 RP_HD RpPairEval rp_pair_eval(const double* ps1, const double* ns1, const double* pt1, const double* nt1,
                               const double* ps2, const double* ns2, const double* pt2, const double* nt2,
                               const RpPairConsts& k) {
     RpPairEval r;
-    double es[3] = {ps1[0] - ps2[0], ps1[1] - ps2[1], ps1[2] - ps2[2]};
-    double et[3] = {pt1[0] - pt2[0], pt1[1] - pt2[1], pt1[2] - pt2[2]};
-    double dis_s = rp_norm3(es[0], es[1], es[2]);
-    double dis_t = rp_norm3(et[0], et[1], et[2]);
-    double dd = dis_s - dis_t;
-    r.d = dd * dd;
-    double mn = dis_s < dis_t ? dis_s : dis_t;     // np.minimum (NaN-propagation irrelevant: compare below is false)
-    r.pass_dist = (r.d < k.dist_thre2) && (mn > k.sep_thre);
+    double es[3], et[3], dis_s, dis_t;
+    r.pass_dist = rp_pair_dist(ps1, pt1, ps2, pt2, k, es, et, dis_s, dis_t, r.d);
     r.alpha = r.beta = r.gamma = 0.0;
     r.pass_all = 0;
     if (!r.pass_dist) return r;

@@ -28,8 +28,8 @@ args = (k["pc"][:, 0].contiguous(), k["nn"][:, 0].contiguous(), k["ft"][:, 0].co
         k["pc"][:, 1].contiguous(), k["nn"][:, 1].contiguous(), k["ft"][:, 1].contiguous(), st["w_t"], st["ns"], st["nt"])
 para = rpmodule.opts(*sig[0])
 out = {}
-for name, env in (("single-workgroup Lanczos fit (default)", {}), ("round-1 launch-sequence fit", {"RELPOSE_LEGACY_FIT": "1", "RELPOSE_LEGACY_AFFINITY": "1"})):
-    for kk in ("RELPOSE_LEGACY_FIT", "RELPOSE_LEGACY_AFFINITY"):
+for name, env in (("single-workgroup Lanczos fit (default)", {}), ("default fit, row-per-wave pair kernels", {"RELPOSE_LEGACY_PAIRS": "1"}), ("round-1 launch-sequence fit", {"RELPOSE_LEGACY_FIT": "1", "RELPOSE_LEGACY_AFFINITY": "1"})):
+    for kk in ("RELPOSE_LEGACY_FIT", "RELPOSE_LEGACY_AFFINITY", "RELPOSE_LEGACY_PAIRS"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     res = rpmodule.match_pairs(*args, para, debug=True, max_edges=pipe.max_edges)
@@ -47,7 +47,8 @@ for name, env in (("single-workgroup Lanczos fit (default)", {}), ("round-1 laun
     out[name] = res.pose.cpu().numpy()
     print(f"{name}: {ms:.3f} ms per relpose_match_pairs (B={B}, N={N}, {ds}); status {np.bincount(res.status.cpu().numpy(), minlength=7).tolist()}; "
           f"edges/pair mean {2 * c[:, 1].mean():.0f} max {2 * c[:, 1].max()}; matrix-vector products per round mean {it.mean(0).round(1).tolist()} max {it.max(0).tolist()}")
-a, b = list(out.values())
+a, b = list(out.values())[0], list(out.values())[-1]
+print('tiled vs row-per-wave pair kernels: poses bit-equal =', np.array_equal(list(out.values())[0], list(out.values())[1]))
 print("rotation difference between the two fits (Frobenius): max %.3e median %.3e" % (np.linalg.norm((a - b)[:, :3, :3], axis=(1, 2)).max(),
       np.median(np.linalg.norm((a - b)[:, :3, :3], axis=(1, 2)))))
 # which fit is right where they differ most?  the CPU oracle (scipy ARPACK like the reference) on that pair
