@@ -665,6 +665,94 @@ __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __res
     }
 }
 
+// ---- conv1 on the matrix pipe ---------------------------------------------------------------------------------
+// Same six 3x3 convs as conv1_direct_kernel, as per-block GEMMs M = pixels, N = 32, K = 9 taps x 4 (2 for depth) channels
+// on v_mfma_f32_32x32x2_f32.  One workgroup = an 8 x 32 pixel tile of one image: the 10 x 34 halo tile of the 16-channel
+// input is staged in LDS once (pixel stride 17 floats: the A fragments of 32 neighbouring pixels hit 32 different banks), the
+// weights of all six blocks as well; wave w owns tile rows 2w, 2w+1 (two 32-pixel M tiles sharing every B fragment).
+// k = tap * 4 + c4 (depth: tap * 2 + c2): at MFMA step kk lanes 0-31 supply k = 2kk, lanes 32-63 k = 2kk + 1.
+// C layout: lane holds output channel lane & 31 of 16 pixels -> every store instruction writes two full 128-byte lines of
+// A1 and the BatchNorm sums need no transposition (the direct kernel went through LDS for both).  The VALU kernel ran
+// 34 TFLOP/s on 44 GFLOP (1.08 ms); here the MFMA time is ~0.25 ms and the 2.47 GB of A1 stores are the bound.
+// One {sum, sum of squares} record per tile and channel: stat[group][(img & 1) * 196 + tile][192][2] (C1_PASSES_PER_GROUP).
+constexpr int C1T_PS = 17;                          // LDS pixel stride (floats)
+constexpr int C1T_XIN = 10 * 34 * C1T_PS;
+__global__ __launch_bounds__(256, 3) void conv1_mfma_kernel(const float* __restrict__ x0, const float* __restrict__ w1,
+                                                          float* __restrict__ a1, double* __restrict__ stat, int n) {
+    __shared__ __attribute__((aligned(16))) float wl[6 * 9 * 4 * 32];
+    __shared__ __attribute__((aligned(16))) float xin[C1T_XIN];      // later reused for the per-wave statistics [4][192][2] f64
+    static_assert(C1T_XIN * 4 >= 4 * 192 * 2 * 8, "statistics scratch aliases the input tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x % 196, img = blockIdx.x / 196;
+    const int ty0 = (tile / 7) * 8, tx0 = (tile % 7) * 32;
+    for (int i = tid; i < 6 * 9 * 4 * 32 / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(w1)[i];
+    for (int i = tid; i < 340 * 4; i += 256) {
+        const int p = i >> 2, q4 = i & 3;
+        const int py = p / 34, px = p - py * 34;
+        const int iy = ty0 + py - 1, ix = tx0 + px - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                  // zero padding
+        if (iy >= 0 && iy < RS && ix >= 0 && ix < RS) v = *reinterpret_cast<const float4*>(x0 + (((size_t)img * RS + iy) * RS + ix) * 16 + q4 * 4);
+        float* d = &xin[p * C1T_PS + q4 * 4];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int pb = ((2 * wave) * 34 + l31) * C1T_PS;                 // tile row 2w, column l31, tap (0, 0), channel 0
+    double st_s[6], st_q[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int m = q >> 1, sft = (q & 1) * 8;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const int nk = (m == 2) ? 9 : 18;
+#pragma unroll
+        for (int kk = 0; kk < nk; ++kk) {
+            // (tap, in-block channel) of k = 2kk (lanes 0-31) and k = 2kk + 1 (lanes 32-63); input channel: rgb {0,1,2,7}, n {3,4,5,7}, d {6,7}
+            const int tap = (m == 2) ? kk : (kk >> 1);
+            const int c40 = (m == 2) ? 0 : 2 * (kk & 1), c41 = c40 + 1;
+            const int ch0 = (m == 2) ? 6 : (c40 == 3 ? 7 : m * 3 + c40);
+            const int ch1 = (m == 2) ? 7 : (c41 == 3 ? 7 : m * 3 + c41);
+            const int tyy = tap / 3, txx = tap - tyy * 3;
+            const int off = (tyy * 34 + txx) * C1T_PS + sft;
+            const int idx = pb + off + (h ? ch1 : ch0);
+            const float a0 = xin[idx];
+            const float a1v = xin[idx + 34 * C1T_PS];
+            const float bv = wl[((q * 9 + tap) * 4 + (h ? c41 : c40)) * 32 + l31];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, bv, acc1, 0, 0, 0);
+        }
+        // store: register r = pixel column (r & 3) + 8 (r >> 2) + 4 h of the M tile, output channel l31
+        double ssum = 0.0, ssq = 0.0;
+        float* o0 = a1 + ((((size_t)img * RS + ty0 + 2 * wave) * RS + tx0 + 4 * h) * 192 + q * 32 + l31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = (r & 3) + 8 * (r >> 2);
+            o0[(size_t)px * 192] = acc0[r];
+            o0[((size_t)RS + px) * 192] = acc1[r];
+            const double v0 = (double)acc0[r], v1 = (double)acc1[r];
+            ssum += v0; ssq += v0 * v0;
+            ssum += v1; ssq += v1 * v1;
+        }
+        st_s[q] = ssum + rp_shfl_xor_d(ssum, 32);
+        st_q[q] = ssq + rp_shfl_xor_d(ssq, 32);
+    }
+    __syncthreads();                                                   // every wave is done with the input tile
+    double* wst = reinterpret_cast<double*>(xin);
+    if (h == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { wst[(wave * 192 + q * 32 + l31) * 2] = st_s[q]; wst[(wave * 192 + q * 32 + l31) * 2 + 1] = st_q[q]; }
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const double ssum = ((wst[tid * 2] + wst[(192 + tid) * 2]) + wst[(384 + tid) * 2]) + wst[(576 + tid) * 2];
+        const double ssq = ((wst[tid * 2 + 1] + wst[(192 + tid) * 2 + 1]) + wst[(384 + tid) * 2 + 1]) + wst[(576 + tid) * 2 + 1];
+        const size_t pass = (size_t)(img >> 1) * C1_PASSES_PER_GROUP + (size_t)(img & 1) * 196 + tile;
+        double* o = stat + (pass * 192 + tid) * 2;
+        o[0] = ssum; o[1] = ssq;
+    }
+}
+
 // ---- the five 1x1 heads deconv1{rgb,n,d,s,f} (mymodel.py:188,196,204,220,228 / :312-376) in one pass ---------
 // HBM-bound: every pixel reads its 224 D2 channels (+ the 3x32 skip channels of A1) exactly once, applies
 // BatchNorm + LeakyReLU, and feeds the five small matrix-vector products (3+3+1+S+32 outputs, 64 inputs each).
@@ -1703,8 +1791,13 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             mark(-1);
         } else if (op.type == OP_CONV1) {
             mark(1);
-            hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
-                               act + net->bufs["A1"].off * n, partial, n);
+            static const bool c1_direct = getenv("RELPOSE_CONV1_DIRECT") != nullptr;      // the round-1 VALU kernel (A/B switch)
+            if (c1_direct)
+                hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
+                                   act + net->bufs["A1"].off * n, partial, n);
+            else
+                hipLaunchKernelGGL(conv1_mfma_kernel, dim3(196 * n), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
+                                   act + net->bufs["A1"].off * n, partial, n);
             mark(-1);
         } else if (op.type == OP_STATS_FUSED) {
             const Buf& B = net->bufs[op.buf];
