@@ -96,9 +96,17 @@ struct ConvDesc {
     float* partial;        // [ksplit][M][CoutPad] partial sums when ksplit > 1
     double* stat_part;     // [mtiles][2 group slots][CoutPad][2] per-tile BatchNorm partial sums (or null)
     int cout_pad;
+    int stat_bm;           // rows per tile of the kernel that writes stat_part (bn_finalize_fused_kernel walks the records with it)
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, slope * v); }   // slope in (0,1]
+
+// buffer_load_dwordx4 v, voff, s[rsrc], soff offen: 128-bit SGPR descriptor, 32-bit lane byte offset, SGPR byte offset
+typedef float rp_f32x4g __attribute__((__vector_size__(16)));
+__device__ __forceinline__ float4 rp_bufld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const rp_f32x4g f = (rp_f32x4g)__builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
 
 // Tile: WM x WN waves (WM*WN = 4), each wave MI x NI MFMA 32x32 blocks.
 // Both tiles are register-staged: the global loads of tile kt+1 (A values, their BatchNorm
@@ -523,6 +531,219 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
         }
 }
 
+// ---- stride-2 4x4 transposed conv, the four sub-pixel phases of a spatial patch in ONE workgroup -------------------------
+// conv_igemm_kernel treats every (phase, tap) of a transposed conv as its own k-tile: a 32-channel chunk of the input is
+// gathered from global memory, BatchNorm-transformed and stored to LDS 16 times per output patch (4 phases x 2x2 taps), which
+// is what holds deconv2 at 96-102 TFLOP/s (the MFMA-only ablation of those launches runs 134).  All 16 (phase, tap)
+// products of a patch read the same 3x3 neighbourhood, so here the (PR + 2) x 18 halo tile of a chunk is fetched and
+// transformed ONCE, out-of-image pixels stored as zeros, and every tap of every phase is an LDS offset into it:
+//   patch = PR x 16 input pixels of one image (PR = 8 MI), wave w owns patch rows 2 MI w .. 2 MI (w + 1) - 1, an MFMA tile
+//   of 32 rows = 2 patch rows x 16 columns; accumulators acc[phase][MI][NI] (128 VGPRs);
+//   per 32-channel chunk: stage the halo tile, then per phase: stage the phase's 4 weight tiles [tap][32 NI cols][32 k] and
+//   run 4 taps x 16 k-steps x MI x NI MFMAs between barriers (conv_igemm_kernel: MI x NI x 16 per barrier pair).
+// Global A loads and transforms per output: 16 x 256 rows -> (PR + 2) x 18 rows per chunk (12.6x / 11.4x fewer).
+// descs: 4 consecutive phase descriptors per head (blockIdx.y), as built for conv_igemm_kernel; the BatchNorm records go to
+// each phase's stat_part with one record per patch (stat_bm = PR * 16, slot 0: a patch lies in one image).
+template <int MI, int NI>
+__global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(const ConvDesc* __restrict__ descs) {
+    constexpr int PR = 8 * MI, PW = 16, HW2 = PW + 2, NPIX = (PR + 2) * HW2;
+    constexpr int A_SLOTS = (NPIX * KQ + 255) / 256;                 // float4 slots per thread for the halo tile
+    constexpr int B_SLOTS = 4 * NI * 32 * KQ / 256;                 // ... for the 4 weight tiles of a phase
+    static_assert(BK == 32, "one 128-byte line per pixel and chunk");
+    __shared__ __attribute__((aligned(16))) float At[NPIX * LDK];
+    __shared__ __attribute__((aligned(16))) float Bt[4 * NI * 32 * LDK];
+    __shared__ __attribute__((aligned(16))) float sstab[2 * 512];   // per 4 channels: 4 scales, then 4 shifts
+    const ConvDesc* dh = descs + blockIdx.y * 4;
+    const ConvDesc d = dh[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int ppx = d.Win / PW, ppi = (d.Hin / PR) * ppx;
+    const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
+    const int y0 = (prem / ppx) * PR, x0 = (prem % ppx) * PW;
+    const int g = img >> 1;
+    for (int c = tid; c < d.Cin; c += 256) {
+        const bool s1 = c >= d.src[0].C;
+        const float2 e = rp_ldg2(reinterpret_cast<const float*>(s1 ? d.src[1].ss + (size_t)g * d.src[1].sstride + (c - d.src[0].C)
+                                                                   : d.src[0].ss + (size_t)g * d.src[0].sstride + c));
+        sstab[(c & ~3) * 2 + (c & 3)] = e.x; sstab[(c & ~3) * 2 + 4 + (c & 3)] = e.y;
+    }
+    // halo slots of this thread: pixel offset in the image (or -1: zero padding) and LDS position
+    // slot it of this thread = halo pixel tid / 8 + 32 it, chunk column kqa (256 % KQ == 0); LDS position = a_lds0 + it * 32 * LDK
+    const int kqa = tid % KQ;
+    const int a_lds0 = (tid / KQ) * LDK + kqa * 4;
+    // Buffer loads (SGPR descriptor + 32-bit lane offset + SGPR chunk offset): one index register per slot instead of a 64-bit
+    // address pair -- with 128 accumulator and 44 + 16 prefetch registers the flat-address version spilled.
+    int a_px[A_SLOTS];                                                // pixel index inside the image, or -1 (zero padding)
+#pragma unroll
+    for (int it = 0; it < A_SLOTS; ++it) {
+        const int pix = tid / KQ + it * 32;
+        const int hy = pix / HW2, hx = pix - hy * HW2;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = (pix < NPIX) && (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
+        a_px[it] = ok ? iy * d.Win + ix : -1;
+    }
+    const size_t img_px = (size_t)img * d.Hin * d.Win;
+    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)(d.src[0].x + img_px * d.src[0].cstride), 0,
+                                                                          d.Hin * d.Win * d.src[0].cstride * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a1 = d.nsrc > 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)(d.src[1].x + img_px * d.src[1].cstride), 0,
+                                                                                       d.Hin * d.Win * d.src[1].cstride * 4, 0x00020000) : rs_a0;
+    __amdgpu_buffer_rsrc_t rs_b[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rs_b[p] = __builtin_amdgcn_make_buffer_rsrc((void*)dh[p].w, 0, d.cout_pad * d.K * 4, 0x00020000);
+    // weight slot it = [tap][col][kq]: row-of-32 index tid / 8 + 32 it = tap * NI * 32 + col, i.e. col = tid / 8 + 32 (it % NI),
+    // tap = it / NI: global offset b_row0 + (it % NI) * 32 K + (it / NI) * Cin, LDS position b_lds0 + it * 32 * LDK
+    const int b_row0 = (tid / KQ) * d.K + kqa * 4;
+    const int b_lds0 = (tid / KQ) * LDK + kqa * 4;
+    floatx16 acc[4][MI][NI];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
+    // A fragment base of MFMA tile i: patch row 2 MI w + 2 i + (l31 >> 4), column l31 & 15, halo origin (+1, +1)
+    int arow[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) arow[i] = ((2 * MI * wave + 2 * i + (l31 >> 4) + 1) * HW2 + (l31 & 15) + 1) * LDK + h * 4;
+    const int brow = l31 * LDK + h * 4;
+    const float slope = d.src[0].slope;
+    int aoffs[4][4];                                                  // block-uniform: LDS offset of (phase, tap) relative to the output pixel
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) aoffs[p][t] = ((int)dh[p].offy[t] * HW2 + (int)dh[p].offx[t]) * LDK;
+    float4 ra[A_SLOTS], rb[B_SLOTS];
+    const int nchunk = d.Cin / BK;
+
+#define RP_DT_LOAD_A(C0)                                                                                       \
+    {                                                                                                         \
+        const bool s1_ = (d.nsrc > 1) && ((C0) >= d.src[0].C);                                                \
+        const int scs4_ = (s1_ ? d.src[1].cstride : d.src[0].cstride) * 4;                                   \
+        const int soff_ = ((C0) - (s1_ ? d.src[0].C : 0)) * 4;                                                \
+        _Pragma("unroll") for (int it = 0; it < A_SLOTS; ++it) {                                              \
+            int px_ = a_px[it];                                                                               \
+            asm volatile("" : "+v"(px_));      /* keep the offset arithmetic here: hoisted, it costs 22 registers */ \
+            const int voff_ = max(px_, 0) * scs4_ + kqa * 16;                                                 \
+            ra[it] = s1_ ? rp_bufld4(rs_a1, voff_, soff_) : rp_bufld4(rs_a0, voff_, soff_);                    \
+        }                                                                                                     \
+    }
+#define RP_DT_STORE_A(C0)                                                                                      \
+    {                                                                                                         \
+        const float4* q = reinterpret_cast<const float4*>(&sstab[2 * ((C0) + kqa * 4)]);                      \
+        const float4 s0_ = q[0], s1v_ = q[1];                                                                 \
+        const rp_v2f sl2_ = {slope, slope};                                                                   \
+        _Pragma("unroll") for (int it = 0; it < A_SLOTS; ++it) {                                              \
+            rp_v2f v01 = {ra[it].x, ra[it].y}, v23 = {ra[it].z, ra[it].w};                                    \
+            v01 = v01 * (rp_v2f){s0_.x, s0_.y} + (rp_v2f){s1v_.x, s1v_.y};                                    \
+            v23 = v23 * (rp_v2f){s0_.z, s0_.w} + (rp_v2f){s1v_.z, s1v_.w};                                    \
+            const rp_v2f t01 = v01 * sl2_, t23 = v23 * sl2_;                                                  \
+            const float okf_ = a_px[it] >= 0 ? 1.f : 0.f;                                                     \
+            const rp_v2f mk_ = {okf_, okf_};                                                                  \
+            v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
+            v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
+            if ((it + 1) * 32 <= NPIX || tid / KQ + it * 32 < NPIX)                                           \
+                *reinterpret_cast<float4*>(&At[a_lds0 + it * 32 * LDK]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+        }                                                                                                     \
+    }
+#define RP_DT_LOAD_B(P, C0)                                                                                    \
+    {                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
+            rb[it] = rp_bufld4(rs_b[P], b_row0 * 4, ((C0) + (it % NI) * 32 * d.K + (it / NI) * d.Cin) * 4);      \
+    }
+#define RP_DT_STORE_B()                                                                                        \
+    {                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * 32 * LDK]) = rb[it]; \
+    }
+
+    RP_DT_LOAD_A(0)
+    RP_DT_LOAD_B(0, 0)
+    __syncthreads();                                                  // sstab
+    RP_DT_STORE_A(0)
+    RP_DT_STORE_B()
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int c0 = ch * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // prefetch into registers: the next phase's weights, and (during the last phase) the next chunk's halo tile
+            const bool last = (ch + 1 == nchunk);
+            if (p < 3) RP_DT_LOAD_B(p + 1, c0)
+            else if (!last) { RP_DT_LOAD_B(0, c0 + BK) RP_DT_LOAD_A(c0 + BK) }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int aoff = aoffs[p][t];
+#pragma unroll
+                for (int kc = 0; kc < BK / 8; ++kc) {
+                    float4 a[MI], b[NI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&At[arow[i] + aoff + kc * 8]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bt[brow + (t * NI + j) * 32 * LDK + kc * 8]);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[p][i][j], 0, 0, 0);
+                            acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[p][i][j], 0, 0, 0);
+                            acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[p][i][j], 0, 0, 0);
+                            acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[p][i][j], 0, 0, 0);
+                        }
+                }
+            }
+            __syncthreads();                                          // every wave is done with this phase's weights (and, p == 3, the halo tile)
+            if (p < 3 || !last) RP_DT_STORE_B()
+            if (p == 3 && !last) RP_DT_STORE_A(c0 + BK)
+            __syncthreads();
+        }
+    }
+#undef RP_DT_LOAD_A
+#undef RP_DT_STORE_A
+#undef RP_DT_LOAD_B
+#undef RP_DT_STORE_B
+
+    // epilogue per phase: BatchNorm record of the patch, then the strided NHWC stores
+    double* red = reinterpret_cast<double*>(&At[0]);                  // [4 waves][NI * 32][2]
+    const int patch = blockIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (dh[p].stat_part) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                double sm = 0.0, sq = 0.0;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const double v = (double)acc[p][i][j][r]; sm += v; sq += v * v; }
+                sm += rp_shfl_xor_d(sm, 32); sq += rp_shfl_xor_d(sq, 32);
+                if (h == 0) { red[((wave * NI + j) * 32 + l31) * 2] = sm; red[((wave * NI + j) * 32 + l31) * 2 + 1] = sq; }
+            }
+            __syncthreads();
+            if (tid < NI * 32) {
+                double a = 0, b = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { a += red[((w * NI) * 32 + tid) * 2]; b += red[((w * NI) * 32 + tid) * 2 + 1]; }
+                double* o = dh[p].stat_part + (((size_t)patch * 2) * d.cout_pad + tid) * 2;
+                rp_stg(o, a); rp_stg(o + 1, b);
+            }
+            __syncthreads();
+        }
+        const int opy = dh[p].py, opx = dh[p].px;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;         // row of the 32-row MFMA tile
+                const int ry = 2 * MI * wave + 2 * i + (rl >> 4), cx = rl & 15;
+                const size_t pix = ((size_t)img * d.Hout + 2 * (y0 + ry) + opy) * d.Wout + 2 * (x0 + cx) + opx;
+                float* yo = d.y + pix * d.ycstride + d.ychoff + l31;
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    if (j * 32 + l31 < d.Cout) rp_stg(yo + j * 32, acc[p][i][j][r]);
+            }
+    }
+}
+
 // y[pix(m)][col] = sum over K slices (fixed order) of the partial tiles
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __restrict__ descs) {
     const ConvDesc d = descs[blockIdx.z];
@@ -911,7 +1132,7 @@ __global__ __launch_bounds__(64) void bn_finalize_wave_kernel(const double* __re
 
 // Finalise BatchNorm from the per-tile records written by the conv epilogue.  One thread per (group, channel);
 // the records of every launch member that wrote this channel are added in (member, tile) order.
-__global__ __launch_bounds__(64) void bn_finalize_fused_kernel(const ConvDesc* __restrict__ descs, int ndesc, int BMt, int C,
+__global__ __launch_bounds__(64) void bn_finalize_fused_kernel(const ConvDesc* __restrict__ descs, int ndesc, int /*unused*/, int C,
                                                                 int rows_per_group, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float2* __restrict__ ss) {
     const int c = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;      // one wave per (channel, group)
@@ -921,6 +1142,7 @@ __global__ __launch_bounds__(64) void bn_finalize_fused_kernel(const ConvDesc* _
         const int cl = c - d.ychoff;
         if (cl < 0 || cl >= d.Cout) continue;
         const int hw = d.Hp * d.Wp;
+        const int BMt = d.stat_bm;
         const int t0 = (2 * g * hw) / BMt, t1 = min(((2 * g + 2) * hw - 1) / BMt, (d.M - 1) / BMt);
         for (int t = t0 + lane; t <= t1; t += 64) {
             const int sl = g - (((t * BMt) / hw) >> 1);
@@ -1303,7 +1525,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5 };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6 };
 struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0, split = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
@@ -1422,7 +1644,24 @@ void Builder::end_group() {
         }
         if (!no_auto128 && !u256 && u128 && (cfg == 1 || cfg == 2)) cfg = cfg == 1 ? 4 : 5;
     }
-    const int BMt = (cfg == 0 || cfg >= 4) ? 128 : 256, BNt = cfg == 6 ? 256 : ((cfg == 0 || cfg == 3) ? 128 : cp);
+    int BMt = (cfg == 0 || cfg >= 4) ? 128 : 256;
+    const int BNt = cfg == 6 ? 256 : ((cfg == 0 || cfg == 3) ? 128 : cp);
+    // Fused-phase kernel (deconv_tile_kernel): the 4 phases of stride-2 4x4 transposed convs with Cout 32 / 64 whose input grid
+    // tiles into 16 x 16 (Cout 32) / 8 x 16 (Cout 64) patches -- deconv2 (112 x 112); fp32 products only.
+    bool dtile = false;
+    {
+        static const bool no_dt = getenv("RELPOSE_NO_DECONV_TILE") != nullptr;
+        static const bool dt_mi1 = getenv("RELPOSE_DT_MI1") != nullptr;     // experiment: 8 x 16 patches (MI = 1) for Cout 32 as well
+        const int PRt = (cp == 32 && !dt_mi1) ? 16 : 8;
+        dtile = !no_dt && net->prec == 0 && (cp == 32 || cp == 64) && count % 4 == 0;
+        for (int i = first; i < first + count && dtile; ++i) {
+            const ConvDesc& d = plan->descs[i];
+            const ConvDesc& d0 = plan->descs[first + ((i - first) & ~3)];
+            dtile = d.osy == 2 && d.osx == 2 && d.sy == 1 && d.ntaps == 4 && d.Hin % PRt == 0 && d.Win % 16 == 0 && d.Hp == d.Hin && d.Wp == d.Win &&
+                    d.Cin <= 512 && d.src[0].sstride != 0 && !d.bias && d.src[0].x == d0.src[0].x && d.y == d0.y && d.ychoff == d0.ychoff && d.Cin == d0.Cin;
+        }
+        if (dtile) BMt = PRt * 16;
+    }
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
     for (int i = first; i < first + count; ++i) {
@@ -1437,7 +1676,7 @@ void Builder::end_group() {
     }
     // split along K until the launch has >= ~3000 tiles (>= 4 waves of resident blocks), keeping >= 8 k-tiles per slice
     int ksplit = 1;
-    while (tiles * ksplit < 3000 && ksplit < 64 && min_kt / (ksplit * 2) >= 8) ksplit *= 2;
+    while (!dtile && tiles * ksplit < 3000 && ksplit < 64 && min_kt / (ksplit * 2) >= 8) ksplit *= 2;
     size_t pf = 0;
     for (int i = first; i < first + count; ++i) {
         ConvDesc& d = plan->descs[i];
@@ -1452,14 +1691,21 @@ void Builder::end_group() {
     for (int i = first; i < first + count; ++i) fuse = fuse && (2 * plan->descs[i].Hp * plan->descs[i].Wp >= BMt) && !plan->descs[i].bias;
     if (pend_first < 0) { pend_first = first; pend_count = 0; pend_bm = BMt; pend_ok = true; }
     pend_count += count;
-    pend_ok = pend_ok && fuse && (pend_bm == BMt);
+    pend_ok = pend_ok && fuse;               // (the groups feeding one BatchNorm may use different tile heights: ConvDesc::stat_bm)
     if (fuse) {
         for (int i = first; i < first + count; ++i) {
             ConvDesc& d = plan->descs[i];
+            d.stat_bm = BMt;
             const size_t nd = (size_t)((d.M + BMt - 1) / BMt) * 2 * cp * 2;
             d.stat_part = statp ? statp + plan->stat_doubles : (double*)(uintptr_t)8;   // non-null marker in the dry run
             plan->stat_doubles += nd;
         }
+    }
+    if (dtile) {
+        Op o; o.type = OP_DECONV_TILE; o.first = first; o.count = count; o.cfg = cp == 32 ? (BMt == 256 ? 0 : 2) : 1;
+        o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count / 4, 1);
+        plan->ops.push_back(o);
+        return;
     }
     Op o; o.type = OP_CONV; o.first = first; o.count = count; o.cfg = cfg;
     // runs of 4 consecutive members that are the phases of one stride-2 transposed conv share their input tile
@@ -1788,6 +2034,12 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             else RP_LAUNCH_T(4, 1, 1, 1);
 #undef RP_LAUNCH_T
 #undef RP_LAUNCH_V
+            mark(-1);
+        } else if (op.type == OP_DECONV_TILE) {
+            mark(1);
+            if (op.cfg == 0) hipLaunchKernelGGL((deconv_tile_kernel<2, 1>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            else if (op.cfg == 2) hipLaunchKernelGGL((deconv_tile_kernel<1, 1>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            else hipLaunchKernelGGL((deconv_tile_kernel<1, 2>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             mark(-1);
         } else if (op.type == OP_CONV1) {
             mark(1);

@@ -56,8 +56,9 @@ def conv_layers(rows, n=64, which=3):
          ('deconv3 x5', 4 * (3 * P(n * 3136, 1024, 64) + 2 * P(n * 3136, 512, 64))),
          ('deconv2 rgb/n/d', 12 * P(n * 12544, 512, 32)), ('deconv2 s/f', 8 * P(n * 12544, 256, 64)),
          ('heads', sum(P(n * 50176, 64, c) for c in (3, 3, 1, 15, 32)))]
-    convs = [r for r in seq if 'conv_igemm' in r[0]]
-    c1 = [r for r in seq if 'conv1_direct' in r[0]]
+    isconv = lambda nm: 'conv_igemm' in nm or 'deconv_tile' in nm      # the implicit-GEMM launches, in network order
+    convs = [r for r in seq if isconv(r[0])]
+    c1 = [r for r in seq if 'conv1_direct' in r[0] or 'conv1_mfma' in r[0]]
     red = sum((r[2] - r[1]) / 1e3 for r in seq if 'splitk_reduce' in r[0])
     out = [f"{len(convs)} conv launches in forward #{which} (expected {len(G)})"]
     tot = sum((r[2] - r[1]) / 1e3 for r in convs)
@@ -67,12 +68,12 @@ def conv_layers(rows, n=64, which=3):
     if c1:
         d1 = (c1[0][2] - c1[0][1]) / 1e3
         f1 = 2.0 * n * 224 * 224 * 192 * 36 * (10 / 12)      # 4 blocks with 36 and 2 blocks with 18 real MACs per output
-        out.append(f"{'conv1 (direct)':16s} time={d1:9.1f}us  useful TFLOP/s={f1/d1/1e6:6.1f} (VALU; writes {n*224*224*192*4/1e9:.2f} GB -> {n*224*224*192*4/d1/1e3:.0f} GB/s)")
+        out.append(f"{'conv1':16s} time={d1:9.1f}us  useful TFLOP/s={f1/d1/1e6:6.1f} ({'MFMA' if 'mfma' in c1[0][0] else 'VALU'}; writes {n*224*224*192*4/1e9:.2f} GB -> {n*224*224*192*4/d1/1e3:.0f} GB/s)")
     out.append(f"conv total {tot:.1f} us (+ split-K reduce {red:.1f} us), useful {sum(f for _, f in G)/tot/1e6:.1f} TFLOP/s; "
                f"forward wall {(seq[-1][2]-seq[0][1])/1e3:.1f} us")
     oth = {}
     for r in seq:
-        if 'conv_igemm' not in r[0]:
+        if not isconv(r[0]):
             oth[short(r[0])[:24]] = oth.get(short(r[0])[:24], 0) + (r[2] - r[1]) / 1e3
     out.append("other kernels (us): " + ", ".join(f"{k}={v:.0f}" for k, v in oth.items()))
     return "\n".join(out)
