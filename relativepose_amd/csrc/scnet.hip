@@ -544,11 +544,18 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
 // Global A loads and transforms per output: 16 x 256 rows -> (PR + 2) x 18 rows per chunk (12.6x / 11.4x fewer).
 // descs: 4 consecutive phase descriptors per head (blockIdx.y), as built for conv_igemm_kernel; the BatchNorm records go to
 // each phase's stat_part with one record per patch (stat_bm = PR * 16, slot 0: a patch lies in one image).
-template <int MI, int NI>
-__global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(const ConvDesc* __restrict__ descs) {
-    constexpr int PR = 8 * MI, PW = 16, HW2 = PW + 2, NPIX = (PR + 2) * HW2;
-    constexpr int A_SLOTS = (NPIX * KQ + 255) / 256;                 // float4 slots per thread for the halo tile
-    constexpr int B_SLOTS = 4 * NI * 32 * KQ / 256;                 // ... for the 4 weight tiles of a phase
+// NW waves per workgroup; an MFMA tile of 32 rows = (32 / TC) patch rows x TC columns.  TC == 16: the NW x MI tiles are stacked
+// vertically (patch 2 MI NW x 16); TC == 8: side by side (patch 4 x 8 NW, MI == 1: a full-width strip of a 56-wide grid with NW = 7).
+// blockIdx.z = N tile of NI * 32 output columns (Cout 64 as two tiles of 32: three workgroups per CU instead of two).
+template <int MI, int NI, int NW, int TC>
+__global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void deconv_tile_kernel(const ConvDesc* __restrict__ descs) {
+    constexpr int NT = NW * 64, TR = 32 / TC;
+    constexpr int PR = TC == 16 ? TR * MI * NW : TR, PW = TC == 16 ? 16 : TC * NW, HW2 = PW + 2, NPIX = (PR + 2) * HW2;
+    static_assert(TC == 16 || MI == 1, "strip layout: one tile per wave");
+    constexpr int PSTEP = NT / KQ;                                    // halo pixels covered per slot iteration
+    constexpr int A_SLOTS = (NPIX + PSTEP - 1) / PSTEP;               // float4 slots per thread for the halo tile
+    constexpr int B_ROWS = 4 * NI * 32;                               // rows [tap][col] of a phase's weight tiles
+    constexpr int B_SLOTS = (B_ROWS + PSTEP - 1) / PSTEP;
     static_assert(BK == 32, "one 128-byte line per pixel and chunk");
     __shared__ __attribute__((aligned(16))) float At[NPIX * LDK];
     __shared__ __attribute__((aligned(16))) float Bt[4 * NI * 32 * LDK];
@@ -560,14 +567,15 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(
     const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
     const int y0 = (prem / ppx) * PR, x0 = (prem % ppx) * PW;
     const int g = img >> 1;
-    for (int c = tid; c < d.Cin; c += 256) {
+    const int n0 = blockIdx.z * NI * 32;
+    for (int c = tid; c < d.Cin; c += NT) {
         const bool s1 = c >= d.src[0].C;
         const float2 e = rp_ldg2(reinterpret_cast<const float*>(s1 ? d.src[1].ss + (size_t)g * d.src[1].sstride + (c - d.src[0].C)
                                                                    : d.src[0].ss + (size_t)g * d.src[0].sstride + c));
         sstab[(c & ~3) * 2 + (c & 3)] = e.x; sstab[(c & ~3) * 2 + 4 + (c & 3)] = e.y;
     }
     // halo slots of this thread: pixel offset in the image (or -1: zero padding) and LDS position
-    // slot it of this thread = halo pixel tid / 8 + 32 it, chunk column kqa (256 % KQ == 0); LDS position = a_lds0 + it * 32 * LDK
+    // slot it of this thread = halo pixel tid / 8 + PSTEP it, chunk column kqa (NT % KQ == 0); LDS position = a_lds0 + it * PSTEP * LDK
     const int kqa = tid % KQ;
     const int a_lds0 = (tid / KQ) * LDK + kqa * 4;
     // Buffer loads (SGPR descriptor + 32-bit lane offset + SGPR chunk offset): one index register per slot instead of a 64-bit
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(
     int a_px[A_SLOTS];                                                // pixel index inside the image, or -1 (zero padding)
 #pragma unroll
     for (int it = 0; it < A_SLOTS; ++it) {
-        const int pix = tid / KQ + it * 32;
+        const int pix = tid / KQ + it * PSTEP;
         const int hy = pix / HW2, hx = pix - hy * HW2;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool ok = (pix < NPIX) && (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
@@ -589,9 +597,14 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(
     __amdgpu_buffer_rsrc_t rs_b[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) rs_b[p] = __builtin_amdgcn_make_buffer_rsrc((void*)dh[p].w, 0, d.cout_pad * d.K * 4, 0x00020000);
-    // weight slot it = [tap][col][kq]: row-of-32 index tid / 8 + 32 it = tap * NI * 32 + col, i.e. col = tid / 8 + 32 (it % NI),
-    // tap = it / NI: global offset b_row0 + (it % NI) * 32 K + (it / NI) * Cin, LDS position b_lds0 + it * 32 * LDK
-    const int b_row0 = (tid / KQ) * d.K + kqa * 4;
+    // weight slot it: row r = tid / 8 + PSTEP it of [tap][col] (r = tap * NI * 32 + col), chunk column kqa; LDS position r * LDK + kqa * 4
+    int b_off[B_SLOTS];                                               // byte offset of the row in the phase's weights (chunk 0), or -1
+#pragma unroll
+    for (int it = 0; it < B_SLOTS; ++it) {
+        const int r = tid / KQ + it * PSTEP;
+        const int tap = r / (NI * 32), col = r - tap * (NI * 32);
+        b_off[it] = r < B_ROWS ? ((n0 + col) * d.K + tap * d.Cin + kqa * 4) * 4 : -1;
+    }
     const int b_lds0 = (tid / KQ) * LDK + kqa * 4;
     floatx16 acc[4][MI][NI];
 #pragma unroll
@@ -602,10 +615,11 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
-    // A fragment base of MFMA tile i: patch row 2 MI w + 2 i + (l31 >> 4), column l31 & 15, halo origin (+1, +1)
+    // A fragment base of MFMA tile i of this wave: patch row / column of MFMA row l31, halo origin (+1, +1)
+    const int try0 = TC == 16 ? TR * MI * wave : 0, tcx0 = TC == 16 ? 0 : TC * wave;       // first patch row / column of the wave's tiles
     int arow[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) arow[i] = ((2 * MI * wave + 2 * i + (l31 >> 4) + 1) * HW2 + (l31 & 15) + 1) * LDK + h * 4;
+    for (int i = 0; i < MI; ++i) arow[i] = ((try0 + TR * i + l31 / TC + 1) * HW2 + tcx0 + (l31 % TC) + 1) * LDK + h * 4;
     const int brow = l31 * LDK + h * 4;
     const float slope = d.src[0].slope;
     int aoffs[4][4];                                                  // block-uniform: LDS offset of (phase, tap) relative to the output pixel
@@ -642,18 +656,19 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(
             const rp_v2f mk_ = {okf_, okf_};                                                                  \
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
-            if ((it + 1) * 32 <= NPIX || tid / KQ + it * 32 < NPIX)                                           \
-                *reinterpret_cast<float4*>(&At[a_lds0 + it * 32 * LDK]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+            if ((it + 1) * PSTEP <= NPIX || tid / KQ + it * PSTEP < NPIX)                                     \
+                *reinterpret_cast<float4*>(&At[a_lds0 + it * PSTEP * LDK]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
         }                                                                                                     \
     }
 #define RP_DT_LOAD_B(P, C0)                                                                                    \
     {                                                                                                         \
         _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
-            rb[it] = rp_bufld4(rs_b[P], b_row0 * 4, ((C0) + (it % NI) * 32 * d.K + (it / NI) * d.Cin) * 4);      \
+            rb[it] = rp_bufld4(rs_b[P], max(b_off[it], 0), (C0) * 4);                                          \
     }
 #define RP_DT_STORE_B()                                                                                        \
     {                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * 32 * LDK]) = rb[it]; \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
+            if ((it + 1) * PSTEP <= B_ROWS || b_off[it] >= 0) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = rb[it]; \
     }
 
     RP_DT_LOAD_A(0)
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(
 #undef RP_DT_STORE_B
 
     // epilogue per phase: BatchNorm record of the patch, then the strided NHWC stores
-    double* red = reinterpret_cast<double*>(&At[0]);                  // [4 waves][NI * 32][2]
+    double* red = reinterpret_cast<double*>(&At[0]);                  // [NW waves][NI * 32][2]
     const int patch = blockIdx.x;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -722,8 +737,8 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(
             if (tid < NI * 32) {
                 double a = 0, b = 0;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) { a += red[((w * NI) * 32 + tid) * 2]; b += red[((w * NI) * 32 + tid) * 2 + 1]; }
-                double* o = dh[p].stat_part + (((size_t)patch * 2) * d.cout_pad + tid) * 2;
+                for (int w = 0; w < NW; ++w) { a += red[((w * NI) * 32 + tid) * 2]; b += red[((w * NI) * 32 + tid) * 2 + 1]; }
+                double* o = dh[p].stat_part + (((size_t)patch * 2) * d.cout_pad + n0 + tid) * 2;
                 rp_stg(o, a); rp_stg(o + 1, b);
             }
             __syncthreads();
@@ -734,12 +749,12 @@ __global__ __launch_bounds__(256, MI * NI == 1 ? 3 : 2) void deconv_tile_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;         // row of the 32-row MFMA tile
-                const int ry = 2 * MI * wave + 2 * i + (rl >> 4), cx = rl & 15;
+                const int ry = try0 + TR * i + rl / TC, cx = tcx0 + rl % TC;
                 const size_t pix = ((size_t)img * d.Hout + 2 * (y0 + ry) + opy) * d.Wout + 2 * (x0 + cx) + opx;
-                float* yo = d.y + pix * d.ycstride + d.ychoff + l31;
+                float* yo = d.y + pix * d.ycstride + d.ychoff + n0 + l31;
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    if (j * 32 + l31 < d.Cout) rp_stg(yo + j * 32, acc[p][i][j][r]);
+                    if (n0 + j * 32 + l31 < d.Cout) rp_stg(yo + j * 32, acc[p][i][j][r]);
             }
     }
 }
@@ -1649,18 +1664,26 @@ void Builder::end_group() {
     // Fused-phase kernel (deconv_tile_kernel): the 4 phases of stride-2 4x4 transposed convs with Cout 32 / 64 whose input grid
     // tiles into 16 x 16 (Cout 32) / 8 x 16 (Cout 64) patches -- deconv2 (112 x 112); fp32 products only.
     bool dtile = false;
+    int dt_cfg = -1;
     {
         static const bool no_dt = getenv("RELPOSE_NO_DECONV_TILE") != nullptr;
-        static const bool dt_mi1 = getenv("RELPOSE_DT_MI1") != nullptr;     // experiment: 8 x 16 patches (MI = 1) for Cout 32 as well
-        const int PRt = (cp == 32 && !dt_mi1) ? 16 : 8;
-        dtile = !no_dt && net->prec == 0 && (cp == 32 || cp == 64) && count % 4 == 0;
+        // variants (RELPOSE_DT_VARIANT overrides; measured at 64 images, profiles/r02_conv_experiments.txt):
+        //   0: <MI 2, NI 1> 16 x 16 patches, 2 workgroups per CU      1: <1, 2> 8 x 16 patches, 2 per CU
+        //   2: <1, 1> 8 x 16 patches, 3 per CU, Cout 64 as two N tiles 3: <1, 1> 4 x 56 strips of 7 waves (56-wide grids)
+        static const int dt_var = getenv("RELPOSE_DT_VARIANT") ? atoi(getenv("RELPOSE_DT_VARIANT")) : -1;
+        const int Wg = plan->descs[first].Win;
+        static const bool dt_strip = getenv("RELPOSE_DT_STRIP") != nullptr;   // 56-wide grids (deconv3): no gain measured (one 7-wave workgroup per CU)
+        dt_cfg = Wg % 16 == 0 ? (cp == 32 ? 2 : 1) : ((Wg == 56 && dt_strip) ? 3 : -1);
+        if (dt_var >= 0 && dt_var <= 2 && Wg % 16 == 0 && !(dt_var == 0 && cp != 32) && !(dt_var == 1 && cp != 64)) dt_cfg = dt_var;
+        const int PRt = dt_cfg == 0 ? 16 : (dt_cfg == 3 ? 4 : 8), PWt = dt_cfg == 3 ? 56 : 16;
+        dtile = !no_dt && dt_cfg >= 0 && net->prec == 0 && (cp == 32 || cp == 64) && count % 4 == 0;
         for (int i = first; i < first + count && dtile; ++i) {
             const ConvDesc& d = plan->descs[i];
             const ConvDesc& d0 = plan->descs[first + ((i - first) & ~3)];
-            dtile = d.osy == 2 && d.osx == 2 && d.sy == 1 && d.ntaps == 4 && d.Hin % PRt == 0 && d.Win % 16 == 0 && d.Hp == d.Hin && d.Wp == d.Win &&
+            dtile = d.osy == 2 && d.osx == 2 && d.sy == 1 && d.ntaps == 4 && d.Hin % PRt == 0 && d.Win % PWt == 0 && d.Hp == d.Hin && d.Wp == d.Win &&
                     d.Cin <= 512 && d.src[0].sstride != 0 && !d.bias && d.src[0].x == d0.src[0].x && d.y == d0.y && d.ychoff == d0.ychoff && d.Cin == d0.Cin;
         }
-        if (dtile) BMt = PRt * 16;
+        if (dtile) BMt = PRt * PWt;
     }
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
@@ -1702,8 +1725,8 @@ void Builder::end_group() {
         }
     }
     if (dtile) {
-        Op o; o.type = OP_DECONV_TILE; o.first = first; o.count = count; o.cfg = cp == 32 ? (BMt == 256 ? 0 : 2) : 1;
-        o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count / 4, 1);
+        Op o; o.type = OP_DECONV_TILE; o.first = first; o.count = count; o.cfg = dt_cfg;
+        o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count / 4, dt_cfg >= 2 ? cp / 32 : 1);
         plan->ops.push_back(o);
         return;
     }
@@ -2037,9 +2060,10 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             mark(-1);
         } else if (op.type == OP_DECONV_TILE) {
             mark(1);
-            if (op.cfg == 0) hipLaunchKernelGGL((deconv_tile_kernel<2, 1>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
-            else if (op.cfg == 2) hipLaunchKernelGGL((deconv_tile_kernel<1, 1>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
-            else hipLaunchKernelGGL((deconv_tile_kernel<1, 2>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            if (op.cfg == 0) hipLaunchKernelGGL((deconv_tile_kernel<2, 1, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            else if (op.cfg == 1) hipLaunchKernelGGL((deconv_tile_kernel<1, 2, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            else if (op.cfg == 2) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            else hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 7, 8>), op.grid, dim3(448), 0, s, plan->d_descs + op.first);
             mark(-1);
         } else if (op.type == OP_CONV1) {
             mark(1);
