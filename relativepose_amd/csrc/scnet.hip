@@ -547,11 +547,15 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
 // NW waves per workgroup; an MFMA tile of 32 rows = (32 / TC) patch rows x TC columns.  TC == 16: the NW x MI tiles are stacked
 // vertically (patch 2 MI NW x 16); TC == 8: side by side (patch 4 x 8 NW, MI == 1: a full-width strip of a 56-wide grid with NW = 7).
 // blockIdx.z = N tile of NI * 32 output columns (Cout 64 as two tiles of 32: three workgroups per CU instead of two).
-template <int MI, int NI, int NW, int TC>
+// PAIR (TC == 8, 4 waves): the workgroup takes TWO 8 x 8 patches (consecutive in patch order, possibly in the two images of one
+// BatchNorm group) with separate 10 x 10 halo tiles -- 56-wide grids tile into 8 x 8 but not into 8 x 16 (deconv3).
+template <int MI, int NI, int NW, int TC, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void deconv_tile_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int NT = NW * 64, TR = 32 / TC;
-    constexpr int PR = TC == 16 ? TR * MI * NW : TR, PW = TC == 16 ? 16 : TC * NW, HW2 = PW + 2, NPIX = (PR + 2) * HW2;
+    constexpr int PR = PAIR ? 8 : (TC == 16 ? TR * MI * NW : TR), PW = PAIR ? 8 : (TC == 16 ? 16 : TC * NW), HW2 = PW + 2;
+    constexpr int SUBPIX = (PR + 2) * HW2, NPIX = (PAIR ? 2 : 1) * SUBPIX;
     static_assert(TC == 16 || MI == 1, "strip layout: one tile per wave");
+    static_assert(!PAIR || (TC == 8 && NW == 4 && MI == 1), "paired 8 x 8 patches: 4 waves of one 4 x 8 tile");
     constexpr int PSTEP = NT / KQ;                                    // halo pixels covered per slot iteration
     constexpr int A_SLOTS = (NPIX + PSTEP - 1) / PSTEP;               // float4 slots per thread for the halo tile
     constexpr int B_ROWS = 4 * NI * 32;                               // rows [tap][col] of a phase's weight tiles
@@ -564,9 +568,16 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
     const ConvDesc d = dh[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ppx = d.Win / PW, ppi = (d.Hin / PR) * ppx;
-    const int img = blockIdx.x / ppi, prem = blockIdx.x - img * ppi;
-    const int y0 = (prem / ppx) * PR, x0 = (prem % ppx) * PW;
-    const int g = img >> 1;
+    int imgs[2], y0s[2], x0s[2];                                      // (PAIR: per sub-patch; block-uniform)
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+        const int q = PAIR ? 2 * blockIdx.x + sp : blockIdx.x;
+        imgs[sp] = q / ppi;
+        const int prem = q - imgs[sp] * ppi;
+        y0s[sp] = (prem / ppx) * PR; x0s[sp] = (prem % ppx) * PW;
+    }
+    const int g = imgs[0] >> 1;
+    const int img_base = PAIR ? 2 * g : imgs[0];                      // image the buffer descriptors start at
     const int n0 = blockIdx.z * NI * 32;
     for (int c = tid; c < d.Cin; c += NT) {
         const bool s1 = c >= d.src[0].C;
@@ -584,16 +595,18 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
 #pragma unroll
     for (int it = 0; it < A_SLOTS; ++it) {
         const int pix = tid / KQ + it * PSTEP;
-        const int hy = pix / HW2, hx = pix - hy * HW2;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const int sp = (PAIR && pix >= SUBPIX) ? 1 : 0, lp = pix - sp * SUBPIX;
+        const int hy = lp / HW2, hx = lp - hy * HW2;
+        const int iy = (sp ? y0s[1] : y0s[0]) - 1 + hy, ix = (sp ? x0s[1] : x0s[0]) - 1 + hx;
         const bool ok = (pix < NPIX) && (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
-        a_px[it] = ok ? iy * d.Win + ix : -1;
+        a_px[it] = ok ? (((sp ? imgs[1] : imgs[0]) - img_base) * d.Hin + iy) * d.Win + ix : -1;
     }
-    const size_t img_px = (size_t)img * d.Hin * d.Win;
+    const size_t img_px = (size_t)img_base * d.Hin * d.Win;
+    const int a_bytes = (PAIR ? 2 : 1) * d.Hin * d.Win * 4;
     const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)(d.src[0].x + img_px * d.src[0].cstride), 0,
-                                                                          d.Hin * d.Win * d.src[0].cstride * 4, 0x00020000);
+                                                                          a_bytes * d.src[0].cstride, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_a1 = d.nsrc > 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)(d.src[1].x + img_px * d.src[1].cstride), 0,
-                                                                                       d.Hin * d.Win * d.src[1].cstride * 4, 0x00020000) : rs_a0;
+                                                                                       a_bytes * d.src[1].cstride, 0x00020000) : rs_a0;
     __amdgpu_buffer_rsrc_t rs_b[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) rs_b[p] = __builtin_amdgcn_make_buffer_rsrc((void*)dh[p].w, 0, d.cout_pad * d.K * 4, 0x00020000);
@@ -616,10 +629,11 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
     // A fragment base of MFMA tile i of this wave: patch row / column of MFMA row l31, halo origin (+1, +1)
-    const int try0 = TC == 16 ? TR * MI * wave : 0, tcx0 = TC == 16 ? 0 : TC * wave;       // first patch row / column of the wave's tiles
+    const int try0 = PAIR ? TR * (wave & 1) : (TC == 16 ? TR * MI * wave : 0), tcx0 = (PAIR || TC == 16) ? 0 : TC * wave;   // first patch row / column of the wave's tiles
+    const int wsp = PAIR ? (wave >> 1) : 0;                           // sub-patch of this wave
     int arow[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) arow[i] = ((try0 + TR * i + l31 / TC + 1) * HW2 + tcx0 + (l31 % TC) + 1) * LDK + h * 4;
+    for (int i = 0; i < MI; ++i) arow[i] = (wsp * SUBPIX + (try0 + TR * i + l31 / TC + 1) * HW2 + tcx0 + (l31 % TC) + 1) * LDK + h * 4;
     const int brow = l31 * LDK + h * 4;
     const float slope = d.src[0].slope;
     int aoffs[4][4];                                                  // block-uniform: LDS offset of (phase, tap) relative to the output pixel
@@ -750,7 +764,7 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;         // row of the 32-row MFMA tile
                 const int ry = try0 + TR * i + rl / TC, cx = tcx0 + rl % TC;
-                const size_t pix = ((size_t)img * d.Hout + 2 * (y0 + ry) + opy) * d.Wout + 2 * (x0 + cx) + opx;
+                const size_t pix = ((size_t)(wsp ? imgs[1] : imgs[0]) * d.Hout + 2 * ((wsp ? y0s[1] : y0s[0]) + ry) + opy) * d.Wout + 2 * ((wsp ? x0s[1] : x0s[0]) + cx) + opx;
                 float* yo = d.y + pix * d.ycstride + d.ychoff + n0 + l31;
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
@@ -1673,9 +1687,11 @@ void Builder::end_group() {
         static const int dt_var = getenv("RELPOSE_DT_VARIANT") ? atoi(getenv("RELPOSE_DT_VARIANT")) : -1;
         const int Wg = plan->descs[first].Win;
         static const bool dt_strip = getenv("RELPOSE_DT_STRIP") != nullptr;   // 56-wide grids (deconv3): no gain measured (one 7-wave workgroup per CU)
-        dt_cfg = Wg % 16 == 0 ? (cp == 32 ? 2 : 1) : ((Wg == 56 && dt_strip) ? 3 : -1);
+        static const bool no_pair = getenv("RELPOSE_DT_NO_PAIR") != nullptr;
+        //   4: <1, 1> pairs of 8 x 8 patches (grids that tile into 8 x 8 only: deconv3, 56 x 56), 3 per CU, Cout 64 as two N tiles
+        dt_cfg = Wg % 16 == 0 ? (cp == 32 ? 2 : 1) : ((Wg == 56 && dt_strip) ? 3 : ((Wg % 8 == 0 && !no_pair) ? 4 : -1));
         if (dt_var >= 0 && dt_var <= 2 && Wg % 16 == 0 && !(dt_var == 0 && cp != 32) && !(dt_var == 1 && cp != 64)) dt_cfg = dt_var;
-        const int PRt = dt_cfg == 0 ? 16 : (dt_cfg == 3 ? 4 : 8), PWt = dt_cfg == 3 ? 56 : 16;
+        const int PRt = dt_cfg == 0 ? 16 : (dt_cfg == 3 ? 4 : 8), PWt = dt_cfg == 3 ? 56 : (dt_cfg == 4 ? 8 : 16);
         dtile = !no_dt && dt_cfg >= 0 && net->prec == 0 && (cp == 32 || cp == 64) && count % 4 == 0;
         for (int i = first; i < first + count && dtile; ++i) {
             const ConvDesc& d = plan->descs[i];
@@ -1683,7 +1699,8 @@ void Builder::end_group() {
             dtile = d.osy == 2 && d.osx == 2 && d.sy == 1 && d.ntaps == 4 && d.Hin % PRt == 0 && d.Win % PWt == 0 && d.Hp == d.Hin && d.Wp == d.Win &&
                     d.Cin <= 512 && d.src[0].sstride != 0 && !d.bias && d.src[0].x == d0.src[0].x && d.y == d0.y && d.ychoff == d0.ychoff && d.Cin == d0.Cin;
         }
-        if (dtile) BMt = PRt * PWt;
+        if (dtile && dt_cfg == 4) dtile = ((plan->descs[first].Hin / 8) * (Wg / 8) * 2) % 2 == 0 && n % 2 == 0;
+        if (dtile) BMt = dt_cfg == 4 ? 128 : PRt * PWt;              // (4: a workgroup = two 8 x 8 patches)
     }
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
@@ -2063,6 +2080,7 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             if (op.cfg == 0) hipLaunchKernelGGL((deconv_tile_kernel<2, 1, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             else if (op.cfg == 1) hipLaunchKernelGGL((deconv_tile_kernel<1, 2, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             else if (op.cfg == 2) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            else if (op.cfg == 4) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 8, true>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             else hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 7, 8>), op.grid, dim3(448), 0, s, plan->d_descs + op.first);
             mark(-1);
         } else if (op.type == OP_CONV1) {
