@@ -773,6 +773,224 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
     }
 }
 
+// ---- stride-2 4x4 convs (conv2, conv3) on parity planes ---------------------------------------------------------------------
+// out(y, x) = sum_{ky, kx} in(2y - 1 + ky, 2x - 1 + kx) w(ky, kx): the four taps with ky = p ? {0, 2} : {1, 3} and kx = q ? {0, 2} : {1, 3}
+// read the parity plane (p, q) of the input, in(2a + p, 2b + q), at a in {y - p, y - p + 1}: a 2x2 stride-1 conv per plane.  Per
+// 32-channel chunk and plane the (PR + 1) x (PW + 1) plane pixels of an output patch are gathered, BatchNorm-transformed and
+// stored to LDS ONCE and the plane's 4 taps are LDS offsets {0, 1} x {0, 1} into that tile (conv_igemm_kernel gathers the PR x PW rows
+// of every one of the 16 taps: 3.3-3.5x the global loads and transforms).  The weight tile of one tap is staged per k-step as before.
+// Geometry as in deconv_tile_kernel: TC == 16: patch 2 MI NW x 16 outputs, tiles stacked; PAIR: two 8 x 8 patches (56-wide grids).
+template <int MI, int NI, int TC, bool PAIR>
+__global__ __launch_bounds__(256, 3) void conv_s2_tile_kernel(const ConvDesc* __restrict__ descs) {
+    constexpr int NW = 4, NT = 256, TR = 32 / TC;
+    constexpr int PR = PAIR ? 8 : TR * MI * NW, PW = PAIR ? 8 : 16, HW1 = PW + 1;
+    constexpr int SUBPIX = (PR + 1) * HW1, NPIX = (PAIR ? 2 : 1) * SUBPIX;
+    static_assert(!PAIR || (TC == 8 && MI == 1), "paired 8 x 8 patches: 4 waves of one 4 x 8 tile");
+    constexpr int PSTEP = NT / KQ;
+    constexpr int A_SLOTS = (NPIX + PSTEP - 1) / PSTEP;
+    constexpr int B_ROWS = NI * 32;
+    constexpr int B_SLOTS = (B_ROWS + PSTEP - 1) / PSTEP;
+    static_assert(BK == 32 && B_ROWS % PSTEP == 0, "weight tile layout");
+    __shared__ __attribute__((aligned(16))) float At[NPIX * LDK];
+    __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LDK];
+    __shared__ __attribute__((aligned(16))) float sstab[2 * 128];
+    const ConvDesc d = descs[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int ppx = d.Wp / PW, ppi = (d.Hp / PR) * ppx;
+    int imgs[2], y0s[2], x0s[2];
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+        const int q = PAIR ? 2 * blockIdx.x + sp : blockIdx.x;
+        imgs[sp] = q / ppi;
+        const int prem = q - imgs[sp] * ppi;
+        y0s[sp] = (prem / ppx) * PR; x0s[sp] = (prem % ppx) * PW;
+    }
+    const int g = imgs[0] >> 1;
+    const int img_base = PAIR ? 2 * g : imgs[0];
+    for (int c = tid; c < d.Cin; c += NT) {
+        const float2 e = rp_ldg2(reinterpret_cast<const float*>(d.src[0].ss + (size_t)g * d.src[0].sstride + c));
+        sstab[(c & ~3) * 2 + (c & 3)] = e.x; sstab[(c & ~3) * 2 + 4 + (c & 3)] = e.y;
+    }
+    const int kqa = tid % KQ;
+    const int a_lds0 = (tid / KQ) * LDK + kqa * 4;
+    // halo slot it = plane-tile pixel tid / 8 + PSTEP it: input pixel (2 (Y0 + r) - p, 2 (X0 + c) - q) of plane (p, q); a_in[it] is the
+    // (p, q) = (0, 0) pixel index relative to image img_base, a_edge[it] flags the slots that leave the image for p = 1 / p = 0 / q = 1 / q = 0
+    int a_in[A_SLOTS], a_edge = 0;
+#pragma unroll
+    for (int it = 0; it < A_SLOTS; ++it) {
+        const int pix = tid / KQ + it * PSTEP;
+        const int sp = (PAIR && pix >= SUBPIX) ? 1 : 0, lp = pix - sp * SUBPIX;
+        const int r = lp / HW1, c = lp - r * HW1;
+        const int iy = 2 * ((sp ? y0s[1] : y0s[0]) + r), ix = 2 * ((sp ? x0s[1] : x0s[0]) + c);
+        a_in[it] = (((sp ? imgs[1] : imgs[0]) - img_base) * d.Hin + iy) * d.Win + ix;
+        // p = 1 needs iy - 1 >= 0; p = 0 needs iy < Hin; same for columns; slots past the tile are always invalid
+        const int e = (pix >= NPIX) ? 15 : ((iy - 1 < 0 ? 1 : 0) | (iy >= d.Hin ? 2 : 0) | (ix - 1 < 0 ? 4 : 0) | (ix >= d.Win ? 8 : 0));
+        if (it < 8) a_edge |= e << (4 * it);                          // (slots 8.. : second word below)
+    }
+    int a_edge2 = 0;
+#pragma unroll
+    for (int it = 8; it < A_SLOTS; ++it) {
+        const int pix = tid / KQ + it * PSTEP;
+        const int sp = (PAIR && pix >= SUBPIX) ? 1 : 0, lp = pix - sp * SUBPIX;
+        const int r = lp / HW1, c = lp - r * HW1;
+        const int iy = 2 * ((sp ? y0s[1] : y0s[0]) + r), ix = 2 * ((sp ? x0s[1] : x0s[0]) + c);
+        const int e = (pix >= NPIX) ? 15 : ((iy - 1 < 0 ? 1 : 0) | (iy >= d.Hin ? 2 : 0) | (ix - 1 < 0 ? 4 : 0) | (ix >= d.Win ? 8 : 0));
+        a_edge2 |= e << (4 * (it - 8));
+    }
+    const size_t img_px = (size_t)img_base * d.Hin * d.Win;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(d.src[0].x + img_px * d.src[0].cstride), 0,
+                                                                         (PAIR ? 2 : 1) * d.Hin * d.Win * 4 * d.src[0].cstride, 0x00020000);
+    const int n0 = blockIdx.z * NI * 32;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.cout_pad * d.K * 4, 0x00020000);
+    int b_off[B_SLOTS];
+#pragma unroll
+    for (int it = 0; it < B_SLOTS; ++it) b_off[it] = ((n0 + tid / KQ + it * PSTEP) * d.K + kqa * 4) * 4;
+    const int b_lds0 = (tid / KQ) * LDK + kqa * 4;
+    floatx16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int try0 = PAIR ? TR * (wave & 1) : TR * MI * wave;
+    const int wsp = PAIR ? (wave >> 1) : 0;
+    int arow[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) arow[i] = (wsp * SUBPIX + (try0 + TR * i + l31 / TC) * HW1 + (l31 % TC)) * LDK + h * 4;
+    const int brow = l31 * LDK + h * 4;
+    const float slope = d.src[0].slope;
+    const int scs4 = d.src[0].cstride * 4;
+    float4 ra[A_SLOTS], rb[B_SLOTS];
+    const int nchunk = d.Cin / BK;
+    const int nstep = nchunk * 16;                                    // (chunk, plane, tap) steps: s = (chunk * 4 + plane) * 4 + tap
+
+    // plane pl = 2 p + q; step tap tt = 2 ty + tx -> kernel tap (ky, kx) = (p ? 2 ty : 1 + 2 ty, q ? 2 tx : 1 + 2 tx), K offset (ky * 4 + kx) * Cin
+#define RP_S2_LOAD_A(CH, PL)                                                                                   \
+    {                                                                                                         \
+        const int p_ = (PL) >> 1, q_ = (PL) & 1;                                                              \
+        const int bad_ = (p_ ? 1 : 2) | (q_ ? 4 : 8);                                                         \
+        const int dlt_ = p_ * d.Win + q_;                                                                     \
+        _Pragma("unroll") for (int it = 0; it < A_SLOTS; ++it) {                                              \
+            const int e_ = ((it < 8 ? a_edge : a_edge2) >> (4 * (it & 7))) & bad_;                            \
+            int px_ = a_in[it];                                                                               \
+            asm volatile("" : "+v"(px_));                                                                     \
+            const int voff_ = (e_ ? 0 : px_ - dlt_) * scs4 + kqa * 16;                                        \
+            ra[it] = rp_bufld4(rs_a, voff_, (CH) * BK * 4);                                                   \
+        }                                                                                                     \
+    }
+#define RP_S2_STORE_A(CH, PL)                                                                                  \
+    {                                                                                                         \
+        const int p_ = (PL) >> 1, q_ = (PL) & 1;                                                              \
+        const int bad_ = (p_ ? 1 : 2) | (q_ ? 4 : 8);                                                         \
+        const float4* qq = reinterpret_cast<const float4*>(&sstab[2 * ((CH) * BK + kqa * 4)]);                \
+        const float4 s0_ = qq[0], s1v_ = qq[1];                                                               \
+        const rp_v2f sl2_ = {slope, slope};                                                                   \
+        _Pragma("unroll") for (int it = 0; it < A_SLOTS; ++it) {                                              \
+            rp_v2f v01 = {ra[it].x, ra[it].y}, v23 = {ra[it].z, ra[it].w};                                    \
+            v01 = v01 * (rp_v2f){s0_.x, s0_.y} + (rp_v2f){s1v_.x, s1v_.y};                                    \
+            v23 = v23 * (rp_v2f){s0_.z, s0_.w} + (rp_v2f){s1v_.z, s1v_.w};                                    \
+            const rp_v2f t01 = v01 * sl2_, t23 = v23 * sl2_;                                                  \
+            const float okf_ = ((((it < 8 ? a_edge : a_edge2) >> (4 * (it & 7))) & bad_) == 0) ? 1.f : 0.f;   \
+            const rp_v2f mk_ = {okf_, okf_};                                                                  \
+            v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
+            v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
+            if ((it + 1) * PSTEP <= NPIX || tid / KQ + it * PSTEP < NPIX)                                     \
+                *reinterpret_cast<float4*>(&At[a_lds0 + it * PSTEP * LDK]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+        }                                                                                                     \
+    }
+#define RP_S2_LOAD_B(S)                                                                                        \
+    {                                                                                                         \
+        const int ch_ = (S) >> 4, pl_ = ((S) >> 2) & 3, tt_ = (S) & 3;                                        \
+        const int ky_ = (pl_ >> 1) ? 2 * (tt_ >> 1) : 1 + 2 * (tt_ >> 1), kx_ = (pl_ & 1) ? 2 * (tt_ & 1) : 1 + 2 * (tt_ & 1); \
+        const int so_ = ((ky_ * 4 + kx_) * d.Cin + ch_ * BK) * 4;                                             \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) rb[it] = rp_bufld4(rs_b, b_off[it], so_);       \
+    }
+#define RP_S2_STORE_B()                                                                                        \
+    {                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = rb[it]; \
+    }
+
+    RP_S2_LOAD_A(0, 0)
+    RP_S2_LOAD_B(0)
+    __syncthreads();                                                  // sstab
+    RP_S2_STORE_A(0, 0)
+    RP_S2_STORE_B()
+    __syncthreads();
+    for (int cp = 0; cp < nchunk * 4; ++cp) {                         // (chunk, plane)
+        const int ch = cp >> 2, pl = cp & 3;
+        const bool lastp = (cp + 1 == nchunk * 4);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int sidx = cp * 4 + tt;
+            if (sidx + 1 < nstep) RP_S2_LOAD_B(sidx + 1)
+            if (tt == 0 && !lastp) RP_S2_LOAD_A((cp + 1) >> 2, (cp + 1) & 3)
+            const int aoff = ((tt >> 1) * HW1 + (tt & 1)) * LDK;
+#pragma unroll
+            for (int kc = 0; kc < BK / 8; ++kc) {
+                float4 a[MI], b[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&At[arow[i] + aoff + kc * 8]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bt[brow + j * 32 * LDK + kc * 8]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+            if (sidx + 1 < nstep) RP_S2_STORE_B()
+            if (tt == 3 && !lastp) RP_S2_STORE_A((cp + 1) >> 2, (cp + 1) & 3)
+            __syncthreads();
+        }
+        (void)ch; (void)pl;
+    }
+#undef RP_S2_LOAD_A
+#undef RP_S2_STORE_A
+#undef RP_S2_LOAD_B
+#undef RP_S2_STORE_B
+
+    // epilogue: one BatchNorm record per workgroup (stat_bm = rows per workgroup, slot 0), then the NHWC stores
+    if (d.stat_part) {
+        double* red = reinterpret_cast<double*>(&At[0]);              // [NW][NI * 32][2]
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            double sm = 0.0, sq = 0.0;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const double v = (double)acc[i][j][r]; sm += v; sq += v * v; }
+            sm += rp_shfl_xor_d(sm, 32); sq += rp_shfl_xor_d(sq, 32);
+            if (h == 0) { red[((wave * NI + j) * 32 + l31) * 2] = sm; red[((wave * NI + j) * 32 + l31) * 2 + 1] = sq; }
+        }
+        __syncthreads();
+        if (tid < NI * 32) {
+            double a = 0, b = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { a += red[((w * NI) * 32 + tid) * 2]; b += red[((w * NI) * 32 + tid) * 2 + 1]; }
+            double* o = d.stat_part + (((size_t)blockIdx.x * 2) * d.cout_pad + n0 + tid) * 2;
+            rp_stg(o, a); rp_stg(o + 1, b);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ry = try0 + TR * i + rl / TC, cx = rl % TC;
+            const size_t pix = ((size_t)(wsp ? imgs[1] : imgs[0]) * d.Hout + (wsp ? y0s[1] : y0s[0]) + ry) * d.Wout + (wsp ? x0s[1] : x0s[0]) + cx;
+            float* yo = d.y + pix * d.ycstride + d.ychoff + n0 + l31;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (n0 + j * 32 + l31 < d.Cout) rp_stg(yo + j * 32, acc[i][j][r]);
+        }
+}
+
 // y[pix(m)][col] = sum over K slices (fixed order) of the partial tiles
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __restrict__ descs) {
     const ConvDesc d = descs[blockIdx.z];
@@ -1554,7 +1772,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6 };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7 };
 struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0, split = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
@@ -1702,6 +1920,25 @@ void Builder::end_group() {
         if (dtile && dt_cfg == 4) dtile = ((plan->descs[first].Hin / 8) * (Wg / 8) * 2) % 2 == 0 && n % 2 == 0;
         if (dtile) BMt = dt_cfg == 4 ? 128 : PRt * PWt;              // (4: a workgroup = two 8 x 8 patches)
     }
+    // Parity-plane kernel (conv_s2_tile_kernel): 4x4 stride-2 pad-1 convs of one source with Cout 64 on 16 x 16 output patches
+    // (conv2) or Cout 128 on pairs of 8 x 8 patches (conv3); fp32 products only.
+    int s2_cfg = -1;
+    {
+        static const bool no_s2 = getenv("RELPOSE_NO_CONV_S2") != nullptr;
+        const ConvDesc& d0 = plan->descs[first];
+        if (!no_s2 && !dtile && net->prec == 0) {
+            if (cp == 64 && d0.Hp % 16 == 0 && d0.Wp % 16 == 0) s2_cfg = 0;
+            else if (cp == 128 && d0.Hp % 8 == 0 && d0.Wp % 8 == 0 && ((d0.Hp / 8) * (d0.Wp / 8) * 2) % 2 == 0 && n % 2 == 0) s2_cfg = 1;
+        }
+        for (int i = first; i < first + count && s2_cfg >= 0; ++i) {
+            const ConvDesc& d = plan->descs[i];
+            const bool ok = d.osy == 1 && d.osx == 1 && d.sy == 2 && d.sx == 2 && d.ntaps == 16 && d.offy[0] == -1 && d.offx[0] == -1 && d.offy[15] == 2 &&
+                            d.offx[15] == 2 && d.nsrc == 1 && d.Cin <= 128 && d.src[0].sstride != 0 && !d.bias && d.Hin == 2 * d.Hp && d.Win == 2 * d.Wp &&
+                            d.Hp == d0.Hp && d.Wp == d0.Wp && d.Cout == cp;
+            if (!ok) s2_cfg = -1;
+        }
+        if (s2_cfg >= 0) BMt = s2_cfg == 0 ? 256 : 128;
+    }
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
     for (int i = first; i < first + count; ++i) {
@@ -1716,7 +1953,7 @@ void Builder::end_group() {
     }
     // split along K until the launch has >= ~3000 tiles (>= 4 waves of resident blocks), keeping >= 8 k-tiles per slice
     int ksplit = 1;
-    while (!dtile && tiles * ksplit < 3000 && ksplit < 64 && min_kt / (ksplit * 2) >= 8) ksplit *= 2;
+    while (!dtile && s2_cfg < 0 && tiles * ksplit < 3000 && ksplit < 64 && min_kt / (ksplit * 2) >= 8) ksplit *= 2;
     size_t pf = 0;
     for (int i = first; i < first + count; ++i) {
         ConvDesc& d = plan->descs[i];
@@ -1740,6 +1977,12 @@ void Builder::end_group() {
             d.stat_part = statp ? statp + plan->stat_doubles : (double*)(uintptr_t)8;   // non-null marker in the dry run
             plan->stat_doubles += nd;
         }
+    }
+    if (s2_cfg >= 0) {
+        Op o; o.type = OP_CONV_S2; o.first = first; o.count = count; o.cfg = s2_cfg;
+        o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count, 1);
+        plan->ops.push_back(o);
+        return;
     }
     if (dtile) {
         Op o; o.type = OP_DECONV_TILE; o.first = first; o.count = count; o.cfg = dt_cfg;
@@ -2074,6 +2317,11 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
             else RP_LAUNCH_T(4, 1, 1, 1);
 #undef RP_LAUNCH_T
 #undef RP_LAUNCH_V
+            mark(-1);
+        } else if (op.type == OP_CONV_S2) {
+            mark(1);
+            if (op.cfg == 0) hipLaunchKernelGGL((conv_s2_tile_kernel<2, 2, 16, false>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            else hipLaunchKernelGGL((conv_s2_tile_kernel<1, 4, 8, true>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             mark(-1);
         } else if (op.type == OP_DECONV_TILE) {
             mark(1);
