@@ -237,7 +237,8 @@ def worker(args):
             # split-16-bit modes: every fp32 product costs three dense 16-bit MFMA products -> algorithmic peak = 2500 / 3
             peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_F16_MFMA_TFLOPS / 3
             tr = _traffic(f"config{args.config}_{prec}_pairs{nloc}")
-            res["roofline"] = {"kernel": "conv_igemm_kernel (fp32 MFMA 32x32x2)" if f32 else f"conv_igemm_kernel (3 x {prec[:-2]} MFMA 32x32x16)",
+            res["roofline"] = {"kernel": "SCNet conv stack: conv_igemm_kernel + conv_s2_tile_kernel + deconv_tile_kernel + conv1_mfma_kernel + heads_kernel (fp32 MFMA 32x32x2)"
+                                         if f32 else f"conv_igemm_kernel (3 x {prec[:-2]} MFMA 32x32x16)",
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": tr["bytes"] if tr else None, "traffic_unit": "HBM bytes per forward (all conv launches; rocprofv3 PMC)",
                                "traffic_profile": tr["profile"] if tr else None,
@@ -246,7 +247,7 @@ def worker(args):
             # --- N x N affinity build at the bench batch and at a batch where the bytes are meaningful
             a_small = affinity_roofline(N, nloc, dev, sigmas)
             a_big = affinity_roofline(N, 1024, dev, sigmas)
-            res["roofline_affinity"] = {"kernel": "affinity_topk_kernel<true> (materialised fp32 wij)", "bound": "hbm", "unit": "GB/s",
+            res["roofline_affinity"] = {"kernel": "affinity_gram_kernel (batch 1024) / affinity_rows_kernel (bench batch), materialised fp32 wij", "bound": "hbm", "unit": "GB/s",
                                         "peak": PEAK_HBM_GBS, "achieved": a_big["achieved"], "frac": a_big["frac"], "traffic": None,
                                         "at_batch_1024": a_big, "at_bench_batch": a_small,
                                         "note": "headline = batch 1024 (one launch at the bench batch moves only "

@@ -19,3 +19,9 @@ done
 python tools/pmc_summary.py gpurun_out > gpurun_out/hbm_pmc.txt 2>&1
 tail -3 gpurun_out/hbm_pmc.txt; tail -4 gpurun_out/conv_layers.txt; cat gpurun_out/overlap.txt | head -8; cut -c1-300 gpurun_out/prof_bench.json
 ls gpurun_out/prof_bench | head
+# 5. the matcher alone (HIP events) + its kernel breakdown
+timeout 300 python tools/matcher_time.py 1 > gpurun_out/matcher_time.txt 2>&1
+timeout 300 python tools/matcher_time.py 2 >> gpurun_out/matcher_time.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace -d gpurun_out/mt -o p -- python tools/matcher_time.py 1 > gpurun_out/mt.log 2>&1
+python tools/kernel_stats.py gpurun_out/mt/p_results.db 2>&1 | grep -E "pair_|affinity|fit_pair|kernel  " > gpurun_out/matcher_kernels.txt
+tail -12 gpurun_out/matcher_time.txt; cat gpurun_out/matcher_kernels.txt
