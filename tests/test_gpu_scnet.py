@@ -112,6 +112,32 @@ def test_scnet_batched_groups_equal_single_pairs():
         assert torch.equal(y1, yb[2 * i:2 * i + 2]), i      # deterministic kernels: bitwise equal
 
 
+def test_scnet_tile_kernels_match_the_implicit_gemm_path(tmp_path):
+    """The round-2 tile kernels (deconv_tile, conv_s2_tile, conv1_mfma) against the one-kernel-for-everything path of round 1
+    (conv_igemm_kernel + conv1_direct_kernel; the switches are read once per process, hence the subprocess) on 2 BatchNorm groups:
+    same fp32 products, different summation order -> agreement at fp32 rounding level."""
+    import subprocess
+    import sys
+    import torch
+    tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
+    net, _ = make_net(S, tanh, seed)
+    x = torch.cat([torch.from_numpy(oracle_scnet_input(700 + i, ds, mm)) for i in range(2)])
+    y = net(x.cuda()).cpu().numpy()
+    np.save(tmp_path / "x.npy", x.numpy())
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, numpy as np, torch; sys.path[:0] = [%r, %r, %r];"
+            "from test_gpu_scnet import make_net; net, _ = make_net(%d, %d, %d);"
+            "np.save(%r, net(torch.from_numpy(np.load(%r)).cuda()).cpu().numpy())"
+            % (here, os.path.dirname(here), os.path.join(here, "golden"), S, tanh, seed,
+               str(tmp_path / "y_legacy.npy"), str(tmp_path / "x.npy")))
+    env = dict(os.environ, RELPOSE_NO_DECONV_TILE="1", RELPOSE_NO_CONV_S2="1", RELPOSE_CONV1_DIRECT="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    y0 = np.load(tmp_path / "y_legacy.npy")
+    err = float(np.abs(y - y0).max()), float(np.abs(y - y0).mean())
+    log("scnet_tile_vs_igemm", max_abs=err[0], mean_abs=err[1], out_absmax=float(np.abs(y0).max()))
+    assert err[0] < 2e-4 and err[1] < 1e-5, err          # measured 3.9e-5 / 1.9e-6 at an output scale of 8
+
+
 def test_scnet_rejects_odd_batch_like_reference():
     import torch
     tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
