@@ -781,7 +781,7 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
 // of every one of the 16 taps: 3.3-3.5x the global loads and transforms).  The weight tile of one tap is staged per k-step as before.
 // Geometry as in deconv_tile_kernel: TC == 16: patch 2 MI NW x 16 outputs, tiles stacked; PAIR: two 8 x 8 patches (56-wide grids).
 template <int MI, int NI, int TC, bool PAIR>
-__global__ __launch_bounds__(256, 3) void conv_s2_tile_kernel(const ConvDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int NW = 4, NT = 256, TR = 32 / TC;
     constexpr int PR = PAIR ? 8 : TR * MI * NW, PW = PAIR ? 8 : 16, HW1 = PW + 1;
     constexpr int SUBPIX = (PR + 1) * HW1, NPIX = (PAIR ? 2 : 1) * SUBPIX;
@@ -1927,7 +1927,8 @@ void Builder::end_group() {
         static const bool no_s2 = getenv("RELPOSE_NO_CONV_S2") != nullptr;
         const ConvDesc& d0 = plan->descs[first];
         if (!no_s2 && !dtile && net->prec == 0) {
-            if (cp == 64 && d0.Hp % 16 == 0 && d0.Wp % 16 == 0) s2_cfg = 0;
+            static const bool s2_small = getenv("RELPOSE_S2_SMALL") != nullptr;     // experiment: 8 x 16 patches, 4 workgroups per CU
+            if (cp == 64 && d0.Hp % 16 == 0 && d0.Wp % 16 == 0) s2_cfg = s2_small ? 2 : 0;
             else if (cp == 128 && d0.Hp % 8 == 0 && d0.Wp % 8 == 0 && ((d0.Hp / 8) * (d0.Wp / 8) * 2) % 2 == 0 && n % 2 == 0) s2_cfg = 1;
         }
         for (int i = first; i < first + count && s2_cfg >= 0; ++i) {
@@ -1937,7 +1938,7 @@ void Builder::end_group() {
                             d.Hp == d0.Hp && d.Wp == d0.Wp && d.Cout == cp;
             if (!ok) s2_cfg = -1;
         }
-        if (s2_cfg >= 0) BMt = s2_cfg == 0 ? 256 : 128;
+        if (s2_cfg >= 0) BMt = s2_cfg == 0 ? 256 : 128;              // (0: 16 x 16 patches; 1: pairs of 8 x 8; 2: 8 x 16)
     }
     int max_mt = 0, min_kt = 1 << 30;
     long tiles = 0;
@@ -2321,6 +2322,7 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         } else if (op.type == OP_CONV_S2) {
             mark(1);
             if (op.cfg == 0) hipLaunchKernelGGL((conv_s2_tile_kernel<2, 2, 16, false>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            else if (op.cfg == 2) hipLaunchKernelGGL((conv_s2_tile_kernel<1, 2, 16, false>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             else hipLaunchKernelGGL((conv_s2_tile_kernel<1, 4, 8, true>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             mark(-1);
         } else if (op.type == OP_DECONV_TILE) {
