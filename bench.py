@@ -177,7 +177,8 @@ def worker(args):
             first = (dj, pj, wj)
         batches.append(pipe.prepare(dj["rgb"], dj["norm"], dj["depth"], pj, wj, dev, keep_host=not args.no_h2d))
 
-    copy_stream = torch.cuda.Stream()
+    # RELPOSE_BENCH_COPY_STREAM=1: upload on a separate copy stream (a fifth stream: shares a hardware queue with one of the others)
+    copy_stream = torch.cuda.Stream() if os.environ.get("RELPOSE_BENCH_COPY_STREAM") else None
 
     def run_steps(k, h2d=False):
         """k steps = k batches of nloc pairs on this GPU, each followed by the pose gather; returns the last result."""
@@ -224,8 +225,8 @@ def worker(args):
             per_step_bytes = sum(t.numel() * t.element_size() for t in batches[0]["host"].values())
             res["pcie_inclusive"] = {"value": total * args.steps / dt_h2d, "unit": "pairs/s", "ms_per_step": dt_h2d / args.steps * 1e3,
                                      "h2d_bytes_per_step_per_gpu": per_step_bytes,
-                                     "note": "every step's panoramas + keypoints uploaded from pinned host memory on a copy stream, "
-                                             "overlapped with the previous step; never the headline value"}
+                                     "note": "every step's panoramas + keypoints uploaded from pinned host memory on the batch's own stream "
+                                             "(under the other in-flight batch's forward); never the headline value"}
         if not args.no_aux:
             # --- roofline of the dominant kernel: implicit-GEMM conv, HIP events on the launch stream
             x = torch.randn(2 * nloc, 16, h, 4 * h, device=dev)

@@ -77,6 +77,13 @@ class RelativePosePipeline:
         the previous use of the device buffers and before the batch's next use (both on st["stream"])."""
         import torch
         ms = st["stream"] if "stream" in st else torch.cuda.current_stream()
+        if copy_stream is None:
+            # on the batch's own (slot) stream: it is idle between the previous batch's last matcher and this batch's first
+            # warp, the other slot's forward runs meanwhile, and no fifth stream has to share a hardware queue (run_pipelined)
+            with torch.cuda.stream(ms):
+                for k, src in st["host"].items():
+                    st[k].copy_(src, non_blocking=True)
+            return
         copy_stream.wait_stream(ms)
         with torch.cuda.stream(copy_stream):
             for k, src in st["host"].items():
