@@ -65,6 +65,8 @@ def parse_args(argv=None):
     ap.add_argument("--keypoints", type=int, default=None)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--total-pairs", type=int, default=256, help="--scaling strong: pairs per step over all GPUs (configs[3]: 256)")
+    ap.add_argument("--gather", choices=["run", "step"], default="run",
+                    help="multi-GPU: one all_gather of every step's poses at the end of the run (default) or one per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-aux", action="store_true", help="skip the roofline / affinity side measurements (profiling runs)")
@@ -183,8 +185,17 @@ def worker(args):
     def run_steps(k, h2d=False):
         """k steps = k batches of nloc pairs on this GPU, each followed by the pose gather; returns the last result."""
         before = (lambda i, st: pipe.upload_inputs(st, copy_stream)) if h2d else None
-        return pipe.run_pipelined(batches, k, lambda i, pose, status: D.gather_poses(pose, status, total, world), depth=depth,
-                                  before_batch=before)[-1]
+        if world == 1 or args.gather == "step" or total % world:        # (ragged shards: the per-step gather pads every block)
+            return pipe.run_pipelined(batches, k, lambda i, pose, status: D.gather_poses(pose, status, total, world), depth=depth,
+                                      before_batch=before)[-1]
+        # --gather run (default): ONE collective for the whole run (north_star: "a single RCCL gather of the poses") -- the k steps'
+        # poses of this rank are stacked and gathered once, inside the timed region; no RCCL kernel shares a hardware queue with
+        # the SCNet / slot streams in steady state
+        res = pipe.run_pipelined(batches, k, None, depth=depth, before_batch=before)
+        pose = torch.stack([r[0] for r in res], 1).reshape(nloc * k, 4, 4)          # [pair, step] order: a rank's block stays contiguous
+        status = torch.stack([r[1] for r in res], 1).reshape(nloc * k)
+        gp, gs = D.gather_poses(pose, status, total * k, world)
+        return gp.reshape(total, k, 4, 4)[:, -1], gs.reshape(total, k)[:, -1]
 
     def timed(k, h2d=False):
         torch.cuda.synchronize()
@@ -219,7 +230,8 @@ def worker(args):
                           "batches_in_flight": depth, "prepared_batches_rotated": nbatch,
                           "dist_backend": dist.get_backend() if world > 1 else None,
                           "dist_world_size": dist.get_world_size() if world > 1 else 1,
-                          "collective": "one all_gather of [pairs,17] f64 (pose + status) per step"},
+                          "collective": ("one all_gather of [steps*pairs,17] f64 (pose + status) per run" if (args.gather == "run" and total % world == 0)
+                                         else "one all_gather of [pairs,17] f64 (pose + status) per step") if world > 1 else None},
                "status_ok_fraction": float((status == 0).double().mean().item())}
         if dt_h2d is not None:
             per_step_bytes = sum(t.numel() * t.element_size() for t in batches[0]["host"].values())
