@@ -70,7 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--no-aux", action="store_true", help="skip the roofline / affinity side measurements (profiling runs)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3"], default=None,
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3", "f16"], default=None,
                     help="conv arithmetic (default: the config's; f32 = exact fp32 MFMA = the parity configuration)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
@@ -221,8 +221,10 @@ def worker(args):
         res = {"metric": "scan-pairs/sec end-to-end (completion+feat+spectral-match), 160x640 RGB-D",
                "value": total * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-               "dtype": "f32" if f32 else f"f32 (conv products as 3 x {prec[:-2]} MFMA terms, fp32 accumulate: the configs[4] 'fp16 MFMA conv path'; "
-                                          "not the fp32 parity configuration)",
+               "dtype": "f32" if f32 else ("f16 (plain fp16 MFMA conv products, fp32 accumulate and fp32 BatchNorm statistics; not the fp32 parity configuration)"
+                                          if prec == "f16" else
+                                          f"f32 (conv products as 3 x {prec[:-2]} MFMA terms, fp32 accumulate: the configs[4] 'fp16 MFMA conv path'; "
+                                          "not the fp32 parity configuration)"),
                "data": "synthetic (seeded box-room RGB-D panoramas, injected keypoints, random-init weights)",
                "config": {"workload": cfg["label"], "baseline_config_index": args.config, "dataset": ds, "mask": mm, "pano": f"{h}x{4 * h}",
                           "pairs_per_step_total": total, "pairs_per_gpu": nloc, "keypoints": N, "semantic_classes": S,
@@ -248,10 +250,10 @@ def worker(args):
             flops = GFLOP_PER_IMAGE * 1e9 * 2 * nloc
             ach = flops / (g_ms * 1e-3) / 1e12
             # split-16-bit modes: every fp32 product costs three dense 16-bit MFMA products -> algorithmic peak = 2500 / 3
-            peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_F16_MFMA_TFLOPS / 3
+            peak = PEAK_F32_MFMA_TFLOPS if f32 else (PEAK_F16_MFMA_TFLOPS if prec == "f16" else PEAK_F16_MFMA_TFLOPS / 3)
             tr = _traffic(f"config{args.config}_{prec}_pairs{nloc}")
             res["roofline"] = {"kernel": "SCNet conv stack: conv_igemm_kernel + conv_s2_tile_kernel + deconv_tile_kernel + conv1_mfma_kernel + heads_kernel (fp32 MFMA 32x32x2)"
-                                         if f32 else f"conv_igemm_kernel (3 x {prec[:-2]} MFMA 32x32x16)",
+                                         if f32 else ("conv_igemm_kernel (fp16 MFMA 32x32x16)" if prec == "f16" else f"conv_igemm_kernel (3 x {prec[:-2]} MFMA 32x32x16)"),
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": tr["bytes"] if tr else None, "traffic_unit": "HBM bytes per forward (all conv launches; rocprofv3 PMC)",
                                "traffic_profile": tr["profile"] if tr else None,

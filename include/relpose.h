@@ -206,8 +206,10 @@ int64_t relpose_scnet_num_params(const RelposeSCNet* net);
  * into bfloat16 hi + lo and a*b ~= hi*hi + hi*lo + lo*hi runs on v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation (products exact to ~2^-16 instead of 2^-24; activations, BatchNorm statistics, conv1 and the heads
  * stay fp32).  RELPOSE_PREC_F16X3 (opt-in): the same with float16 halves (11 + 11 mantissa bits: products exact to
- * ~2^-21 for O(1) operands; float16 range, so inputs must stay below 65504).  May be switched at any time after finalize. */
-enum { RELPOSE_PREC_F32 = 0, RELPOSE_PREC_BF16X3 = 1, RELPOSE_PREC_F16X3 = 2 };
+ * ~2^-21 for O(1) operands; float16 range, so inputs must stay below 65504).  RELPOSE_PREC_F16 (opt-in): plain float16 products
+ * (the hi halves only, one v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and fp32 BatchNorm statistics: SURVEY 8d
+ * config 5's "fp16 MFMA convs"; products exact to 2^-11).  May be switched at any time after finalize. */
+enum { RELPOSE_PREC_F32 = 0, RELPOSE_PREC_BF16X3 = 1, RELPOSE_PREC_F16X3 = 2, RELPOSE_PREC_F16 = 3 };
 int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode);
 
 size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n_images, int32_t H, int32_t W);

@@ -38,6 +38,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int SPLIT> struct SplitT { typedef bf16x8 v8; typedef bf16x4 v4; };
 template <> struct SplitT<2> { typedef f16x8 v8; typedef f16x4 v4; };
+template <> struct SplitT<3> { typedef f16x8 v8; typedef f16x4 v4; };     // plain fp16 products (hi halves only), fp32 accumulate
 typedef float rp_f4v __attribute__((ext_vector_type(4)));
 
 #ifndef RP_ABLATE
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
                 const h4_ hi_ = __builtin_convertvector(vf_, h4_);                                                \
                 const h4_ lo_ = __builtin_convertvector(vf_ - __builtin_convertvector(hi_, rp_f4v), h4_);         \
                 h4_* ar_ = reinterpret_cast<h4_*>(&As[BUF][(lrow + it * RPI) * LDK]);                             \
-                ar_[kq] = hi_; ar_[8 + kq] = lo_;                                                                 \
+                ar_[kq] = hi_;                                                                                    \
+                if (SPLIT != 3) ar_[8 + kq] = lo_;                                                                \
             }                                                                                                     \
         }                                                                                                         \
         if (BN >= RPI || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb[0];            \
@@ -337,18 +339,20 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     ah[i] = *reinterpret_cast<const h8*>(&As[buf][arow + i * 32 * LDK + st * 8]);
-                    al[i] = *reinterpret_cast<const h8*>(&As[buf][arow + i * 32 * LDK + 16 + st * 8]);
+                    if (SPLIT != 3) al[i] = *reinterpret_cast<const h8*>(&As[buf][arow + i * 32 * LDK + 16 + st * 8]);
                 }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     bh[j] = *reinterpret_cast<const h8*>(&Bs[buf][brow + j * 32 * LDK + st * 8]);
-                    bl[j] = *reinterpret_cast<const h8*>(&Bs[buf][brow + j * 32 * LDK + 16 + st * 8]);
+                    if (SPLIT != 3) bl[j] = *reinterpret_cast<const h8*>(&Bs[buf][brow + j * 32 * LDK + 16 + st * 8]);
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        if constexpr (SPLIT == 1) {
+                        if constexpr (SPLIT == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        } else if constexpr (SPLIT == 1) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
     }
 #undef RP_ISSUE_LOADS
 #undef RP_STORE_TILE
-    if constexpr (SPLIT == 2) {                        // undo the power-of-two weight pre-scale (exact)
+    if constexpr (SPLIT == 2 || SPLIT == 3) {          // undo the power-of-two weight pre-scale (exact)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1847,8 +1851,8 @@ void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, con
         }
         d.ntaps = P.ntaps;
         memcpy(d.offy, P.offy, 16); memcpy(d.offx, P.offx, 16);
-        d.w = net->d_w + ((net->prec == 1 && P.ws_off) ? P.ws_off : (net->prec == 2 && P.wh_off) ? P.wh_off : P.w_off);
-        d.wscale = (net->prec == 2 && P.wh_off) ? P.wh_scale : 1.f;
+        d.w = net->d_w + ((net->prec == 1 && P.ws_off) ? P.ws_off : (net->prec >= 2 && P.wh_off) ? P.wh_off : P.w_off);
+        d.wscale = (net->prec >= 2 && P.wh_off) ? P.wh_scale : 1.f;
         d.Cout = L.cout; d.cout_pad = L.cout_pad;
         d.y = buf(out); d.Hout = Hout; d.Wout = Hout; d.ycstride = (out == "OUT") ? net->cf : O.C; d.ychoff = ochoff;
         d.bias = (L.kind == 2) ? net->d_w + L.bias_off : nullptr;
@@ -2142,7 +2146,7 @@ int64_t relpose_scnet_num_params(const RelposeSCNet* net) {
 }
 
 int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode) {
-    if (!net || mode < RELPOSE_PREC_F32 || mode > RELPOSE_PREC_F16X3) return RELPOSE_EINVAL;
+    if (!net || mode < RELPOSE_PREC_F32 || mode > RELPOSE_PREC_F16) return RELPOSE_EINVAL;
     if (net->prec != mode) { net->prec = mode; free_plan(net); }     // the launch plans hold weight pointers and kernel variants
     return 0;
 }
@@ -2300,6 +2304,10 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
                     if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 2);                                \
                     else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 2);                        \
                     else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, 2);                                     \
+                } else if (op.split == 3) {                                                                    \
+                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 3);                                \
+                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 3);                        \
+                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, 3);                                     \
                 } else {                                                                                       \
                     if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 0);                                \
                     else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 0);                        \

@@ -100,9 +100,9 @@ class SCNet:
         return self.load_state_dict(load_checkpoint(path))
 
     def set_precision(self, mode):
-        """'f32' (default, the parity configuration), 'bf16x3' or 'f16x3' (split 16-bit MFMA products, fp32 accumulation:
-        relpose_scnet_set_precision).  Not part of the reference interface."""
-        code = {"f32": 0, "bf16x3": 1, "f16x3": 2}[mode]
+        """'f32' (default, the parity configuration), 'bf16x3' or 'f16x3' (split 16-bit MFMA products, fp32 accumulation) or 'f16'
+        (plain fp16 MFMA products, fp32 accumulation): relpose_scnet_set_precision.  Not part of the reference interface."""
+        code = {"f32": 0, "bf16x3": 1, "f16x3": 2, "f16": 3}[mode]
         _lib.check(_lib.lib().relpose_scnet_set_precision(self._h, code), "relpose_scnet_set_precision")
         return self
 

@@ -146,7 +146,7 @@ def test_scnet_rejects_odd_batch_like_reference():
         net(torch.zeros(1, 16, 160, 640, device="cuda"))
 
 
-@pytest.mark.parametrize("mode,bound_max,bound_mean", [("f16x3", 5e-4, 2e-5), ("bf16x3", 2e-3, 1e-4)])
+@pytest.mark.parametrize("mode,bound_max,bound_mean", [("f16x3", 5e-4, 2e-5), ("bf16x3", 2e-3, 1e-4), ("f16", 1e-1, 5e-3)])
 @pytest.mark.parametrize("hw", [(160, 640), (320, 1280)])
 def test_scnet_split_precision_options_close_to_f32_and_reversible(hw, mode, bound_max, bound_mean):
     """relpose_scnet_set_precision(F16X3 / BF16X3): split 16-bit MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate) are
