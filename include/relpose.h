@@ -218,6 +218,13 @@ size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n_images, 
  * consecutive group of 2 images (the reference always feeds batch 2, evaluation.py:242). */
 int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The same forward with its HBM-bound ends -- the head (input resize mymodel.py:261 + conv1* :266-286) and the tail (the five 1x1
+ * heads deconv1* :312-376 + the final resize :379) -- enqueued on `tail_stream` and the MFMA-bound middle on `stream`, ordered by
+ * events: `stream` is busy with this forward only between conv2 and deconv2, so the next forward -- of ANOTHER workspace -- overlaps
+ * its convolutions with this head / tail (pipeline.run_pipelined).  x is read and `out` written on tail_stream only.
+ * tail_stream == stream is relpose_scnet_forward. */
+int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
+                           void* workspace, size_t workspace_bytes, void* stream, void* tail_stream);
 
 /* Debug: copy a raw (pre-BatchNorm) layer output of the last forward, NHWC float32, to out (device).
  * Returns the number of floats written (or needed if out is NULL), <0 if unknown. */

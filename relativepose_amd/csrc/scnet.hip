@@ -1786,6 +1786,9 @@ struct Plan {
     size_t splitk_floats = 0;
     size_t stat_doubles = 0;     // per-tile BatchNorm records of all fused-statistics groups
     ConvDesc* d_descs = nullptr; // device copy of `descs`
+    int tail_first = -1;         // first op of the forward's tail (the heads; resize_out follows): relpose_scnet_forward2 moves it to a second stream
+    int head_count = 0;          // ops of the forward's head (conv1 + its BatchNorm finalize; resize_in precedes): second stream as well
+    hipEvent_t tail_ev = nullptr, head_ev = nullptr;
 };
 
 struct Builder {
@@ -2038,6 +2041,7 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     { Op o; o.type = OP_CONV1; o.first = o.count = o.cfg = 0; R.plan->ops.push_back(o); }   // direct kernel
     R.stats("A1");
     R.plan->ops.back().cfg = 1;                   // partial records already written by conv1_direct_kernel
+    R.plan->head_count = (int)R.plan->ops.size();
     R.begin_group();
     for (int q = 0; q < 6; ++q) R.conv(std::string("conv2") + mods[q / 2], R.src("A1", q * 32, 32), nullptr, 224, "A2", q * 64);
     R.end_group(); R.stats("A2");
@@ -2072,6 +2076,7 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     R.begin_group();
     for (int m = 3; m < 5; ++m) R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), nullptr, 112, "D2", d2off[m]);
     R.end_group(); R.stats("D2");
+    R.plan->tail_first = (int)R.plan->ops.size();
     if (getenv("RELPOSE_GEMM_HEADS") || (net->S != 15 && net->S != 21)) {   // generic implicit-GEMM path (5 members)
         const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
         R.begin_group();
@@ -2088,6 +2093,8 @@ void free_plan(RelposeSCNet* net) {
     for (auto& kv : net->plans) {
         Plan* p = (Plan*)kv.second;
         if (p->d_descs) (void)hipFree(p->d_descs);
+        if (p->tail_ev) (void)hipEventDestroy(p->tail_ev);
+        if (p->head_ev) (void)hipEventDestroy(p->head_ev);
         delete p;
     }
     net->plans.clear();
@@ -2250,6 +2257,11 @@ size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n, int32_t
 
 int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                           size_t workspace_bytes, void* stream) {
+    return relpose_scnet_forward2(net, x, out, n, H, W, workspace, workspace_bytes, stream, stream);
+}
+
+int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
+                           size_t workspace_bytes, void* stream, void* tail_stream) {
     if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0) return RELPOSE_EINVAL;
     const int G = n / 2;
     Plan* plan = nullptr;
@@ -2273,7 +2285,10 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
         net->plans[std::make_pair(workspace, (int)n)] = plan;
     }
     net->last_n = n;
-    hipStream_t s = (hipStream_t)stream;
+    // two-stream mode: the HBM-bound head (resize_in, conv1) and tail (heads, resize_out) run on tail_stream, the MFMA-bound middle on `stream`
+    static const bool head_side = getenv("RELPOSE_NO_HEAD_OVERLAP") == nullptr;
+    const bool two = tail_stream != stream;
+    hipStream_t s = (two && head_side && plan->head_count > 0) ? (hipStream_t)tail_stream : (hipStream_t)stream;
     const WsOffsets o = ws_offsets(net, n);
     char* ws = (char*)workspace;
     float* act = (float*)(ws + o.act);
@@ -2287,7 +2302,23 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
     mark(3);
     hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, s, x, act + net->bufs["X0"].off * n, n, H, W);
     mark(-3);
+    int op_index = -1;
     for (const Op& op : plan->ops) {
+        ++op_index;
+        if (op_index == plan->head_count && s != (hipStream_t)stream) {      // head done: the convolutions continue on `stream`
+            if (!plan->head_ev) RP_HIP(hipEventCreateWithFlags(&plan->head_ev, hipEventDisableTiming));
+            RP_HIP(hipEventRecord(plan->head_ev, s));
+            s = (hipStream_t)stream;
+            RP_HIP(hipStreamWaitEvent(s, plan->head_ev, 0));
+        }
+        if (op_index == plan->tail_first && two) {
+            // the HBM-bound tail (heads, resize_out) continues on the caller's second stream, ordered behind everything above;
+            // `stream` is free for the next forward (which must use another workspace)
+            if (!plan->tail_ev) RP_HIP(hipEventCreateWithFlags(&plan->tail_ev, hipEventDisableTiming));
+            RP_HIP(hipEventRecord(plan->tail_ev, s));
+            s = (hipStream_t)tail_stream;
+            RP_HIP(hipStreamWaitEvent(s, plan->tail_ev, 0));
+        }
         if (op.type == OP_CONV) {
             mark(1);
             const ConvDesc* dd = plan->d_descs + op.first;

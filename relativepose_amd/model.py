@@ -109,12 +109,12 @@ class SCNet:
     def num_params(self):
         return int(_lib.lib().relpose_scnet_num_params(self._h))
 
-    def _workspace(self, n, H, W, dev):
+    def _workspace(self, n, H, W, dev, ws_key=None):
         import torch
         nbytes = _lib.lib().relpose_scnet_workspace_bytes(self._h, n, H, W)
         if nbytes == 0:
             raise RuntimeError("relpose_scnet_workspace_bytes: invalid shape (n must be even) or weights not loaded")
-        key = (torch.cuda.current_stream().cuda_stream, n, dev.index)
+        key = (torch.cuda.current_stream().cuda_stream if ws_key is None else ("key", ws_key), n, dev.index)
         ws = self._wss.get(key)
         if ws is None or ws.numel() < nbytes:
             if len(self._wss) >= 8:
@@ -124,7 +124,10 @@ class SCNet:
         self._ws = ws
         return ws
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, tail_stream=None, ws_key=None):
+        """tail_stream (a torch stream; not part of the reference interface): run the HBM-bound tail of the forward (heads + final
+        resize) there, behind the convolutions on the current stream (relpose_scnet_forward2) -- `out` is then valid on tail_stream only.
+        ws_key: name of the workspace to use (forwards that may overlap need different workspaces; default: one per stream)."""
         import torch
         dev = _lib.require_gpu()
         if not self._loaded:
@@ -132,10 +135,14 @@ class SCNet:
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 16
         x = x.contiguous()
         n, _, H, W = x.shape
-        ws = self._workspace(n, H, W, x.device)
+        ws = self._workspace(n, H, W, x.device, ws_key)
         if out is None:
             out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
-        rc = _lib.lib().relpose_scnet_forward(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        if tail_stream is None:
+            rc = _lib.lib().relpose_scnet_forward(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        else:
+            rc = _lib.lib().relpose_scnet_forward2(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(),
+                                                   C.c_void_p(tail_stream.cuda_stream))
         _lib.check(rc, "relpose_scnet_forward")
         return out
 

@@ -11,6 +11,8 @@ B scan pairs and kept on the device from the input panoramas to the 4x4 poses:
 Keypoints are an input (the reference detects them with cv2 SIFT + random
 sampling, rputil.getKeypoint; not part of this build -- SURVEY.md §8a a6.3).
 """
+import os
+
 import numpy as np
 
 from . import rpmodule, util
@@ -34,6 +36,8 @@ class RelativePosePipeline:
         self.sigmas = np.asarray(sigmas, dtype=np.float64).reshape(-1, 4)
         self.feat_off = 7 + net.snumclass
         self._slot_streams = []
+        # RELPOSE_TAIL_OVERLAP=0: the whole forward on the SCNet stream (pipelined modes)
+        self.tail_overlap = os.environ.get("RELPOSE_TAIL_OVERLAP", "1") != "0"
 
     def prepare(self, rgb, norm, depth, pts, ptw, device, keep_host=False):
         """Host arrays (dataset dict layout: rgb/norm [B,2,3,h,4h], depth [B,2,h,4h] f32; pts [B,2,N,2],
@@ -231,12 +235,20 @@ class RelativePosePipeline:
                 # every SCNet forward of every batch in flight goes to ONE dedicated stream, in enqueue order
                 ms, ns = torch.cuda.current_stream(), self._net_stream
                 ns.wait_stream(ms)
-                with torch.cuda.stream(ns):
-                    f = self.net(x)
-                    done = torch.cuda.Event()
-                    done.record()
-                ms.wait_event(done)
-                f.record_stream(ms)        # allocated under the net stream, consumed on the batch stream
+                if self.tail_overlap:
+                    # the convolutions on the SCNet stream, the HBM-bound tail (heads + resize, 1.9 ms) on this batch's own stream: the
+                    # SCNet stream goes straight on to the other batch's forward, whose MFMA-bound convs overlap this tail.  Overlapping
+                    # forwards need separate workspaces: one per stream (= per in-flight slot).
+                    f = torch.empty(x.shape[0], self.net.out_channels, x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+                    with torch.cuda.stream(ns):
+                        self.net.forward(x, out=f, tail_stream=ms, ws_key=ms.cuda_stream)
+                else:
+                    with torch.cuda.stream(ns):
+                        f = self.net(x)
+                        done = torch.cuda.Event()
+                        done.record()
+                    ms.wait_event(done)
+                    f.record_stream(ms)        # allocated under the net stream, consumed on the batch stream
                 yield                                            # one yield per level: the other batches enqueue theirs
             else:
                 f = self.net(x)
