@@ -995,6 +995,183 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
         }
 }
 
+// ---- stride-2 4x4 convs on parity planes, LINEAR tiles (conv4, conv5: 28 x 28 / 14 x 14 grids that do not tile into patches) ----------
+// Same decomposition as conv_s2_tile_kernel, but the M tile is 128 consecutive output pixels (like conv_igemm_kernel) and the plane
+// pixels are staged as a STRIP: in the padded plane of (Hp + 1) x (Wp + 1) positions per image (local (r, c) = input pixel
+// (2r - p, 2c - q); row Hp / column Wp and the p = 1 / q = 1 first row / column are zero padding) output (img, y, x) sits at position
+// P = (img (Hp + 1) + y)(Wp + 1) + x and its four taps at P + {0, 1, Wp + 1, Wp + 2}.  A tile's taps therefore lie in ONE contiguous
+// position range of <= BM + BM / Wp + 2 (Wp + 1) + 4 (+ Wp + 1 when the tile crosses an image) <= 224 positions, staged once per
+// chunk and plane (conv_igemm_kernel: 4 x 128 rows).  Any Wp; a tile may span two images / two BatchNorm groups (scale / shift of both
+// groups in registers, selected per staged position).  Used for split-K layers only: the epilogue writes partial sums
+// [ks][M][cout_pad], reduced (and BatchNorm statistics taken) by the existing kernels.
+template <int NI>
+__global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* __restrict__ descs) {
+    constexpr int BM = 128, SMAX = 224, PSTEP = 256 / KQ, A_SLOTS = SMAX / PSTEP, B_ROWS = NI * 32, B_SLOTS = B_ROWS / PSTEP;
+    static_assert(BK == 32 && SMAX % PSTEP == 0 && B_ROWS % PSTEP == 0, "slot layout");
+    __shared__ __attribute__((aligned(16))) float At[SMAX * LDK];
+    __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LDK];
+    const ConvDesc d = descs[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int ks = blockIdx.y / d.ntiles_n, n0 = (blockIdx.y - ks * d.ntiles_n) * NI * 32;
+    const int m0 = blockIdx.x * BM, hw = d.Hp * d.Wp, W1 = d.Wp + 1, H1 = d.Hp + 1, img_pos = H1 * W1;
+    auto pos_of = [&](int m) { const int img = m / hw, rem = m - img * hw; const int y = rem / d.Wp; return (img * H1 + y) * W1 + (rem - y * d.Wp); };
+    const int pmin = pos_of(m0);
+    const int nvalid = pos_of(min(m0 + BM, d.M) - 1) + W1 + 2 - pmin;          // staged positions (host guarantees <= SMAX)
+    const int g0 = (m0 / hw) >> 1;                                             // first BatchNorm group of the tile; rsrc starts at image 2 g0
+    const int kqa = tid % KQ;
+    const int a_lds0 = (tid / KQ) * LDK + kqa * 4;
+    // slot it = position pmin + tid / 8 + PSTEP it: input pixel index of plane (0, 0) relative to image 2 g0, edge bits (as in
+    // conv_s2_tile_kernel) and the BatchNorm group (0 / 1 relative to g0), packed: a_in[it] = index, bits in a_edge (4 per slot) / a_grp
+    int a_in[A_SLOTS], a_edge = 0, a_grp = 0;
+#pragma unroll
+    for (int it = 0; it < A_SLOTS; ++it) {
+        const int sl = tid / KQ + it * PSTEP;
+        const int pos = pmin + sl;
+        const int img = pos / img_pos, rem = pos - img * img_pos;
+        const int r = rem / W1, c = rem - r * W1;
+        const int iy = 2 * r, ix = 2 * c;
+        a_in[it] = ((img - 2 * g0) * d.Hin + iy) * d.Win + ix;
+        const int e = (sl >= nvalid || img >= d.Nimg) ? 15 : ((iy - 1 < 0 ? 1 : 0) | (iy >= d.Hin ? 2 : 0) | (ix - 1 < 0 ? 4 : 0) | (ix >= d.Win ? 8 : 0));
+        a_edge |= e << (4 * it);
+        a_grp |= (((img >> 1) - g0) & 1) << it;
+    }
+    static_assert(A_SLOTS <= 8, "edge bits in one register");
+    const size_t base_px = (size_t)(2 * g0) * d.Hin * d.Win;
+    const int nimg_left = min(4, d.Nimg - 2 * g0);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(d.src[0].x + base_px * d.src[0].cstride), 0,
+                                                                         nimg_left * d.Hin * d.Win * 4 * d.src[0].cstride, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.cout_pad * d.K * 4, 0x00020000);
+    // scale / shift of the two groups the tile can touch (clamped to the last group)
+    const int ng = d.Nimg / 2;
+    const float* ss0 = reinterpret_cast<const float*>(d.src[0].ss + (size_t)g0 * d.src[0].sstride) + kqa * 8;
+    const float* ss1 = reinterpret_cast<const float*>(d.src[0].ss + (size_t)min(g0 + 1, ng - 1) * d.src[0].sstride) + kqa * 8;
+    int b_off[B_SLOTS];
+#pragma unroll
+    for (int it = 0; it < B_SLOTS; ++it) b_off[it] = ((n0 + tid / KQ + it * PSTEP) * d.K + kqa * 4) * 4;
+    const int b_lds0 = (tid / KQ) * LDK + kqa * 4;
+    floatx16 acc[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int mrow = min(m0 + 32 * wave + l31, d.M - 1);                        // this lane's MFMA row (rows past M are never stored)
+    const int arow = (pos_of(mrow) - pmin) * LDK + h * 4;
+    const int brow = l31 * LDK + h * 4;
+    const float slope = d.src[0].slope;
+    const int scs4 = d.src[0].cstride * 4;
+    const int nchunk = d.Cin / BK;
+    const int cpk = (nchunk + d.ksplit - 1) / d.ksplit;
+    const int ch_begin = ks * cpk, ch_end = min(nchunk, ch_begin + cpk);
+    float4 ra[A_SLOTS], rb[B_SLOTS];
+    float4 sc0a, sc0b, sc1a, sc1b;                                             // {scale, shift} pairs of the thread's 4 channels, groups g0 / g0 + 1
+
+#define RP_ST_LOAD_SS(CH)                                                                                       \
+    { sc0a = rp_ldg4(ss0 + (CH) * BK * 2); sc0b = rp_ldg4(ss0 + (CH) * BK * 2 + 4);                               \
+      sc1a = rp_ldg4(ss1 + (CH) * BK * 2); sc1b = rp_ldg4(ss1 + (CH) * BK * 2 + 4); }
+#define RP_ST_LOAD_A(CH, PL)                                                                                   \
+    {                                                                                                         \
+        const int p_ = (PL) >> 1, q_ = (PL) & 1;                                                              \
+        const int bad_ = (p_ ? 1 : 2) | (q_ ? 4 : 8);                                                         \
+        const int dlt_ = p_ * d.Win + q_;                                                                     \
+        _Pragma("unroll") for (int it = 0; it < A_SLOTS; ++it) {                                              \
+            const int e_ = (a_edge >> (4 * it)) & bad_;                                                       \
+            int px_ = a_in[it];                                                                               \
+            asm volatile("" : "+v"(px_));                                                                     \
+            const int voff_ = (e_ ? 0 : px_ - dlt_) * scs4 + kqa * 16;                                        \
+            ra[it] = rp_bufld4(rs_a, voff_, (CH) * BK * 4);                                                   \
+        }                                                                                                     \
+    }
+#define RP_ST_STORE_A(PL)                                                                                      \
+    {                                                                                                         \
+        const int p_ = (PL) >> 1, q_ = (PL) & 1;                                                              \
+        const int bad_ = (p_ ? 1 : 2) | (q_ ? 4 : 8);                                                         \
+        const rp_v2f sl2_ = {slope, slope};                                                                   \
+        _Pragma("unroll") for (int it = 0; it < A_SLOTS; ++it) {                                              \
+            const bool g1_ = (a_grp >> it) & 1;                                                               \
+            const float4 qa_ = g1_ ? sc1a : sc0a, qb_ = g1_ ? sc1b : sc0b;     /* {s0, h0, s1, h1}, {s2, h2, s3, h3} */ \
+            rp_v2f v01 = {ra[it].x, ra[it].y}, v23 = {ra[it].z, ra[it].w};                                    \
+            v01 = v01 * (rp_v2f){qa_.x, qa_.z} + (rp_v2f){qa_.y, qa_.w};                                      \
+            v23 = v23 * (rp_v2f){qb_.x, qb_.z} + (rp_v2f){qb_.y, qb_.w};                                      \
+            const rp_v2f t01 = v01 * sl2_, t23 = v23 * sl2_;                                                  \
+            const float okf_ = (((a_edge >> (4 * it)) & bad_) == 0) ? 1.f : 0.f;                              \
+            const rp_v2f mk_ = {okf_, okf_};                                                                  \
+            v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
+            v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
+            *reinterpret_cast<float4*>(&At[a_lds0 + it * PSTEP * LDK]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+        }                                                                                                     \
+    }
+#define RP_ST_LOAD_B(S)                                                                                        \
+    {                                                                                                         \
+        const int ch_ = (S) >> 4, pl_ = ((S) >> 2) & 3, tt_ = (S) & 3;                                        \
+        const int ky_ = (pl_ >> 1) ? 2 * (tt_ >> 1) : 1 + 2 * (tt_ >> 1), kx_ = (pl_ & 1) ? 2 * (tt_ & 1) : 1 + 2 * (tt_ & 1); \
+        const int so_ = ((ky_ * 4 + kx_) * d.Cin + ch_ * BK) * 4;                                             \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) rb[it] = rp_bufld4(rs_b, b_off[it], so_);       \
+    }
+#define RP_ST_STORE_B()                                                                                        \
+    {                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = rb[it]; \
+    }
+
+    if (ch_begin < ch_end) {
+        const int s_begin = ch_begin * 16, s_end = ch_end * 16;                // (chunk, plane, tap) steps: s = (chunk * 4 + plane) * 4 + tap
+        RP_ST_LOAD_SS(ch_begin)
+        RP_ST_LOAD_A(ch_begin, 0)
+        RP_ST_LOAD_B(s_begin)
+        RP_ST_STORE_A(0)
+        RP_ST_STORE_B()
+        __syncthreads();
+        for (int cp = ch_begin * 4; cp < ch_end * 4; ++cp) {                   // (chunk, plane)
+            const bool lastp = (cp + 1 == ch_end * 4);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int sidx = cp * 4 + tt;
+                if (sidx + 1 < s_end) RP_ST_LOAD_B(sidx + 1)
+                if (tt == 0 && !lastp) {
+                    RP_ST_LOAD_A((cp + 1) >> 2, (cp + 1) & 3)
+                    // last plane of a chunk: all four planes of this chunk are stored already, so the next chunk's scale / shift
+                    // can be fetched straight into the registers (consumed when its plane 0 is stored, 4 taps from now)
+                    if (((cp + 1) & 3) == 0) RP_ST_LOAD_SS((cp + 1) >> 2)
+                }
+                const int aoff = ((tt >> 1) * W1 + (tt & 1)) * LDK;
+#pragma unroll
+                for (int kc = 0; kc < BK / 8; ++kc) {
+                    float4 b[NI];
+                    const float4 a = *reinterpret_cast<const float4*>(&At[arow + aoff + kc * 8]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bt[brow + j * 32 * LDK + kc * 8]);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[j].x, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[j].y, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[j].z, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[j].w, acc[j], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+                if (sidx + 1 < s_end) RP_ST_STORE_B()
+                if (tt == 3 && !lastp) {
+                    RP_ST_STORE_A((cp + 1) & 3)
+                }
+                __syncthreads();
+            }
+        }
+    }
+#undef RP_ST_LOAD_SS
+#undef RP_ST_LOAD_A
+#undef RP_ST_STORE_A
+#undef RP_ST_LOAD_B
+#undef RP_ST_STORE_B
+    // partial sums of this K slice (an empty slice writes zeros): reduced in fixed order by splitk_reduce_kernel
+    float* po = d.partial + (size_t)ks * d.M * d.cout_pad;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= d.M) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) rp_stg(po + (size_t)m * d.cout_pad + n0 + j * 32 + l31, acc[j][r]);
+    }
+}
+
 // y[pix(m)][col] = sum over K slices (fixed order) of the partial tiles
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __restrict__ descs) {
     const ConvDesc d = descs[blockIdx.z];
@@ -1776,7 +1953,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7 };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7, OP_CONV_STRIP = 8 };
 struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0, split = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
@@ -1997,6 +2174,24 @@ void Builder::end_group() {
         o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count / 4, dt_cfg >= 2 ? cp / 32 : 1);
         plan->ops.push_back(o);
         return;
+    }
+    {   // split-K stride-2 4x4 convs of one source with Cout a multiple of 128 (conv4, conv5): the strip kernel
+        static const bool no_strip = getenv("RELPOSE_NO_CONV_STRIP") != nullptr;
+        const ConvDesc& d = plan->descs[first];
+        const int hw = d.Hp * d.Wp;
+        bool ok = !no_strip && net->prec == 0 && count == 1 && ksplit > 1 && cfg == 0 && cp % 128 == 0 && d.osy == 1 && d.osx == 1 && d.sy == 2 && d.sx == 2 &&
+                  d.ntaps == 16 && d.offy[0] == -1 && d.offx[0] == -1 && d.offy[15] == 2 && d.offx[15] == 2 && d.nsrc == 1 && d.src[0].sstride != 0 && !d.bias &&
+                  d.Hin == 2 * d.Hp && d.Win == 2 * d.Wp && hw >= 128;
+        // staged positions of a 128-pixel tile: 127 + row wraps + one image crossing + the taps' reach
+        ok = ok && 127 + (127 + d.Wp - 1) / d.Wp + (d.Wp + 1) + (d.Wp + 1) + 2 <= 224;
+        if (ok) {
+            Op o; o.type = OP_CONV_STRIP; o.first = first; o.count = 1; o.cfg = 0;
+            o.grid = dim3((unsigned)((d.M + 127) / 128), (cp / 128) * ksplit, 1);
+            plan->ops.push_back(o);
+            Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
+            plan->ops.push_back(r);
+            return;
+        }
     }
     Op o; o.type = OP_CONV; o.first = first; o.count = count; o.cfg = cfg;
     // runs of 4 consecutive members that are the phases of one stride-2 transposed conv share their input tile
@@ -2357,6 +2552,10 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
             else RP_LAUNCH_T(4, 1, 1, 1);
 #undef RP_LAUNCH_T
 #undef RP_LAUNCH_V
+            mark(-1);
+        } else if (op.type == OP_CONV_STRIP) {
+            mark(1);
+            hipLaunchKernelGGL((conv_s2_strip_kernel<4>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             mark(-1);
         } else if (op.type == OP_CONV_S2) {
             mark(1);

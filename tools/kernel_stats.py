@@ -56,7 +56,7 @@ def conv_layers(rows, n=64, which=3):
          ('deconv3 x5', 4 * (3 * P(n * 3136, 1024, 64) + 2 * P(n * 3136, 512, 64))),
          ('deconv2 rgb/n/d', 12 * P(n * 12544, 512, 32)), ('deconv2 s/f', 8 * P(n * 12544, 256, 64)),
          ('heads', sum(P(n * 50176, 64, c) for c in (3, 3, 1, 15, 32)))]
-    isconv = lambda nm: 'conv_igemm' in nm or 'deconv_tile' in nm or 'conv_s2_tile' in nm      # the implicit-GEMM launches, in network order
+    isconv = lambda nm: 'conv_igemm' in nm or 'deconv_tile' in nm or 'conv_s2_tile' in nm or 'conv_s2_strip' in nm      # the implicit-GEMM launches, in network order
     convs = [r for r in seq if isconv(r[0])]
     c1 = [r for r in seq if 'conv1_direct' in r[0] or 'conv1_mfma' in r[0]]
     red = sum((r[2] - r[1]) / 1e3 for r in seq if 'splitk_reduce' in r[0])
