@@ -34,5 +34,5 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["us"]):
     print(f"{k:46s} {a['n']:5d} {a['us']:9.1f} {f:9.2f} {2*f:11.2f} {w:9.2f}")
     if any(t in k for t in ('conv_igemm', 'conv1_direct', 'conv1_mfma', 'conv_s2_tile', 'conv_s2_strip', 'deconv_tile')):
         tf += f; tw += w
-print(f"conv stack (conv_igemm + conv_s2_tile + deconv_tile + conv1): fetch {tf:.2f} GB raw / {2*tf:.2f} GB corrected, write {tw:.2f} GB "
+print(f"conv stack (conv_igemm + conv_s2_tile + conv_s2_strip + deconv_tile + conv1): fetch {tf:.2f} GB raw / {2*tf:.2f} GB corrected, write {tw:.2f} GB "
       f"-> HBM traffic per forward {2*tf+tw:.2f} GB (corrected)")
