@@ -1558,29 +1558,39 @@ __global__ __launch_bounds__(64) void bn_finalize_wave_kernel(const double* __re
     ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
 }
 
-// Finalise BatchNorm from the per-tile records written by the conv epilogue.  One thread per (group, channel);
-// the records of every launch member that wrote this channel are added in (member, tile) order.
-__global__ __launch_bounds__(64) void bn_finalize_fused_kernel(const ConvDesc* __restrict__ descs, int ndesc, int /*unused*/, int C,
-                                                                int rows_per_group, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, float2* __restrict__ ss) {
-    const int c = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;      // one wave per (channel, group)
+// Finalise BatchNorm from the per-tile records written by the conv epilogues.  A workgroup = 32 consecutive channels x 32 record
+// parts of one group: lane = channel, so a wave's 16-byte record reads are 512 contiguous bytes (one wave per channel walking
+// its records read 16 bytes per 1-4 KB line: 50 us per layer on D2 / D3).  Part k adds records k, k + 32, ... of every launch
+// member that wrote the channel, in (member, tile) order; the 32 parts are then added in order: fixed order, deterministic.
+__global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(const ConvDesc* __restrict__ descs, int ndesc, int /*unused*/, int C,
+                                                                 int rows_per_group, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float2* __restrict__ ss) {
+    __shared__ double red[32][32][2];
+    const int cq = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cq, g = blockIdx.y;
     double s = 0, q = 0;
-    for (int z = 0; z < ndesc; ++z) {
-        const ConvDesc& d = descs[z];
-        const int cl = c - d.ychoff;
-        if (cl < 0 || cl >= d.Cout) continue;
-        const int hw = d.Hp * d.Wp;
-        const int BMt = d.stat_bm;
-        const int t0 = (2 * g * hw) / BMt, t1 = min(((2 * g + 2) * hw - 1) / BMt, (d.M - 1) / BMt);
-        for (int t = t0 + lane; t <= t1; t += 64) {
-            const int sl = g - (((t * BMt) / hw) >> 1);
-            if (sl < 0 || sl > 1) continue;
-            const double* p = d.stat_part + (((size_t)t * 2 + sl) * d.cout_pad + cl) * 2;
-            s += p[0]; q += p[1];
+    if (c < C) {
+        for (int z = 0; z < ndesc; ++z) {
+            const ConvDesc& d = descs[z];
+            const int cl = c - d.ychoff;
+            if (cl < 0 || cl >= d.Cout) continue;
+            const int hw = d.Hp * d.Wp;
+            const int BMt = d.stat_bm;
+            const int t0 = (2 * g * hw) / BMt, t1 = min(((2 * g + 2) * hw - 1) / BMt, (d.M - 1) / BMt);
+            for (int t = t0 + part; t <= t1; t += 32) {
+                const int sl = g - (((t * BMt) / hw) >> 1);
+                if (sl < 0 || sl > 1) continue;
+                const double2 v = *reinterpret_cast<const double2*>(d.stat_part + (((size_t)t * 2 + sl) * d.cout_pad + cl) * 2);
+                s += v.x; q += v.y;
+            }
         }
     }
-    s = rp_wave_sum(s); q = rp_wave_sum(q);          // fixed butterfly order: deterministic
-    if (lane) return;
+    red[part][cq][0] = s; red[part][cq][1] = q;
+    __syncthreads();
+    if (part || c >= C) return;
+    s = 0; q = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { s += red[k][cq][0]; q += red[k][cq][1]; }
     const double mean = s / rows_per_group;
     double var = q / rows_per_group - mean * mean;
     if (var < 0) var = 0;
@@ -2584,7 +2594,7 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
         } else if (op.type == OP_STATS_FUSED) {
             const Buf& B = net->bufs[op.buf];
             mark(2);
-            hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(B.C, G), dim3(64), 0, s, plan->d_descs + op.first, op.count, op.cfg,
+            hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((B.C + 31) / 32, G), dim3(1024), 0, s, plan->d_descs + op.first, op.count, op.cfg,
                                B.C, 2 * B.H * B.H, net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
             mark(-2);
         } else if (op.type == OP_HEADS) {
