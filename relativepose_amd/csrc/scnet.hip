@@ -1489,6 +1489,55 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     for (int k = 0; k < cf / 2; ++k) *reinterpret_cast<float2*>(o + 2 * k) = make_float2(r[2 * k], r[2 * k + 1]);
 }
 
+// Split-K reduce + BatchNorm partial sums in one pass (round 2): grid (chunk, group, member); a workgroup adds the K slices of a
+// chunk of one group's rows of member z in fixed order, stores y, and leaves the float64 {sum, sum of squares} of those rows per
+// channel as record [group][z * nch + chunk][C][2] for bn_finalize_kernel -- y is not read back by a separate statistics pass.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const ConvDesc* __restrict__ descs, int nch, int C, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double sm_rs[];
+    const ConvDesc d = descs[blockIdx.z];
+    const int q4 = d.cout_pad >> 2, nrl = 256 / q4;
+    const int cq = threadIdx.x % q4, rl = threadIdx.x / q4;
+    const int g = blockIdx.y, chunk = blockIdx.x;
+    const int hw = d.Hp * d.Wp, R = 2 * hw;
+    const int chunk_rows = (R + nch - 1) / nch;
+    const int r0 = g * R + chunk * chunk_rows, r1 = min(min(r0 + chunk_rows, (g + 1) * R), d.M);
+    double sv[4] = {0, 0, 0, 0}, qv[4] = {0, 0, 0, 0};
+    if (rl < nrl) {
+        const int c4 = cq * 4;
+        for (int m = r0 + rl; m < r1; m += nrl) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ks = 0; ks < d.ksplit; ++ks) {
+                const float4 v = rp_ldg4(d.partial + ((size_t)ks * d.M + m) * d.cout_pad + c4);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            const int img = m / hw, rem = m - img * hw;
+            const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
+            const size_t pix = ((size_t)img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
+            float* yo = d.y + pix * d.ycstride + d.ychoff + c4;
+            if (c4 + 3 < d.Cout) rp_stg4(yo, a);
+            else { if (c4 < d.Cout) rp_stg(yo, a.x); if (c4 + 1 < d.Cout) rp_stg(yo + 1, a.y); if (c4 + 2 < d.Cout) rp_stg(yo + 2, a.z); }
+            const double e0 = a.x, e1 = a.y, e2 = a.z, e3 = a.w;
+            sv[0] += e0; sv[1] += e1; sv[2] += e2; sv[3] += e3;
+            qv[0] += e0 * e0; qv[1] += e1 * e1; qv[2] += e2 * e2; qv[3] += e3 * e3;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sm_rs[(rl * q4 + cq) * 8 + k] = sv[k]; sm_rs[(rl * q4 + cq) * 8 + 4 + k] = qv[k]; }
+    }
+    __syncthreads();
+    if (rl == 0) {
+        const size_t rec = (size_t)g * (nch * gridDim.z) + blockIdx.z * nch + chunk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = cq * 4 + k;
+            if (c >= d.Cout) continue;
+            double a = 0, b = 0;
+            for (int j = 0; j < nrl; ++j) { a += sm_rs[(j * q4 + cq) * 8 + k]; b += sm_rs[(j * q4 + cq) * 8 + 4 + k]; }
+            double* o = partial + (rec * C + d.ychoff + c) * 2;
+            o[0] = a; o[1] = b;
+        }
+    }
+}
+
 // ---- BatchNorm batch statistics (per group of 2 images, per channel), float64 ---------------------
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int rows_per_group, int C, int chunk_rows,
                                                           double* __restrict__ partial) {
@@ -1533,6 +1582,33 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nchun
     }
     const double mean = s / rows_per_group;
     double var = q / rows_per_group - mean * mean;       // biased variance (training-mode BN)
+    if (var < 0) var = 0;
+    const double sc = (double)gamma[c] / sqrt(var + BN_EPS);
+    ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
+}
+
+// Same for record lists of up to a few hundred entries: a workgroup = 32 consecutive channels x 32 record parts of one group (lane =
+// channel: coalesced record reads); part k adds records k, k + 32, ..., the parts are then added in order.
+__global__ __launch_bounds__(1024) void bn_finalize_parts_kernel(const double* __restrict__ partial, int nchunks, int C, int rows_per_group,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float2* __restrict__ ss) {
+    __shared__ double red[32][32][2];
+    const int cq = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cq, g = blockIdx.y;
+    double s = 0, q = 0;
+    if (c < C)
+        for (int k = part; k < nchunks; k += 32) {
+            const double2 v = *reinterpret_cast<const double2*>(partial + (((size_t)g * nchunks + k) * C + c) * 2);
+            s += v.x; q += v.y;
+        }
+    red[part][cq][0] = s; red[part][cq][1] = q;
+    __syncthreads();
+    if (part || c >= C) return;
+    s = 0; q = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { s += red[k][cq][0]; q += red[k][cq][1]; }
+    const double mean = s / rows_per_group;
+    double var = q / rows_per_group - mean * mean;
     if (var < 0) var = 0;
     const double sc = (double)gamma[c] / sqrt(var + BN_EPS);
     ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
@@ -1982,6 +2058,7 @@ struct Builder {
     RelposeSCNet* net; int n, G;
     float* act; float2* ss; float* splitk; double* statp;   // may be null for a sizing dry run
     int pend_first = -1, pend_count = 0, pend_bm = 0; bool pend_ok = true;   // conv groups since the last stats() call
+    int pend_reduce = -1, pend_groups = 0;   // ... the split-K reduce op of the (only) producer group, number of producer groups
     Plan* plan;
     int rc = 0;
     int group_first = -1;
@@ -2005,9 +2082,27 @@ void Builder::stats(const std::string& b) {
         o.type = OP_STATS; o.first = o.count = 0;
         // a mixed / ineligible producer set: drop the per-tile records again (they would be written for nothing)
         if (pend_first >= 0) for (int i = pend_first; i < pend_first + pend_count; ++i) plan->descs[i].stat_part = nullptr;
+        static const bool no_rs = getenv("RELPOSE_NO_REDUCE_STATS") != nullptr;
+        if (!no_rs && pend_groups == 1 && pend_reduce >= 0) {
+            // one split-K producer group: its reduce kernel also leaves the BatchNorm partial sums (chunk count fixed per layer,
+            // independent of the batch: results stay bitwise batch-invariant)
+            Op& r = plan->ops[pend_reduce];
+            const ConvDesc& d = plan->descs[r.first];
+            const int R = 2 * d.Hp * d.Wp;
+            // one or two rows per row-lane of a workgroup (the sum over up to 128 K slices is the long loop), bounded by the record buffer
+            const int nrl = std::max(1, 256 / (d.cout_pad / 4));
+            const int cap = std::max(1, std::min(128, 65536 / (net->bufs[b].C * r.count)));
+            int nch = std::min(cap, std::max(1, (R + nrl - 1) / nrl));
+            const int chunk_rows = (R + nch - 1) / nch;
+            nch = (R + chunk_rows - 1) / chunk_rows;
+            if ((size_t)nch * r.count * net->bufs[b].C * 2 <= (size_t)64 * 1024 * 2 && d.cout_pad <= 1024) {
+                r.cfg = 1; r.ninner = nch; r.grid = dim3(nch, G, r.count); r.buf = b;
+                o.cfg = 3; o.count = nch * r.count;          // finalize only, from the reduce kernel's records
+            }
+        }
     }
     plan->ops.push_back(o);
-    pend_first = -1; pend_count = 0;
+    pend_first = -1; pend_count = 0; pend_reduce = -1; pend_groups = 0;
 }
 
 float* Builder::buf(const std::string& b) { return act ? act + net->bufs[b].off * n : nullptr; }
@@ -2163,6 +2258,7 @@ void Builder::end_group() {
     for (int i = first; i < first + count; ++i) fuse = fuse && (2 * plan->descs[i].Hp * plan->descs[i].Wp >= BMt) && !plan->descs[i].bias;
     if (pend_first < 0) { pend_first = first; pend_count = 0; pend_bm = BMt; pend_ok = true; }
     pend_count += count;
+    ++pend_groups;
     pend_ok = pend_ok && fuse;               // (the groups feeding one BatchNorm may use different tile heights: ConvDesc::stat_bm)
     if (fuse) {
         for (int i = first; i < first + count; ++i) {
@@ -2200,6 +2296,7 @@ void Builder::end_group() {
             plan->ops.push_back(o);
             Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
             plan->ops.push_back(r);
+            pend_reduce = (int)plan->ops.size() - 1;
             return;
         }
     }
@@ -2233,6 +2330,7 @@ void Builder::end_group() {
     if (ksplit > 1) {
         Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
         plan->ops.push_back(r);
+        pend_reduce = (int)plan->ops.size() - 1;
     }
 }
 
@@ -2609,14 +2707,26 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
             mark(-1);
         } else if (op.type == OP_REDUCE) {
             mark(4);
-            hipLaunchKernelGGL(splitk_reduce_kernel, op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            if (op.cfg == 1) {
+                const ConvDesc& d0 = plan->descs[op.first];
+                const int q4 = d0.cout_pad / 4, nrl = 256 / q4;
+                hipLaunchKernelGGL(splitk_reduce_stats_kernel, op.grid, dim3(256), (size_t)std::max(nrl, 1) * q4 * 8 * sizeof(double), s,
+                                   plan->d_descs + op.first, op.ninner, net->bufs[op.buf].C, partial);
+            } else hipLaunchKernelGGL(splitk_reduce_kernel, op.grid, dim3(256), 0, s, plan->d_descs + op.first);
             mark(-4);
         } else {
             const Buf& B = net->bufs[op.buf];
             const int rows = 2 * B.H * B.H;
             if (op.cfg == 1) {                     // A1: finalise the per-pass records of conv1_direct_kernel
                 mark(2);
-                hipLaunchKernelGGL(bn_finalize_wave_kernel, dim3(B.C, G), dim3(64), 0, s, partial, C1_PASSES_PER_GROUP, B.C, rows,
+                hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3((B.C + 31) / 32, G), dim3(1024), 0, s, partial, C1_PASSES_PER_GROUP, B.C, rows,
+                                   net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
+                mark(-2);
+                continue;
+            }
+            if (op.cfg == 3) {                     // the split-K reduce kernel left op.count records per group: finalize only
+                mark(2);
+                hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3((B.C + 31) / 32, G), dim3(1024), 0, s, partial, op.count, B.C, rows,
                                    net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
                 mark(-2);
                 continue;
