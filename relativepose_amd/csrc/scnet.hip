@@ -1614,26 +1614,6 @@ __global__ __launch_bounds__(1024) void bn_finalize_parts_kernel(const double* _
     ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
 }
 
-// Same, one wave per (channel, group) for long record lists (the 392 per-pass records of conv1): lane l adds records
-// l, l+64, ... in order, then a fixed xor tree.
-__global__ __launch_bounds__(64) void bn_finalize_wave_kernel(const double* __restrict__ partial, int nchunks, int C, int rows_per_group,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float2* __restrict__ ss) {
-    const int c = blockIdx.x, g = blockIdx.y;
-    double s = 0, q = 0;
-    for (int k = threadIdx.x; k < nchunks; k += 64) {
-        const double* p = partial + (((size_t)g * nchunks + k) * C + c) * 2;
-        s += p[0]; q += p[1];
-    }
-    s = rp_wave_sum(s); q = rp_wave_sum(q);
-    if (threadIdx.x) return;
-    const double mean = s / rows_per_group;
-    double var = q / rows_per_group - mean * mean;
-    if (var < 0) var = 0;
-    const double sc = (double)gamma[c] / sqrt(var + BN_EPS);
-    ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
-}
-
 // Finalise BatchNorm from the per-tile records written by the conv epilogues.  A workgroup = 32 consecutive channels x 32 record
 // parts of one group: lane = channel, so a wave's 16-byte record reads are 512 contiguous bytes (one wave per channel walking
 // its records read 16 bytes per 1-4 KB line: 50 us per layer on D2 / D3).  Part k adds records k, k + 32, ... of every launch
