@@ -103,7 +103,7 @@ class RelativePosePipeline:
         import torch
         cur = torch.cuda.current_stream()
         self._chain_nets = len(states) > 1
-        self._ensure_net_stream()
+        self._ensure_net_stream(states)
         for st in states:
             if "stream" not in st:
                 st["stream"] = torch.cuda.Stream()
@@ -125,18 +125,21 @@ class RelativePosePipeline:
         self._chain_nets = False
         return [(o[0], o[1]) for o in out]
 
-    def _ensure_net_stream(self):
+    def _ensure_net_stream(self, states=None):
         # created BEFORE the per-batch streams: on this runtime the tiny kernels of a later-created stream are
         # dispatched promptly next to an earlier-created stream's big grids, but not the other way round
         # (measured: matcher phase 16 ms vs 29 ms under a concurrent forward, profiles/r01_overlap.txt).  Round-2 experiments on the
-        # scheduling of this stream, both worse: high stream priority (the matcher starves and becomes critical: 394 -> 365-377
-        # pairs/s) and two SCNet streams whose forwards may overlap (394 -> 358-360: the two working sets fight over L2)
+        # scheduling of this stream: high stream priority while the matcher still took 10 ms (it starved and became critical: 394 ->
+        # 365-377 pairs/s; see below for today's rule) and two SCNet streams whose forwards may overlap (394 -> 358-360: the two
+        # working sets fight over L2)
         import torch
         if self._net_stream is None:
-            # RELPOSE_NET_PRIO: HIP stream priority of the SCNet stream (experiment; -1 = high: conv workgroups are dispatched
-            # ahead of the matcher / geometry kernels of the batches in flight)
-            import os
-            prio = int(os.environ.get("RELPOSE_NET_PRIO", "0"))
+            # HIP stream priority of the SCNet stream (RELPOSE_NET_PRIO overrides; -1 = high: conv workgroups are dispatched ahead of
+            # the slot streams' kernels, which then fill the holes -- the drain of every conv launch, barrier stalls).  With the forwards'
+            # head / tail on the slot streams this is worth +1..2 % at 200 keypoints (489 -> 495-500 pairs/s) but costs 3 % at 400,
+            # where the slot-stream chain (tail -> matcher -> warp -> head) has no slack left and becomes critical when deprioritised.
+            nmax = max([int(st["N"]) for st in states] or [0]) if states else 0
+            prio = int(os.environ.get("RELPOSE_NET_PRIO", "-1" if (self.tail_overlap and 0 < nmax <= 256) else "0"))
             self._net_stream = torch.cuda.Stream(priority=prio)
         self._net_stream.wait_stream(torch.cuda.current_stream())
 
@@ -155,7 +158,7 @@ class RelativePosePipeline:
         nst = len(states)
         depth = nst if depth is None else max(1, min(depth, nst))
         self._chain_nets = depth > 1
-        self._ensure_net_stream()
+        self._ensure_net_stream(states)
         # One HIP stream per IN-FLIGHT SLOT, not per prepared batch: the runtime multiplexes streams onto 4 hardware queues, and with
         # net + default + 4 batch streams two batch streams share a queue -- the input preparation of a new batch then sits behind
         # the other batch's last matcher (which waits for ITS forward) in that queue, and the SCNet stream idles for a matcher
