@@ -17,6 +17,9 @@ import numpy as np
 from . import _lib
 from .weights import state_dict_spec
 
+# relpose_scnet_set_precision modes (include/relpose.h: RELPOSE_PREC_*)
+PRECISION_CODES = {"f32": 0, "bf16x3": 1, "f16x3": 2, "f16": 3}
+
 BUFFER_SHAPES = {"X0": (224, 16), "A1": (224, 192), "A2": (112, 384), "A3": (56, 768), "A4": (28, 256), "A5": (14, 512),
                  "A6": (7, 512), "A7": (3, 512), "A8": (3, 512), "A9": (1, 1024), "D9": (3, 512), "D8": (3, 512),
                  "D7": (7, 512), "D6": (14, 512), "D5": (28, 256), "D4": (56, 128), "D3": (112, 320), "D2": (224, 224)}
@@ -102,7 +105,7 @@ class SCNet:
     def set_precision(self, mode):
         """'f32' (default, the parity configuration), 'bf16x3' or 'f16x3' (split 16-bit MFMA products, fp32 accumulation) or 'f16'
         (plain fp16 MFMA products, fp32 accumulation): relpose_scnet_set_precision.  Not part of the reference interface."""
-        code = {"f32": 0, "bf16x3": 1, "f16x3": 2, "f16": 3}[mode]
+        code = PRECISION_CODES[mode]
         _lib.check(_lib.lib().relpose_scnet_set_precision(self._h, code), "relpose_scnet_set_precision")
         return self
 

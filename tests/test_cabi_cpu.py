@@ -71,3 +71,15 @@ def test_product_path_has_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         from relativepose_amd import util
         util.warping(np.zeros((1, 8, 160, 640), np.float32), np.eye(4), "suncg")
+
+
+def test_precision_codes_match_the_header():
+    """SCNet.set_precision's mode names map to the RELPOSE_PREC_* enumerators of include/relpose.h."""
+    import re
+    from relativepose_amd import model
+    hdr = open(os.path.join(ROOT, "include", "relpose.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"(RELPOSE_PREC_[A-Z0-9]+)\s*=\s*(\d+)", hdr))
+    want = {"f32": "RELPOSE_PREC_F32", "bf16x3": "RELPOSE_PREC_BF16X3", "f16x3": "RELPOSE_PREC_F16X3", "f16": "RELPOSE_PREC_F16"}
+    assert set(model.PRECISION_CODES) == set(want)
+    for name, sym in want.items():
+        assert enum[sym] == model.PRECISION_CODES[name], (name, sym)
