@@ -262,8 +262,11 @@ def worker(args):
             # --- N x N affinity build at the bench batch and at a batch where the bytes are meaningful
             a_small = affinity_roofline(N, nloc, dev, sigmas)
             a_big = affinity_roofline(N, 1024, dev, sigmas)
-            res["roofline_affinity"] = {"kernel": "affinity_gram_kernel (batch 1024) / affinity_rows_kernel (bench batch), materialised fp32 wij", "bound": "hbm", "unit": "GB/s",
-                                        "peak": PEAK_HBM_GBS, "achieved": a_big["achieved"], "frac": a_big["frac"], "traffic": None,
+            tra = _traffic(f"affinity_b1024_n{N}")
+            res["roofline_affinity"] = {"kernel": "affinity_tile_kernel + fix-up scan (batch 1024) / affinity_rows_kernel (bench batch), materialised fp32 wij", "bound": "hbm", "unit": "GB/s",
+                                        "peak": PEAK_HBM_GBS, "achieved": a_big["achieved"], "frac": a_big["frac"],
+                                        "traffic": tra["bytes"] if tra else None, "traffic_unit": "HBM bytes per launch at batch 1024 (rocprofv3 PMC; upper bound, see profiles/traffic.json)",
+                                        "traffic_profile": tra["profile"] if tra else None,
                                         "at_batch_1024": a_big, "at_bench_batch": a_small,
                                         "note": "headline = batch 1024 (one launch at the bench batch moves only "
                                                 f"{a_small['algorithmic_bytes_per_launch'] / 1e6:.1f} MB, i.e. less than 1 us of HBM time)"}

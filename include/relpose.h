@@ -68,6 +68,20 @@ typedef struct RelposeParams {
 } RelposeParams;
 
 void relpose_default_params(RelposeParams* p_host);
+
+/* Process-wide kernel-selection knobs.  Every setting produces the same results (the parity tests force each variant
+ * through the same checks); they exist for those tests and for tuning, not for the data path.  Returns the previous
+ * value, RELPOSE_EINVAL for an unknown key.  Not synchronised with calls in flight on other threads.
+ *   RELPOSE_TUNE_AFFINITY_KERNEL    0 = by batch size (default), 1 = row kernel (targets in registers), 2 = tile kernel
+ *                                   (fp16-MFMA candidates + exact arithmetic on them), 3 = LDS kernel (the nt_max > 512 path)
+ *   RELPOSE_TUNE_FIT_MAX_PRODUCTS   0 = default budget (192) of matrix-vector products per eigen-solve; a tiny budget
+ *                                   forces RELPOSE_NOT_CONVERGED
+ *   RELPOSE_TUNE_FIT_CLUSTER        0 = by problem size (default), n = workgroups per scan pair in the fit (1, 2, 4, 8)
+ *   RELPOSE_TUNE_FIT_GLOBAL_VECTORS 0 = by problem size, 1 = keep the fit's per-correspondence vectors in global memory
+ *                                   (the > 4500-correspondence layout) whatever the size */
+enum { RELPOSE_TUNE_AFFINITY_KERNEL = 0, RELPOSE_TUNE_FIT_MAX_PRODUCTS = 1, RELPOSE_TUNE_FIT_CLUSTER = 2,
+       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_COUNT = 8 };
+int relpose_set_tuning(int32_t key, int32_t value);
 const char* relpose_version(void);
 
 /* ------------------------------------------------------------------ matcher

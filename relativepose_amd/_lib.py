@@ -34,6 +34,7 @@ class MatchDebug(C.Structure):
 SIGNATURES = {
     "relpose_default_params": (None, [C.POINTER(Params)]),
     "relpose_version": (c_char_p, []),
+    "relpose_set_tuning": (c_int, [c_int, c_int]),
     "relpose_match_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int64]),
     "relpose_match_pairs": (c_int, [C.POINTER(Params), C.POINTER(Keypoints), c_void_p, c_size_t, c_int64,
                                     c_void_p, c_void_p, C.POINTER(MatchDebug), c_void_p]),
@@ -107,6 +108,30 @@ def _build_locked():
                 _b.build(verbose=False)
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+# relpose_set_tuning keys (include/relpose.h RELPOSE_TUNE_*)
+TUNE_KEYS = {"affinity_kernel": 0, "fit_max_products": 1, "fit_cluster": 2, "fit_global_vectors": 3}
+AFFINITY_KERNELS = {"auto": 0, "rows": 1, "tile": 2, "lds": 3}
+
+
+class tuning:
+    """``with tuning(affinity_kernel="tile"): ...`` -- force a kernel variant for the calls inside (process-wide knob of the
+    library, restored on exit).  Every variant produces the same results; the parity tests use this to check each one."""
+
+    def __init__(self, **kw):
+        self.kw = {k: (AFFINITY_KERNELS[v] if k == "affinity_kernel" and isinstance(v, str) else int(v)) for k, v in kw.items()}
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = lib().relpose_set_tuning(TUNE_KEYS[k], v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            lib().relpose_set_tuning(TUNE_KEYS[k], v)
+        return False
 
 
 def check(rc, what):

@@ -12,6 +12,7 @@ ARCH = "gfx950"
 # (source, extra flags).  matcher/geometry must round like numpy: no FMA contraction.
 SOURCES = [
     ("matcher.hip", ["-ffp-contract=off"]),
+    ("affinity.hip", ["-ffp-contract=off"]),
     ("geometry.hip", ["-ffp-contract=off"]),
     ("scnet.hip", []),
 ]

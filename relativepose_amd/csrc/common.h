@@ -6,6 +6,15 @@
 
 #define RP_WAVE 64
 
+// A/B switches of the experiment log exist only in builds with -DRP_EXPERIMENTS (tools/build_variant.py);
+// the product library reads no environment variable.
+#ifdef RP_EXPERIMENTS
+#include <stdlib.h>
+#define RP_ENV(name) getenv(name)
+#else
+#define RP_ENV(name) ((const char*)nullptr)
+#endif
+
 #define RP_CHECK_LAUNCH()                                   \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

@@ -307,6 +307,12 @@ __global__ void get_pixel_kernel(const double* __restrict__ depth, const double*
     const int W = 4 * h;
     const double px = pts[(size_t)k * 2 + 0], py = pts[(size_t)k * 2 + 1];
     const int tx = (int)floor(px), ty = (int)floor(py);
+    if (!(tx >= 0 && tx + 1 < W && ty >= 0 && ty + 1 < h)) {
+        // outside the reference's precondition x <= W-2, y <= H-2 (rputil.py:194-203; numpy raises IndexError there): no read past the
+        // maps, NaN outputs; the reference-named shim raises IndexError before launching
+        for (int a = 0; a < 3; ++a) { nn_out[(size_t)k * 3 + a] = NAN; pc[(size_t)k * 3 + a] = NAN; }
+        return;
+    }
     const double fx1 = px - tx, fx0 = tx + 1 - px, fy1 = py - ty, fy0 = ty + 1 - py;
     const size_t p00 = (size_t)ty * W + tx, p01 = p00 + 1, p10 = p00 + W, p11 = p10 + 1;
     const double val = ((depth[p00] * fy0 * fx0 + depth[p01] * fx1 * fy0) + depth[p10] * fy1 * fx0) + depth[p11] * fx1 * fy1;
@@ -333,6 +339,10 @@ __global__ void interpolate_kernel(const float* __restrict__ feat, const float* 
     const float x0 = floorf(x), y0 = floorf(y);
     const int xi = (int)x0, yi = (int)y0;
     const float wx0 = x0 + 1.0f - x, wy0 = y0 + 1.0f - y, wx1 = x - x0, wy1 = y - y0;
+    if (!(xi >= 0 && xi + 1 < w && yi >= 0 && yi + 1 < h)) {      // pt outside [0, 1): torch raises IndexError in the reference (rputil.py:52-55)
+        for (int c = 0; c < c_total; ++c) out[(size_t)c * k_total + k] = NAN;
+        return;
+    }
     for (int c = 0; c < c_total; ++c) {
         const float* fc = feat + (size_t)c * h * w;
         const float v00 = fc[(size_t)yi * w + xi], v10 = fc[(size_t)(yi + 1) * w + xi];

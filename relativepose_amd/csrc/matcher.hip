@@ -17,8 +17,7 @@
 // graph instead of ARPACK on the (Ns*Nt)^2 sparse matrix.
 //
 // Compiled with -ffp-contract=off: the f32 distance and the f64 threshold tests must round like numpy.
-#include "common.h"
-#include "rp_math.h"
+#include "matcher_internal.h"
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,8 +25,6 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#define RP_MAXK 8
-#define RP_FEAT 32
 #define RP_FIT_THREADS 512
 #define RP_EIG_MAX_ITERS 64     // SpMV launches per spectral round (upper bound; converged pairs exit early)
 #define RP_EIG_NORM_EVERY 4    // renormalise + test convergence every 4th SpMV (|y| grows by lambda^4 at most: safe in f64)
@@ -88,567 +85,6 @@ __device__ __forceinline__ void load_corr(const RelposeKeypoints& kp, const Grap
         o.pt[a] = kp.pc_t[ti * 3 + a]; o.nt[a] = kp.normal_t[ti * 3 + a];
     }
     o.ws = kp.weight_s[si]; o.wt = kp.weight_t[ti];
-}
-
-// ------------------------------------------------------------------ affinity + top-K
-__device__ __forceinline__ float desc_dist(float fs, const float* ftT, int ldt, int j) {
-    float r[8];
-#pragma unroll
-    for (int c = 0; c < RP_FEAT; ++c) {
-        float s = __shfl(fs, c, 64);
-        float df = s - ftT[c * ldt + j];
-        float sq = df * df;
-        if (c < 8) r[c] = sq; else r[c & 7] = r[c & 7] + sq;
-    }
-    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-}
-
-template <bool WRITE_WIJ>
-__global__ __launch_bounds__(256) void affinity_topk_kernel(RelposeKeypoints kp, RpPairConsts kc, int topK, int rows_per_block,
-                                                             float* __restrict__ wij, int32_t* __restrict__ corres_j,
-                                                             double* __restrict__ corres_w, int32_t* __restrict__ keff_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.y;
-    const int ns = kp.ns[b], nt = kp.nt[b];
-    const int ntp = (kp.nt_max + 63) & ~63;
-    const int ldt = ntp + 1;
-    double* wt_s = (double*)smem;                       // [ntp]
-    float* ftT = (float*)(smem + (size_t)ntp * 8);      // [32][ldt]
-    const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
-    if (keff == 0) return;
-    const float* ft = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
-    for (int idx = threadIdx.x; idx < ntp * RP_FEAT; idx += 256) {
-        int j = idx >> 5, c = idx & 31;
-        ftT[c * ldt + j] = (j < nt) ? ft[(size_t)j * RP_FEAT + c] / 100.0f : 0.0f;
-    }
-    for (int j = threadIdx.x; j < ntp; j += 256) wt_s[j] = (j < nt) ? kp.weight_t[(size_t)b * kp.nt_max + j] : 0.0;
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int rr = wave; rr < rows_per_block; rr += 4) {
-        const int i = blockIdx.x * rows_per_block + rr;
-        if (i >= ns) break;
-        const size_t si = (size_t)b * kp.ns_max + i;
-        const float fs = (lane < RP_FEAT) ? kp.feat_s[si * RP_FEAT + lane] / 100.0f : 0.0f;
-        const double wsi = kp.weight_s[si];
-        double te[RP_MAXK];
-        int tj[RP_MAXK];
-#pragma unroll
-        for (int q = 0; q < RP_MAXK; ++q) { te[q] = -INFINITY; tj[q] = INT_MAX; }
-        double sumsq = 0.0;
-        for (int j0 = 0; j0 < nt; j0 += 64) {
-            const int j = j0 + lane;
-            const bool valid = j < nt;
-            const int jj = valid ? j : 0;
-            const float d = desc_dist(fs, ftT, ldt, jj);
-            const double den = (wsi * wt_s[jj] == 1.0) ? kc.den_both : kc.den_other;
-            const double e = (-(double)d) / den;
-            const double w = exp(e);
-            if (valid) {
-                sumsq += w * w;
-                if (e > te[RP_MAXK - 1]) {            // strict: equal e keeps the smaller (earlier) j
-                    te[RP_MAXK - 1] = e; tj[RP_MAXK - 1] = j;
-#pragma unroll
-                    for (int q = RP_MAXK - 1; q > 0; --q) {
-                        if (te[q] > te[q - 1]) {
-                            double t0 = te[q]; te[q] = te[q - 1]; te[q - 1] = t0;
-                            int t1 = tj[q]; tj[q] = tj[q - 1]; tj[q - 1] = t1;
-                        }
-                    }
-                }
-            }
-        }
-        const double nm = sqrt(rp_wave_sum(sumsq));
-        for (int k = 0; k < keff; ++k) {
-            double be = te[0];
-            int bj = tj[0];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                double oe = rp_shfl_xor_d(be, m);
-                int oj = __shfl_xor(bj, m, 64);
-                if (oe > be || (oe == be && oj < bj)) { be = oe; bj = oj; }
-            }
-            if (tj[0] == bj && bj != INT_MAX) {       // this lane owned the winner: pop it
-#pragma unroll
-                for (int q = 0; q < RP_MAXK - 1; ++q) { te[q] = te[q + 1]; tj[q] = tj[q + 1]; }
-                te[RP_MAXK - 1] = -INFINITY; tj[RP_MAXK - 1] = INT_MAX;
-            }
-            if (lane == 0) {
-                const bool ok = bj >= 0 && bj < nt;
-                corres_j[si * topK + k] = ok ? bj : 0;
-                corres_w[si * topK + k] = (ok && nm != 0.0) ? exp(be) / nm : 0.0;
-            }
-        }
-        if (WRITE_WIJ) {
-            float* row = wij + si * kp.nt_max;
-            for (int j0 = 0; j0 < nt; j0 += 64) {
-                const int j = j0 + lane;
-                const bool valid = j < nt;
-                const int jj = valid ? j : 0;
-                const float d = desc_dist(fs, ftT, ldt, jj);
-                const double den = (wsi * wt_s[jj] == 1.0) ? kc.den_both : kc.den_other;
-                const double w = exp((-(double)d) / den);
-                if (valid) row[j] = (nm != 0.0) ? (float)(w / nm) : 0.0f;
-            }
-        }
-    }
-}
-
-// ---- register-resident variant (the default for nt_max <= 512) -----------------------------------------------------
-// A lane OWNS up to T targets (j = t*64 + lane) with their scaled 32-float descriptors in VGPRs; a wave walks over
-// `rows_per_wave` source rows, broadcasting the row's descriptor through SGPRs (v_readlane), so an entry costs no LDS
-// traffic at all: only the 32 x {sub, mul, add} of the numpy-order float32 distance, as packed fp32 math over two target
-// slots.  Per row: e = -d/den (float64 division replaced by Markstein's exact q + fma(rem, 1/den, q) sequence; den takes
-// two values), the K winners by K rounds of {per-lane best, DPP wave maximum, owner pops}, exp() only in the target slots
-// where some lane is within 110 of the row maximum (everything below is < 2^-150 relative: exactly 0 in the float32 wij and
-// invisible in the float64 row norm), the norm, the K outputs (exp + divide on K lanes in parallel) and, if wanted, wij.
-struct AffConsts { double den[2], rden[2]; int exact_div; };
-// wij entries more than RP_AFF_WINDOW below the row's best exponent (< e^-75 = 2.7e-33 of the row maximum) are written as exact zeros and
-// left out of the float64 row norm (they change it by < 1e-65 relative): exp() is evaluated only inside the window
-#define RP_AFF_WINDOW 75.0        // [0] = other, [1] = both observed
-
-__device__ __forceinline__ double rp_wave_max_d(double v) {
-    // butterfly inside every row of 16 lanes (DPP), then the four row results through SGPRs
-    v = fmax(v, rp_dpp_d<0xB1>(v));          // quad_perm [1,0,3,2]
-    v = fmax(v, rp_dpp_d<0x4E>(v));          // quad_perm [2,3,0,1]
-    v = fmax(v, rp_dpp_d<0x141>(v));         // row_half_mirror
-    v = fmax(v, rp_dpp_d<0x140>(v));         // row_mirror
-    const double a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
-    const double b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
-    const double c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
-    const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
-    return fmax(fmax(a, b), fmax(c, d));
-}
-
-// FIXUP: only the rows that affinity_gram_kernel marked (corres_j[row][0] == RP_AFF_REDO: more candidates than its per-lane
-// stack holds) are processed; a wave without marked rows exits before staging anything.
-#define RP_AFF_REDO (-1)
-template <int TP, bool WRITE_WIJ, bool FIXUP = false>       // TP = pairs of target slots per lane (targets <= 128 * TP)
-__global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp, AffConsts ac, int topK, int rows_per_wave,
-                                                             float* __restrict__ wij, int32_t* __restrict__ corres_j,
-                                                             double* __restrict__ corres_w, int32_t* __restrict__ keff_out) {
-    constexpr int T = 2 * TP;
-    const int b = blockIdx.y;
-    const int ns = kp.ns[b], nt = kp.nt[b];
-    const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
-    if (!FIXUP && blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
-    if (keff == 0) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
-    if (row0 >= ns) return;
-    if (FIXUP) {
-        bool any = false;
-        for (int rr = 0; rr < rows_per_wave && row0 + rr < ns; ++rr)
-            any = any || corres_j[((size_t)b * kp.ns_max + row0 + rr) * topK] == RP_AFF_REDO;
-        if (!any) return;
-    }
-    // ---- this lane's targets: descriptors / 100 (float32 division like numpy), observed-weight flags
-    rp_v2f ft[TP][RP_FEAT];
-    double wt[T];
-    const float* ftg = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
-#pragma unroll
-    for (int p = 0; p < TP; ++p) {
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int j = (2 * p + h2) * 64 + lane;
-            const bool ok = j < nt;
-            const float* src = ftg + (size_t)(ok ? j : 0) * RP_FEAT;
-            wt[2 * p + h2] = ok ? kp.weight_t[(size_t)b * kp.nt_max + j] : 0.0;
-#pragma unroll
-            for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
-                const float4 v = rp_ldg4(src + 4 * c4);
-                const float q0 = ok ? v.x / 100.0f : 0.0f, q1 = ok ? v.y / 100.0f : 0.0f, q2 = ok ? v.z / 100.0f : 0.0f, q3 = ok ? v.w / 100.0f : 0.0f;
-                if (h2 == 0) { ft[p][4 * c4].x = q0; ft[p][4 * c4 + 1].x = q1; ft[p][4 * c4 + 2].x = q2; ft[p][4 * c4 + 3].x = q3; }
-                else { ft[p][4 * c4].y = q0; ft[p][4 * c4 + 1].y = q1; ft[p][4 * c4 + 2].y = q2; ft[p][4 * c4 + 3].y = q3; }
-            }
-        }
-    }
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-        const int i = row0 + rr;
-        if (i >= ns) break;
-        const size_t si = (size_t)b * kp.ns_max + i;
-        if (FIXUP && corres_j[si * topK] != RP_AFF_REDO) continue;
-        const float fsl = kp.feat_s[si * RP_FEAT + (lane & 31)] / 100.0f;
-        const double wsi = kp.weight_s[si];
-        float sc[RP_FEAT];                       // the row's descriptor, wave-uniform (SGPRs)
-#pragma unroll
-        for (int c = 0; c < RP_FEAT; ++c) sc[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fsl), c));
-        // ---- numpy-order float32 squared distances (8 strided partial sums + fixed tree), two target slots per packed op
-        double e[T];
-#pragma unroll
-        for (int p = 0; p < TP; ++p) {
-            rp_v2f r8[8];
-#pragma unroll
-            for (int c = 0; c < RP_FEAT; ++c) {
-                const rp_v2f sv = {sc[c], sc[c]};
-                const rp_v2f df = sv - ft[p][c];
-                const rp_v2f sq = df * df;
-                if (c < 8) r8[c] = sq; else r8[c & 7] = r8[c & 7] + sq;
-            }
-            const rp_v2f d2 = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int t = 2 * p + h2;
-                const double x = (double)(h2 ? d2.y : d2.x);
-                const bool cls = (wsi * wt[t] == 1.0);
-                const double den = cls ? ac.den[1] : ac.den[0], rd = cls ? ac.rden[1] : ac.rden[0];
-                double q = x * rd;                                    // Markstein: rd = RN(1/den), one correction step = RN(x/den)
-                const double rem = __builtin_fma(-q, den, x);
-                q = __builtin_fma(rem, rd, q);
-                e[t] = (t * 64 + lane < nt) ? -q : -INFINITY;
-            }
-        }
-        // ---- K winners: largest e, ties to the smaller j
-        double ek[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) ek[t] = e[t];
-        double be[RP_MAXK];
-        int bj[RP_MAXK];
-#pragma unroll
-        for (int k = 0; k < RP_MAXK; ++k) {
-            be[k] = -INFINITY; bj[k] = INT_MAX;
-            if (k < keff) {
-                double lb = ek[0];
-                int lt = 0;
-#pragma unroll
-                for (int t = 1; t < T; ++t) if (ek[t] > lb) { lb = ek[t]; lt = t; }
-                const double mx = rp_wave_max_d(lb);
-                const unsigned long long cand = __ballot(lb == mx);
-                const int jl = lt * 64 + lane;
-                int owner = __ffsll((long long)cand) - 1;
-                int jwin = __builtin_amdgcn_readlane(jl, owner);
-                if (cand & (cand - 1)) {                              // several lanes hold the same e: the smallest j wins
-                    unsigned long long rest = cand & (cand - 1);
-                    while (rest) {
-                        const int l2 = __ffsll((long long)rest) - 1;
-                        const int j2 = __builtin_amdgcn_readlane(jl, l2);
-                        if (j2 < jwin) { jwin = j2; owner = l2; }
-                        rest &= rest - 1;
-                    }
-                }
-                be[k] = mx; bj[k] = (mx == -INFINITY) ? INT_MAX : jwin;
-                if (lane == owner) {
-#pragma unroll
-                    for (int t = 0; t < T; ++t) if (t == lt) ek[t] = -INFINITY;
-                }
-            }
-        }
-        // ---- exp only where it can matter, row norm
-        const double emax = be[0];
-        double w[T];
-        double sumsq = 0.0;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const bool need = e[t] >= emax - RP_AFF_WINDOW;       // false for the padding (-inf)
-            w[t] = 0.0;
-            if (__ballot(need)) {
-                const double v = exp(e[t]);
-                w[t] = need ? v : 0.0;
-            }
-            sumsq += w[t] * w[t];
-        }
-        const double nm = sqrt(rp_wave_sum(sumsq));
-        const double inm = (nm != 0.0) ? 1.0 / nm : 0.0;
-        {   // the K outputs: lane k takes winner k (exp + one division per lane, all K in parallel)
-            double mybe = -INFINITY;
-            int mybj = INT_MAX;
-#pragma unroll
-            for (int k = 0; k < RP_MAXK; ++k) if (k == lane) { mybe = be[k]; mybj = bj[k]; }
-            if (lane < keff) {
-                const bool ok = mybj >= 0 && mybj < nt;
-                corres_j[si * topK + lane] = ok ? mybj : 0;
-                corres_w[si * topK + lane] = (ok && nm != 0.0) ? exp(mybe) / nm : 0.0;
-            }
-        }
-        if (WRITE_WIJ) {
-            float* row = wij + si * kp.nt_max;
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int j = t * 64 + lane;
-                if (j < nt) row[j] = (float)(w[t] * inm);
-            }
-        }
-    }
-}
-
-// ---- Gram (MFMA) variant: exact work only for candidates ------------------------------------------------------------------
-// The numpy-order float32 distance costs 95 separately rounded operations per entry and the row top-K costs K cross-lane
-// reductions per row -- but only a handful of entries per row matter: the K winners and whatever lies within 110 of the
-// row maximum (everything else is exactly 0 in the float32 wij and invisible in the float64 norm).  This kernel finds those
-// entries from an APPROXIMATE distance and spends exact arithmetic only on them:
-//   1. approximate squared distances |s|^2 + |t|^2 - 2 s.t from v_mfma_f32_32x32x2_f32 with the TARGETS as the M dimension
-//      and 32 source rows as the N dimension: in the C layout lane l then holds, for ITS source row (l & 31), 16 targets per
-//      32-target tile (lanes l and l ^ 32 share a row).  Row-wise selection becomes in-lane work: every lane keeps the K
-//      largest approximate exponents of its half row (one v_max + K-1 v_med3 per entry, no cross-lane traffic), the two
-//      halves are merged with K exchanges.
-//   2. with err bounding |approximate - exact| exponent, every true winner satisfies e~ >= e~_(K) - 2 err, and every entry
-//      that can contribute to the norm or to wij satisfies e~ >= e~_max - 110 - 2 err: a second MFMA pass pushes the entries
-//      above min(those two thresholds) on a per-lane stack (LDS);
-//   3. the stack entries get the exact treatment of affinity_rows_kernel: numpy-order distance (packed over feature pairs),
-//      Markstein division, float64 exp, exact (e, smaller j) ordering, norm.  A row with more candidates than the stack
-//      holds is marked RP_AFF_REDO and redone by affinity_rows_kernel<FIXUP> (launched right behind, normally a no-op).
-// Results are identical to affinity_rows_kernel's (same exact arithmetic on a superset of the entries that matter).
-#define AG_WAVES 8             // waves per workgroup = tiles of 32 source rows
-#define AG_LDT 36              // LDS row stride of the target descriptors (floats): conflict-free b128 reads
-#define AG_CAP 48              // candidate stack entries per lane (half a row), uint16 target indices
-
-template <bool WRITE_WIJ, int KL>       // KL = length of the per-lane winner lists (>= topK): 5 or RP_MAXK
-__global__ __launch_bounds__(AG_WAVES * 64) void affinity_gram_kernel(RelposeKeypoints kp, AffConsts ac, int topK, int ntp,
-                                                                       float* __restrict__ wij, int32_t* __restrict__ corres_j,
-                                                                       double* __restrict__ corres_w, int32_t* __restrict__ keff_out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int NT = blockDim.x, rows_per_block = (NT >> 6) * 32;      // 2, 4 or 8 waves: small batches use smaller workgroups
-    const int b = blockIdx.y;
-    const int ns = kp.ns[b], nt = kp.nt[b];
-    const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
-    if (keff == 0) return;
-    if (blockIdx.x * rows_per_block >= ns) return;
-    float* ftT = (float*)smem;                                   // [ntp][AG_LDT] scaled target descriptors
-    double* wts = (double*)(ftT + (size_t)ntp * AG_LDT);         // [ntp] target weights
-    float* ntn = (float*)(wts + ntp);                            // [ntp] |t|^2 (+inf beyond nt: such entries get e~ = -inf)
-    float* ntmax_s = ntn + ntp;                                  // [4]
-    unsigned short* stk = (unsigned short*)(ntmax_s + 4);         // [AG_CAP][NT] candidate target indices (nt <= 512)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, n = lane & 31;
-    {   // ---- stage the pair's targets: descriptors / 100 (float32 division like numpy), squared norms, weights
-        const float* ftg = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
-        for (int idx = tid; idx < ntp * (RP_FEAT / 4); idx += NT) {
-            const int j = idx >> 3, c4 = idx & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < nt) { v = rp_ldg4(ftg + (size_t)j * RP_FEAT + 4 * c4); v.x /= 100.0f; v.y /= 100.0f; v.z /= 100.0f; v.w /= 100.0f; }
-            *reinterpret_cast<float4*>(&ftT[j * AG_LDT + 4 * c4]) = v;
-        }
-        for (int j = tid; j < ntp; j += NT) wts[j] = (j < nt) ? kp.weight_t[(size_t)b * kp.nt_max + j] : 0.0;
-        if (tid == 0) ntmax_s[0] = 0.f;
-        __syncthreads();
-        float mx = 0.f;
-        for (int j = tid; j < ntp; j += NT) {
-            float a = 0.f;
-            for (int c = 0; c < RP_FEAT; ++c) a += ftT[j * AG_LDT + c] * ftT[j * AG_LDT + c];
-            ntn[j] = (j < nt) ? a : INFINITY;
-            if (j < nt) mx = fmaxf(mx, a);
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-        if (lane == 0) atomicMax((int*)&ntmax_s[0], __float_as_int(mx));       // non-negative floats order like ints
-        __syncthreads();
-    }
-    const float ntmax = ntmax_s[0];
-    const int i = blockIdx.x * rows_per_block + wave * 32 + n;                   // this lane's source row (both halves of a wave share it)
-    const bool rowok = i < ns;
-    const size_t si = (size_t)b * kp.ns_max + (rowok ? i : 0);
-    // ---- the source row: all 32 scaled features (exact distances) + the half this lane feeds to the MFMA
-    float fs[RP_FEAT];
-#pragma unroll
-    for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
-        float4 v = rowok ? rp_ldg4(kp.feat_s + si * RP_FEAT + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        fs[4 * c4] = v.x / 100.0f; fs[4 * c4 + 1] = v.y / 100.0f; fs[4 * c4 + 2] = v.z / 100.0f; fs[4 * c4 + 3] = v.w / 100.0f;
-    }
-    float sb[16], nsq = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) sb[q] = h ? fs[16 + q] : fs[q];
-#pragma unroll
-    for (int c = 0; c < RP_FEAT; ++c) nsq += fs[c] * fs[c];
-    const double wsi = rowok ? kp.weight_s[si] : 0.0;
-    const float rdf0 = (float)ac.rden[0], rdf1 = (float)ac.rden[1];
-    const int ntiles = ntp / 32;                                                // even: ntp is a multiple of 64
-
-    // approximate exponents of TWO 32-target tiles (two independent MFMA accumulator chains) for this lane's row:
-    // et[u][r] belongs to target j0 + 32 u + 8 (r >> 2) + 4 h + (r & 3)
-    auto tile_exponents = [&](int j0, float (&et)[2][16]) {
-        floatx16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        const float4* ar0 = reinterpret_cast<const float4*>(&ftT[(j0 + n) * AG_LDT + 16 * h]);
-        const float4* ar1 = reinterpret_cast<const float4*>(&ftT[(j0 + 32 + n) * AG_LDT + 16 * h]);
-        const float4 a0 = ar0[0], a1 = ar0[1], a2 = ar0[2], a3 = ar0[3], b0 = ar1[0], b1 = ar1[1], b2 = ar1[2], b3 = ar1[3];
-        const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-        const float bv[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], sb[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[q], sb[q], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int jb = j0 + 32 * u + 8 * r4 + 4 * h;
-                const float4 tn = *reinterpret_cast<const float4*>(&ntn[jb]);
-                const double2 w01 = *reinterpret_cast<const double2*>(&wts[jb]), w23 = *reinterpret_cast<const double2*>(&wts[jb + 2]);
-                const float tnv[4] = {tn.x, tn.y, tn.z, tn.w};
-                const double wv[4] = {w01.x, w01.y, w23.x, w23.y};
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float g = u ? acc1[4 * r4 + rr] : acc0[4 * r4 + rr];
-                    const float dt = __builtin_fmaf(-2.0f, g, nsq + tnv[rr]);
-                    const float rd = (wsi * wv[rr] == 1.0) ? rdf1 : rdf0;
-                    et[u][4 * r4 + rr] = -(dt * rd);
-                }
-            }
-    };
-
-    // ---- pass 1: the KL largest approximate exponents of the half row (sorted, te[0] = max)
-    float te[KL];
-#pragma unroll
-    for (int k = 0; k < KL; ++k) te[k] = -INFINITY;
-    for (int t = 0; t < ntiles; t += 2) {
-        float et[2][16];
-        tile_exponents(t * 32, et);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = et[u][r];
-                float prev = te[0];
-                te[0] = fmaxf(prev, x);
-#pragma unroll
-                for (int k = 1; k < KL; ++k) { const float cur = te[k]; te[k] = __builtin_amdgcn_fmed3f(prev, cur, x); prev = cur; }
-            }
-    }
-    {   // merge with the other half of the row (lane ^ 32)
-        float ot[KL];
-#pragma unroll
-        for (int k = 0; k < KL; ++k) ot[k] = __shfl_xor(te[k], 32, 64);
-#pragma unroll
-        for (int kk = 0; kk < KL; ++kk) {
-            const float x = ot[kk];
-            float prev = te[0];
-            te[0] = fmaxf(prev, x);
-#pragma unroll
-            for (int k = 1; k < KL; ++k) { const float cur = te[k]; te[k] = __builtin_amdgcn_fmed3f(prev, cur, x); prev = cur; }
-        }
-    }
-    float kth = te[0];
-#pragma unroll
-    for (int k = 1; k < KL; ++k) if (k == keff - 1) kth = te[k];
-    const float emax_a = te[0];
-    // |e~ - e| <= (distance error) / den_min + float32 rounding of e~ itself; generous constants
-    const float rdmax = fmaxf(rdf0, rdf1);
-    const float err = 1.52587890625e-5f * (nsq + ntmax) * rdmax + 4.76837158203125e-7f * fmaxf(fabsf(kth), fabsf(emax_a)) + 1e-30f;
-    const float thr = fminf(kth, emax_a - (float)RP_AFF_WINDOW) - 2.0f * err;
-    const double need_lo = (double)emax_a - RP_AFF_WINDOW - 3.0 * (double)err;
-    // wij entries are staged relative to exp(emax_a) so that a row whose best exponent is -300 still fits float32
-    const double sup = (emax_a > -700.0f) ? exp(-(double)emax_a) : 0.0;
-
-    if (WRITE_WIJ) {   // zero-fill the wave's rows of wij (coalesced); the few non-zero entries are scattered below
-        const int r0 = blockIdx.x * rows_per_block + wave * 32;
-        for (int rr = 0; rr < 32 && r0 + rr < ns; ++rr) {
-            float* row = wij + ((size_t)b * kp.ns_max + r0 + rr) * kp.nt_max;
-            for (int j = lane; j < nt; j += 64) row[j] = 0.f;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-
-    // ---- pass 2: candidates onto the lane's stack
-    int cnt = 0;
-    for (int t = 0; t < ntiles; t += 2) {
-        float et[2][16];
-        tile_exponents(t * 32, et);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (et[u][r] >= thr) {
-                    const int jc = (t + u) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    if (jc < nt) {
-                        if (cnt < AG_CAP) stk[cnt * NT + tid] = (unsigned short)jc;
-                        ++cnt;
-                    }
-                }
-            }
-    }
-    const bool over = cnt > AG_CAP;
-    const int ncand = min(cnt, AG_CAP);
-
-    // ---- exact treatment of the candidates: sorted list of the KL best by (e descending, j ascending), norm
-    double le[KL];
-    int lj[KL];
-#pragma unroll
-    for (int k = 0; k < KL; ++k) { le[k] = -INFINITY; lj[k] = INT_MAX; }
-    double sumsq = 0.0;
-    float* wrow = WRITE_WIJ ? wij + si * kp.nt_max : nullptr;
-    for (int c = 0; __ballot(c < ncand); ++c) {
-        if (c < ncand) {
-            const int j = stk[c * NT + tid];
-            // numpy-order float32 squared distance: 8 strided partial sums + fixed tree, packed over feature pairs
-            const rp_v2f* tv = reinterpret_cast<const rp_v2f*>(&ftT[j * AG_LDT]);
-            rp_v2f r8[4];
-#pragma unroll
-            for (int c2 = 0; c2 < 16; ++c2) {
-                const rp_v2f sv = {fs[2 * c2], fs[2 * c2 + 1]};
-                const rp_v2f df = sv - tv[c2];
-                const rp_v2f sq = df * df;
-                if (c2 < 4) r8[c2] = sq; else r8[c2 & 3] = r8[c2 & 3] + sq;
-            }
-            const float d = ((r8[0].x + r8[0].y) + (r8[1].x + r8[1].y)) + ((r8[2].x + r8[2].y) + (r8[3].x + r8[3].y));
-            const bool cls = (wsi * wts[j] == 1.0);
-            const double den = cls ? ac.den[1] : ac.den[0], rd = cls ? ac.rden[1] : ac.rden[0];
-            const double x = (double)d;
-            double q = x * rd;
-            const double rem = __builtin_fma(-q, den, x);
-            q = __builtin_fma(rem, rd, q);
-            double e = -q;
-            int jj = j;
-            if (e >= need_lo) {
-                const double w = exp(e);
-                sumsq += w * w;
-                if (WRITE_WIJ && rowok) wrow[j] = (float)(w * sup);
-            }
-            // insert (e, jj) into the sorted list
-#pragma unroll
-            for (int k = 0; k < KL; ++k) {
-                const bool better = (e > le[k]) || (e == le[k] && jj < lj[k]);
-                const double te_ = le[k]; const int tj_ = lj[k];
-                le[k] = better ? e : te_; lj[k] = better ? jj : tj_;
-                e = better ? te_ : e; jj = better ? tj_ : jj;
-            }
-        }
-    }
-    {   // merge the two halves of the row: the partner's list, the partner's share of the norm, the partner's overflow flag
-        double oe[KL]; int oj[KL];
-#pragma unroll
-        for (int k = 0; k < KL; ++k) { oe[k] = rp_shfl_xor_d(le[k], 32); oj[k] = __shfl_xor(lj[k], 32, 64); }
-#pragma unroll
-        for (int kk = 0; kk < KL; ++kk) {
-            double e = oe[kk]; int jj = oj[kk];
-#pragma unroll
-            for (int k = 0; k < KL; ++k) {
-                const bool better = (e > le[k]) || (e == le[k] && jj < lj[k]);
-                const double te_ = le[k]; const int tj_ = lj[k];
-                le[k] = better ? e : te_; lj[k] = better ? jj : tj_;
-                e = better ? te_ : e; jj = better ? tj_ : jj;
-            }
-        }
-    }
-    // fixed order: (half 0) + (half 1)
-    const double s_other = rp_shfl_xor_d(sumsq, 32);
-    const double nm = sqrt(h == 0 ? sumsq + s_other : s_other + sumsq);
-    const int partner_over = __shfl_xor((int)over, 32, 64);       // unconditionally: a short-circuited shuffle would read inactive lanes
-    const bool redo = over || partner_over != 0;
-    if (rowok && h == 0) {
-        if (redo) corres_j[si * topK] = RP_AFF_REDO;
-        else {
-#pragma unroll
-            for (int k = 0; k < KL; ++k) {
-                if (k < keff) {
-                    const bool ok = lj[k] >= 0 && lj[k] < nt;
-                    corres_j[si * topK + k] = ok ? lj[k] : 0;
-                    corres_w[si * topK + k] = (ok && nm != 0.0) ? exp(le[k]) / nm : 0.0;
-                }
-            }
-        }
-    }
-    if (WRITE_WIJ && rowok && !redo) {
-        // normalise the staged entries in place (this lane wrote them; make its own stores visible first)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const double scale = (nm != 0.0 && sup != 0.0) ? 1.0 / (sup * nm) : 0.0;
-        for (int c = 0; c < ncand; ++c) {
-            const int j = stk[c * NT + tid];
-            const float v = *(volatile float*)(wrow + j);
-            if (v != 0.f || scale == 0.0) wrow[j] = (float)((double)v * scale);
-        }
-    }
 }
 
 // ------------------------------------------------------------------ pair consistency
@@ -1843,114 +1279,14 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     if (tid == 0) status[b] = all_converged ? RELPOSE_OK : RELPOSE_NOT_CONVERGED;
 }
 
-RpPairConsts make_consts(const RelposeParams& p) {
-    RpPairConsts k;
-    k.dist_thre2 = p.distThre * p.distThre;
-    k.sep_thre = 1.5 * (p.distSepThre * p.distSepThre);
-    k.angle_thre2 = p.angleThre * p.angleThre;
-    k.two_sd2 = 2 * (p.sigmaDist * p.sigmaDist);
-    k.two_sa1_2 = 2 * (p.sigmaAngle1 * p.sigmaAngle1);
-    k.two_sa2_2 = 2 * (p.sigmaAngle2 * p.sigmaAngle2);
-    double s1 = (p.sigmaFeat / 1.2) / 5, s0 = p.sigmaFeat / 5;
-    k.den_both = 2 * (s1 * s1);
-    k.den_other = 2 * (s0 * s0);
-    k.mu = p.mu;
-    return k;
-}
-
 bool kp_ok(const RelposeKeypoints* kp, const RelposeParams* p) {
     return kp && p && kp->B > 0 && kp->ns_max > 0 && kp->nt_max > 0 && kp->nt_max <= 4096 && p->topK >= 1 && p->topK <= RP_MAXK &&
            kp->ns && kp->nt && kp->pc_s && kp->pc_t && kp->normal_s && kp->normal_t && kp->feat_s && kp->feat_t &&
            kp->weight_s && kp->weight_t;
 }
 
-template <int TP>
-int launch_affinity_rows(const RelposeKeypoints& kp, const AffConsts& ac, int topK, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
-    // ~2 waves per SIMD over the whole chip, between 2 and 32 rows per wave (the per-wave target staging costs ~2 rows' worth)
-    const long long rows = (long long)kp.B * kp.ns_max;
-    int rpw = (int)((rows + 2047) / 2048);
-    rpw = rpw < 2 ? 2 : (rpw > 32 ? 32 : rpw);
-    dim3 grid((kp.ns_max + 4 * rpw - 1) / (4 * rpw), kp.B);
-    if (wij) hipLaunchKernelGGL((affinity_rows_kernel<TP, true>), grid, dim3(256), 0, s, kp, ac, topK, rpw, wij, cj, cw, keff);
-    else hipLaunchKernelGGL((affinity_rows_kernel<TP, false>), grid, dim3(256), 0, s, kp, ac, topK, rpw, wij, cj, cw, keff);
-    RP_CHECK_LAUNCH();
-    return 0;
-}
-
-int launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
-    if (kp.nt_max <= 512 && !getenv("RELPOSE_LEGACY_AFFINITY")) {
-        const RpPairConsts kc0 = make_consts(p);
-        AffConsts ac;
-        ac.den[0] = kc0.den_other; ac.den[1] = kc0.den_both;
-        ac.exact_div = 1;
-        for (int q = 0; q < 2; ++q) {
-            ac.rden[q] = 1.0 / ac.den[q];
-            uint64_t bits; memcpy(&bits, &ac.den[q], 8);
-            // Markstein's theorem needs RN(1/den) and excludes an all-ones significand; fall back to the hardware division otherwise
-            if (!(ac.den[q] > 1e-290 && ac.den[q] < 1e290) || (bits & 0xfffffffffffffull) == 0xfffffffffffffull) ac.exact_div = 0;
-        }
-        const int tp = (kp.nt_max + 127) / 128;
-        // small batches: the register kernel (one wave per few rows) has the lower latency; the Gram kernel pays from ~1000 row tiles on
-        const bool use_gram = getenv("RELPOSE_AFFINITY_GRAM") || (!getenv("RELPOSE_AFFINITY_ROWS") && (long long)kp.B * ((kp.ns_max + 31) / 32) >= 1024);
-        if (ac.exact_div && use_gram) {
-            // Gram kernel + (normally idle) exact redo of the rows whose candidate stacks overflowed
-            const int ntp = (kp.nt_max + 63) & ~63;
-            // waves (32-row tiles) per workgroup: 8 when the batch fills the chip anyway, fewer for small batches (the per-workgroup target
-            // staging is then paid more often, but more CUs work)
-            const long long tiles32 = (long long)kp.B * ((kp.ns_max + 31) / 32);
-            const int agw = tiles32 >= 4096 ? AG_WAVES : (tiles32 >= 1024 ? 4 : 2);
-            const size_t lds = (size_t)ntp * AG_LDT * 4 + (size_t)ntp * 8 + (size_t)ntp * 4 + 16 + (size_t)AG_CAP * agw * 64 * 2;
-            dim3 grid((kp.ns_max + agw * 32 - 1) / (agw * 32), kp.B);
-#define RP_GRAM_LAUNCH(W_, KL_)                                                                                                       \
-            {                                                                                                                          \
-                RP_HIP(hipFuncSetAttribute((const void*)affinity_gram_kernel<W_, KL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                hipLaunchKernelGGL((affinity_gram_kernel<W_, KL_>), grid, dim3(agw * 64), lds, s, kp, ac, p.topK, ntp, wij, cj, cw, keff); \
-            }
-            if (wij) { if (p.topK <= 5) RP_GRAM_LAUNCH(true, 5) else RP_GRAM_LAUNCH(true, RP_MAXK) }
-            else { if (p.topK <= 5) RP_GRAM_LAUNCH(false, 5) else RP_GRAM_LAUNCH(false, RP_MAXK) }
-#undef RP_GRAM_LAUNCH
-            RP_CHECK_LAUNCH();
-            const int rpw = 8;
-            dim3 grid2((kp.ns_max + 4 * rpw - 1) / (4 * rpw), kp.B);
-#define RP_FIXUP_LAUNCH(TP_)                                                                                                             \
-            if (wij) hipLaunchKernelGGL((affinity_rows_kernel<TP_, true, true>), grid2, dim3(256), 0, s, kp, ac, p.topK, rpw, wij, cj, cw, keff);   \
-            else hipLaunchKernelGGL((affinity_rows_kernel<TP_, false, true>), grid2, dim3(256), 0, s, kp, ac, p.topK, rpw, wij, cj, cw, keff);
-            switch (tp) {
-                case 1: RP_FIXUP_LAUNCH(1) break;
-                case 2: RP_FIXUP_LAUNCH(2) break;
-                case 3: RP_FIXUP_LAUNCH(3) break;
-                default: RP_FIXUP_LAUNCH(4) break;
-            }
-#undef RP_FIXUP_LAUNCH
-            RP_CHECK_LAUNCH();
-            return 0;
-        }
-        if (ac.exact_div) switch (tp) {
-            case 1: return launch_affinity_rows<1>(kp, ac, p.topK, wij, cj, cw, keff, s);
-            case 2: return launch_affinity_rows<2>(kp, ac, p.topK, wij, cj, cw, keff, s);
-            case 3: return launch_affinity_rows<3>(kp, ac, p.topK, wij, cj, cw, keff, s);
-            default: return launch_affinity_rows<4>(kp, ac, p.topK, wij, cj, cw, keff, s);
-        }
-    }
-    const int ntp = (kp.nt_max + 63) & ~63;
-    const size_t lds = (size_t)ntp * 8 + (size_t)RP_FEAT * (ntp + 1) * 4;
-    if (lds > 160 * 1024) return RELPOSE_EINVAL;
-    const int rows = 8;
-    dim3 grid((kp.ns_max + rows - 1) / rows, kp.B);
-    RpPairConsts kc = make_consts(p);
-    if (wij) {
-        RP_HIP(hipFuncSetAttribute((const void*)affinity_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(affinity_topk_kernel<true>, grid, dim3(256), lds, s, kp, kc, p.topK, rows, wij, cj, cw, keff);
-    } else {
-        RP_HIP(hipFuncSetAttribute((const void*)affinity_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(affinity_topk_kernel<false>, grid, dim3(256), lds, s, kp, kc, p.topK, rows, wij, cj, cw, keff);
-    }
-    RP_CHECK_LAUNCH();
-    return 0;
-}
-
 // the single-workgroup fit keeps 3 vectors + the row pointers of a pair in LDS and packs (row, column) into 32 bits
-static bool fit1_ok(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && !getenv("RELPOSE_LEGACY_FIT"); }
+static bool fit1_ok(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && !RP_ENV("RELPOSE_LEGACY_FIT"); }
 static size_t fit1_lds(int32_t Cmax) { return (size_t)Cmax * 24 + (size_t)(5 * (RP_LZ_M + 1)) * 8 + (size_t)(Cmax + 1) * 8 + 16; }
 
 struct WsLayout {
@@ -1997,7 +1333,16 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
 
 }  // namespace
 
+int32_t g_rp_tune[RELPOSE_TUNE_COUNT] = {0};
+
 extern "C" {
+
+int relpose_set_tuning(int32_t key, int32_t value) {
+    if (key < 0 || key >= RELPOSE_TUNE_COUNT) return RELPOSE_EINVAL;
+    const int32_t old = g_rp_tune[key];
+    g_rp_tune[key] = value;
+    return old;
+}
 
 void relpose_default_params(RelposeParams* p) {
     p->distThre = 0.08; p->distSepThre = 1.5 * 0.08; p->angleThre = 45 / 180. * M_PI;
@@ -2016,7 +1361,7 @@ size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, 
 int relpose_affinity_topk(const RelposeParams* p, const RelposeKeypoints* kp, float* wij, int32_t* corres_j, double* corres_w,
                           int32_t* k_eff, void* stream) {
     if (!kp_ok(kp, p) || !corres_j || !corres_w || !k_eff) return RELPOSE_EINVAL;
-    return launch_affinity(*p, *kp, wij, corres_j, corres_w, k_eff, (hipStream_t)stream);
+    return rp_launch_affinity(*p, *kp, wij, corres_j, corres_w, k_eff, (hipStream_t)stream);
 }
 
 int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void* workspace, size_t workspace_bytes, int64_t max_edges,
@@ -2042,12 +1387,12 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     g.segptr = (int32_t*)(ws + L.segptr); g.segrow = (int32_t*)(ws + L.segrow); g.part = (double*)(ws + L.part);
     // tiled pair kernels (symmetric bitmap); RELPOSE_LEGACY_PAIRS = the row-per-wave kernels of round 1 (upper-triangle bitmap).
     // The fill kernel's row lists are uint16: C <= 65536; its LDS need is 8 * Cmax bytes.
-    g.sym = (!getenv("RELPOSE_LEGACY_PAIRS") && L.Cmax <= 8192) ? 1 : 0;
+    g.sym = (!RP_ENV("RELPOSE_LEGACY_PAIRS") && L.Cmax <= 8192) ? 1 : 0;
     if (g.sym) RP_HIP(hipMemsetAsync(ws + L.counters, 0, (size_t)kp->B * 16, s));
     else RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
-    int rc = launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
+    int rc = rp_launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
     if (rc) return rc;
-    const RpPairConsts kc = make_consts(*p);
+    const RpPairConsts kc = rp_make_consts(*p);
     dim3 grid_rows((L.Cmax + 3) / 4, kp->B);
     if (g.sym) hipLaunchKernelGGL(pair_tile_kernel, dim3((unsigned)(L.Wmax * (L.Wmax + 1) / 2), kp->B), dim3(256), 0, s, *kp, g, kc, p->topK);
     else hipLaunchKernelGGL(pair_flags_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK);
@@ -2071,16 +1416,16 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
         // ---- fit: ONE launch, one 1024-thread workgroup per pair (fit_pair_kernel)
         const size_t lds = fit1_lds(L.Cmax);
         static long long* prof = nullptr;
-        if (getenv("RELPOSE_FIT_PROF")) {
+        if (RP_ENV("RELPOSE_FIT_PROF")) {
             if (!prof) RP_HIP(hipMalloc((void**)&prof, 64));
             RP_HIP(hipMemsetAsync(prof, 0, 64, s));
         }
         // (multisection rounds | product budget << 8); RELPOSE_LZ_MAXPROD is a test hook: a tiny budget forces RELPOSE_NOT_CONVERGED
-        const int tri_rounds = (getenv("RELPOSE_TRI_ROUNDS") ? atoi(getenv("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS) |
-                               ((getenv("RELPOSE_LZ_MAXPROD") ? atoi(getenv("RELPOSE_LZ_MAXPROD")) : RP_LZ_MAXPROD) << 8);
+        const int tri_rounds = (RP_ENV("RELPOSE_TRI_ROUNDS") ? atoi(RP_ENV("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS) |
+                               ((g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] > 0 ? g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] : RP_LZ_MAXPROD) << 8);
         // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences,
         // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 768 | 1024 overrides (experiments).
-        const int fit_threads = getenv("RELPOSE_FIT_THREADS") ? atoi(getenv("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);
+        const int fit_threads = RP_ENV("RELPOSE_FIT_THREADS") ? atoi(RP_ENV("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);
         if (fit_threads == 768) {
             RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(fit_pair_kernel<768>, dim3(kp->B), dim3(768), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,

@@ -15,6 +15,16 @@
 #define RP_HD inline
 #endif
 
+// RN(x / 100) in float32 (numpy's feat / 100, rpmodule.py:342-343) by Markstein's correction of x * RN(1/100): three operations
+// instead of the hardware division sequence.  Exhaustively equal to x / 100.0f for every float with 1e-30 < |x| < 1e30 and for
+// +-0 (all 3.3e9 of them were compared on the host; tests/test_host_math.py keeps a sample); rp_div100_ok says whether x is one.
+RP_HD float rp_div100_fast(float x) {
+    const float q0 = x * 0.01f;
+    const float rem = fmaf(-q0, 100.0f, x);
+    return copysignf(fmaf(rem, 0.01f, q0), x);
+}
+RP_HD bool rp_div100_ok(float x) { const float ax = fabsf(x); return (ax < 1e30f) && (ax > 1e-30f || ax == 0.0f); }
+
 struct RpPairConsts {       // derived on the host in double, exactly as numpy does
     double dist_thre2;      // np.power(distThre, 2)
     double sep_thre;        // 1.5 * np.power(distSepThre, 2)   (sic: a distance vs a squared threshold)

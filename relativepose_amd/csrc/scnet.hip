@@ -2062,7 +2062,7 @@ void Builder::stats(const std::string& b) {
         o.type = OP_STATS; o.first = o.count = 0;
         // a mixed / ineligible producer set: drop the per-tile records again (they would be written for nothing)
         if (pend_first >= 0) for (int i = pend_first; i < pend_first + pend_count; ++i) plan->descs[i].stat_part = nullptr;
-        static const bool no_rs = getenv("RELPOSE_NO_REDUCE_STATS") != nullptr;
+        static const bool no_rs = RP_ENV("RELPOSE_NO_REDUCE_STATS") != nullptr;
         if (!no_rs && pend_groups == 1 && pend_reduce >= 0) {
             // one split-K producer group: its reduce kernel also leaves the BatchNorm partial sums (chunk count fixed per layer,
             // independent of the batch: results stay bitwise batch-invariant)
@@ -2125,7 +2125,7 @@ void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, con
         d.M = n * d.Hp * d.Wp; d.K = P.K;
         d.ksplit = 1; d.kt_per = d.K / BK; d.partial = nullptr;
         {   // K order: tap-inner for the 2x2-tap phases of transposed convs (RELPOSE_TAP_INNER=0 none / 2 every conv: experiments)
-            static const int ti = getenv("RELPOSE_TAP_INNER") ? atoi(getenv("RELPOSE_TAP_INNER")) : 1;
+            static const int ti = RP_ENV("RELPOSE_TAP_INNER") ? atoi(RP_ENV("RELPOSE_TAP_INNER")) : 1;
             d.tap_inner = (ti == 2 || (ti == 1 && d.osy == 2)) ? 1 : 0;
         }
         if (d.K != d.ntaps * d.Cin || d.Cin % BK || (s1 && s0.C % BK)) { rc = RELPOSE_EINVAL; return; }
@@ -2145,14 +2145,14 @@ void Builder::end_group() {
     for (int i = first; i < first + count; ++i) big_m = std::max(big_m, plan->descs[i].M / n * 64);   // at the nominal batch
     // tile configs: 0 = 128x128 (4 waves), 3 = 256x128 (8 waves, 4 waves/SIMD at 2 blocks/CU), 1 = 256x64, 2 = 256x32
     // (3 measured within 1 % of 0 on conv3/conv4/deconv4-6 but needs twice the split-K: off unless RELPOSE_8WAVE is set)
-    static const bool tile128 = getenv("RELPOSE_TILE128") != nullptr;      // experiment: 128-row tiles, 4 workgroups per CU
-    int cfg = cp >= 128 ? ((big_m >= 8192 && getenv("RELPOSE_8WAVE")) ? 3 : 0) : (cp == 64 ? (tile128 ? 4 : 1) : (tile128 ? 5 : 2));
+    static const bool tile128 = RP_ENV("RELPOSE_TILE128") != nullptr;      // experiment: 128-row tiles, 4 workgroups per CU
+    int cfg = cp >= 128 ? ((big_m >= 8192 && RP_ENV("RELPOSE_8WAVE")) ? 3 : 0) : (cp == 64 ? (tile128 ? 4 : 1) : (tile128 ? 5 : 2));
     // 6 = 128 x 256 tiles (2 x 2 waves of 64 x 128: 8 accumulators per wave, 2 workgroups per CU) for Cout >= 256 (RELPOSE_TILE256N)
-    static const bool tile256n = getenv("RELPOSE_TILE256N") != nullptr;
+    static const bool tile256n = RP_ENV("RELPOSE_TILE256N") != nullptr;
     if (tile256n && cp >= 256 && cp % 256 == 0) cfg = 6;
     {   // 256-row tiles that would straddle BatchNorm groups where 128-row tiles would not: take the 128-row variant
         // (same throughput per tile shape, but it gets the uniform-group loader)
-        static const bool no_auto128 = getenv("RELPOSE_NO_AUTO128") != nullptr;
+        static const bool no_auto128 = RP_ENV("RELPOSE_NO_AUTO128") != nullptr;
         bool u256 = true, u128 = true;
         for (int i = first; i < first + count; ++i) {
             const int rows = 2 * plan->descs[i].Hp * plan->descs[i].Wp;
@@ -2167,14 +2167,14 @@ void Builder::end_group() {
     bool dtile = false;
     int dt_cfg = -1;
     {
-        static const bool no_dt = getenv("RELPOSE_NO_DECONV_TILE") != nullptr;
+        static const bool no_dt = RP_ENV("RELPOSE_NO_DECONV_TILE") != nullptr;
         // variants (RELPOSE_DT_VARIANT overrides; measured at 64 images, profiles/r02_conv_experiments.txt):
         //   0: <MI 2, NI 1> 16 x 16 patches, 2 workgroups per CU      1: <1, 2> 8 x 16 patches, 2 per CU
         //   2: <1, 1> 8 x 16 patches, 3 per CU, Cout 64 as two N tiles 3: <1, 1> 4 x 56 strips of 7 waves (56-wide grids)
-        static const int dt_var = getenv("RELPOSE_DT_VARIANT") ? atoi(getenv("RELPOSE_DT_VARIANT")) : -1;
+        static const int dt_var = RP_ENV("RELPOSE_DT_VARIANT") ? atoi(RP_ENV("RELPOSE_DT_VARIANT")) : -1;
         const int Wg = plan->descs[first].Win;
-        static const bool dt_strip = getenv("RELPOSE_DT_STRIP") != nullptr;   // 56-wide grids (deconv3): no gain measured (one 7-wave workgroup per CU)
-        static const bool no_pair = getenv("RELPOSE_DT_NO_PAIR") != nullptr;
+        static const bool dt_strip = RP_ENV("RELPOSE_DT_STRIP") != nullptr;   // 56-wide grids (deconv3): no gain measured (one 7-wave workgroup per CU)
+        static const bool no_pair = RP_ENV("RELPOSE_DT_NO_PAIR") != nullptr;
         //   4: <1, 1> pairs of 8 x 8 patches (grids that tile into 8 x 8 only: deconv3, 56 x 56), 3 per CU, Cout 64 as two N tiles
         dt_cfg = Wg % 16 == 0 ? (cp == 32 ? 2 : 1) : ((Wg == 56 && dt_strip) ? 3 : ((Wg % 8 == 0 && !no_pair) ? 4 : -1));
         if (dt_var >= 0 && dt_var <= 2 && Wg % 16 == 0 && !(dt_var == 0 && cp != 32) && !(dt_var == 1 && cp != 64)) dt_cfg = dt_var;
@@ -2193,10 +2193,10 @@ void Builder::end_group() {
     // (conv2) or Cout 128 on pairs of 8 x 8 patches (conv3); fp32 products only.
     int s2_cfg = -1;
     {
-        static const bool no_s2 = getenv("RELPOSE_NO_CONV_S2") != nullptr;
+        static const bool no_s2 = RP_ENV("RELPOSE_NO_CONV_S2") != nullptr;
         const ConvDesc& d0 = plan->descs[first];
         if (!no_s2 && !dtile && net->prec == 0) {
-            static const bool s2_small = getenv("RELPOSE_S2_SMALL") != nullptr;     // experiment: 8 x 16 patches, 4 workgroups per CU
+            static const bool s2_small = RP_ENV("RELPOSE_S2_SMALL") != nullptr;     // experiment: 8 x 16 patches, 4 workgroups per CU
             if (cp == 64 && d0.Hp % 16 == 0 && d0.Wp % 16 == 0) s2_cfg = s2_small ? 2 : 0;
             else if (cp == 128 && d0.Hp % 8 == 0 && d0.Wp % 8 == 0 && ((d0.Hp / 8) * (d0.Wp / 8) * 2) % 2 == 0 && n % 2 == 0) s2_cfg = 1;
         }
@@ -2262,7 +2262,7 @@ void Builder::end_group() {
         return;
     }
     {   // split-K stride-2 4x4 convs of one source with Cout a multiple of 128 (conv4, conv5): the strip kernel
-        static const bool no_strip = getenv("RELPOSE_NO_CONV_STRIP") != nullptr;
+        static const bool no_strip = RP_ENV("RELPOSE_NO_CONV_STRIP") != nullptr;
         const ConvDesc& d = plan->descs[first];
         const int hw = d.Hp * d.Wp;
         bool ok = !no_strip && net->prec == 0 && count == 1 && ksplit > 1 && cfg == 0 && cp % 128 == 0 && d.osy == 1 && d.osx == 1 && d.sy == 2 && d.sx == 2 &&
@@ -2290,7 +2290,7 @@ void Builder::end_group() {
                 ph = ph && plan->descs[i + k].src[0].x == plan->descs[i].src[0].x && plan->descs[i + k].osy == 2 && plan->descs[i].osy == 2;
         // the 4 phase tiles of one spatial tile run back to back on the same XCD and share their input lines in its
         // L2 (deconv2: -10 %, deconv3: -2 %); small layers lose to the grid padding (8 tiles), so only above 512 tiles
-        static const bool no_pi = getenv("RELPOSE_NO_PHASE_INTERLEAVE") != nullptr;
+        static const bool no_pi = RP_ENV("RELPOSE_NO_PHASE_INTERLEAVE") != nullptr;
         if (ph && !no_pi && max_mt >= 512) o.ninner = 4;
     }
     o.grid = (o.ninner == 1) ? dim3(max_mt * count, (cp / BNt) * ksplit, 1)
@@ -2360,7 +2360,7 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     for (int m = 3; m < 5; ++m) R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), nullptr, 112, "D2", d2off[m]);
     R.end_group(); R.stats("D2");
     R.plan->tail_first = (int)R.plan->ops.size();
-    if (getenv("RELPOSE_GEMM_HEADS") || (net->S != 15 && net->S != 21)) {   // generic implicit-GEMM path (5 members)
+    if (RP_ENV("RELPOSE_GEMM_HEADS") || (net->S != 15 && net->S != 21)) {   // generic implicit-GEMM path (5 members)
         const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
         R.begin_group();
         for (int m = 0; m < 5; ++m) {
@@ -2569,7 +2569,7 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
     }
     net->last_n = n;
     // two-stream mode: the HBM-bound head (resize_in, conv1) and tail (heads, resize_out) run on tail_stream, the MFMA-bound middle on `stream`
-    static const bool head_side = getenv("RELPOSE_NO_HEAD_OVERLAP") == nullptr;
+    static const bool head_side = RP_ENV("RELPOSE_NO_HEAD_OVERLAP") == nullptr;
     const bool two = tail_stream != stream;
     hipStream_t s = (two && head_side && plan->head_count > 0) ? (hipStream_t)tail_stream : (hipStream_t)stream;
     const WsOffsets o = ws_offsets(net, n);
@@ -2661,7 +2661,7 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
             mark(-1);
         } else if (op.type == OP_CONV1) {
             mark(1);
-            static const bool c1_direct = getenv("RELPOSE_CONV1_DIRECT") != nullptr;      // the round-1 VALU kernel (A/B switch)
+            static const bool c1_direct = RP_ENV("RELPOSE_CONV1_DIRECT") != nullptr;      // the round-1 VALU kernel (A/B switch)
             if (c1_direct)
                 hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                    act + net->bufs["A1"].off * n, partial, n);

@@ -112,18 +112,26 @@ class SCNet:
     def num_params(self):
         return int(_lib.lib().relpose_scnet_num_params(self._h))
 
-    def _workspace(self, n, H, W, dev, ws_key=None):
+    MAX_WORKSPACES = 8          # cached workspaces (148 MB per image each); the C side caches 16 launch plans keyed by (n, workspace)
+
+    def _workspace(self, n, H, W, dev, ws_key=None, also_streams=()):
         import torch
         nbytes = _lib.lib().relpose_scnet_workspace_bytes(self._h, n, H, W)
         if nbytes == 0:
             raise RuntimeError("relpose_scnet_workspace_bytes: invalid shape (n must be even) or weights not loaded")
         key = (torch.cuda.current_stream().cuda_stream if ws_key is None else ("key", ws_key), n, dev.index)
-        ws = self._wss.get(key)
+        ws = self._wss.pop(key, None)                      # (re-inserted below: the dict keeps least-recently-used order)
         if ws is None or ws.numel() < nbytes:
-            if len(self._wss) >= 8:
-                self._wss.clear()
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._wss[key] = ws
+            while len(self._wss) >= self.MAX_WORKSPACES:
+                # evict ONE entry, the least recently used.  Dropping it is stream-safe: every stream that ever ran a kernel on a
+                # workspace was recorded on it (record_stream below), so the caching allocator keeps the block until those kernels
+                # have finished, whichever stream asks for memory next.
+                self._wss.pop(next(iter(self._wss)))
+        self._wss[key] = ws
+        ws.record_stream(torch.cuda.current_stream())
+        for s in also_streams:
+            ws.record_stream(s)
         self._ws = ws
         return ws
 
@@ -138,7 +146,7 @@ class SCNet:
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 16
         x = x.contiguous()
         n, _, H, W = x.shape
-        ws = self._workspace(n, H, W, x.device, ws_key)
+        ws = self._workspace(n, H, W, x.device, ws_key, () if tail_stream is None else (tail_stream,))
         if out is None:
             out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
         if tail_stream is None:

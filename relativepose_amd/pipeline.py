@@ -21,6 +21,7 @@ from . import rpmodule, util
 class RelativePosePipeline:
     _chain_nets = False
     _net_stream = None
+    _net_streams = None
 
     def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0, compose=0):
         self.net = net
@@ -133,14 +134,19 @@ class RelativePosePipeline:
         # 365-377 pairs/s; see below for today's rule) and two SCNet streams whose forwards may overlap (394 -> 358-360: the two
         # working sets fight over L2)
         import torch
-        if self._net_stream is None:
-            # HIP stream priority of the SCNet stream (RELPOSE_NET_PRIO overrides; -1 = high: conv workgroups are dispatched ahead of
-            # the slot streams' kernels, which then fill the holes -- the drain of every conv launch, barrier stalls).  With the forwards'
-            # head / tail on the slot streams this is worth +1..2 % at 200 keypoints (489 -> 495-500 pairs/s) but costs 3 % at 400,
-            # where the slot-stream chain (tail -> matcher -> warp -> head) has no slack left and becomes critical when deprioritised.
-            nmax = max([int(st["N"]) for st in states] or [0]) if states else 0
-            prio = int(os.environ.get("RELPOSE_NET_PRIO", "-1" if (self.tail_overlap and 0 < nmax <= 256) else "0"))
-            self._net_stream = torch.cuda.Stream(priority=prio)
+        # HIP stream priority of the SCNet stream (RELPOSE_NET_PRIO overrides; -1 = high: conv workgroups are dispatched ahead of
+        # the slot streams' kernels, which then fill the holes -- the drain of every conv launch, barrier stalls).  With the forwards'
+        # head / tail on the slot streams this is worth +1..2 % at 200 keypoints (489 -> 495-500 pairs/s) but costs 3 % at 400,
+        # where the slot-stream chain (tail -> matcher -> warp -> head) has no slack left and becomes critical when deprioritised.
+        # The rule is re-evaluated on every call (one stream per priority, both created up front).
+        if self._net_streams is None:
+            self._net_streams = {0: torch.cuda.Stream(priority=0), -1: torch.cuda.Stream(priority=-1)}
+        nmax = max([int(st["N"]) for st in states] or [0]) if states else 0
+        prio = int(os.environ.get("RELPOSE_NET_PRIO", "-1" if (self.tail_overlap and 0 < nmax <= 256) else "0"))
+        new_stream = self._net_streams[-1 if prio < 0 else 0]
+        if self._net_stream is not None and new_stream is not self._net_stream:
+            new_stream.wait_stream(self._net_stream)            # forwards of the previous call stay ordered before this call's
+        self._net_stream = new_stream
         self._net_stream.wait_stream(torch.cuda.current_stream())
 
     def run_pipelined(self, states, steps, on_result=None, depth=None, before_batch=None):

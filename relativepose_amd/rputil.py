@@ -51,6 +51,8 @@ def interpolate(feat, pt):
     p = pt.to(dev, torch.float32).contiguous()
     c, h, w = f.shape
     k = p.shape[0]
+    if k and not bool(((p >= 0) & (p < 1)).all()):
+        raise IndexError("interpolate: pt must lie in [0, 1) (the reference indexes feat[:, y0 + 1, x0 + 1], rputil.py:52-55)")
     out = torch.empty(c, k, dtype=torch.float32, device=dev)
     if k:
         _lib.check(_lib.lib().relpose_interpolate(_lib.ptr(f), _lib.ptr(p), _lib.ptr(out), c, h, w, k, _lib.stream_ptr()),
@@ -72,6 +74,8 @@ def getPixel(depth, normal, pts, dataset='suncg', representation='skybox'):
     k = pts.shape[0]
     if k == 0:
         return np.zeros((3, 0)), np.zeros((0, 3))
+    if not ((pts[:, 0] >= 0) & (pts[:, 0] < 4 * h - 1) & (pts[:, 1] >= 0) & (pts[:, 1] < h - 1)).all():
+        raise IndexError("getPixel: pts must satisfy 0 <= x < 4h-1, 0 <= y < h-1 (the reference reads depth[y + 1, x + 1], rputil.py:92-95)")
     dev = _lib.require_gpu()
     d, n, p = (torch.from_numpy(a).to(dev) for a in (depth, normal, pts))
     pc = torch.empty(k, 3, dtype=torch.float64, device=dev)

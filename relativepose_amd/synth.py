@@ -201,15 +201,15 @@ def _project(P_w, T, dataset, slot, h):
     return (xs / 2 + 0.5) * h + slot * h, (0.5 - ys / 2) * h, (z > 0) & (np.abs(xs) < 1) & (np.abs(ys) < 1)
 
 
-def make_wc_pair(seed, n_match=150, n_free=50, angle=0.2, shift=0.25, h=H, margin=14.0):
-    """A scan pair on which the recurrent loop is WELL-CONDITIONED (SUNCG conventions, 'second' mask): the two
+def make_wc_pair(seed, n_match=150, n_free=50, angle=0.2, shift=0.25, h=H, margin=14.0, dataset="suncg", mask_method="second"):
+    """A scan pair on which the recurrent loop is WELL-CONDITIONED (any dataset convention / mask method: the face rotation
+    table of ``dataset``, keypoints inside ``observed_box(mask_method)`` shrunk by ``margin`` pixels): the two
     cameras differ by a small rigid motion so that their observed faces see the same walls; ``n_match`` keypoints
     are the projections of common world points into BOTH observed faces (sub-pixel coordinates), ``n_free`` more
     per view are unrelated; all lie in the observed region (weight 1).  With a network whose descriptors follow
     the view-invariant wall texture (weights.make_descriptor_state_dict) the true correspondences dominate the
     matching graph.  Returns (data dict like make_pairs, pts [1,2,N,2], ptw [1,2,N], T_rel 4x4 source->target)."""
     rs = np.random.RandomState(seed)
-    dataset = "suncg"
     half = rs.uniform(2.0, 3.5, 3)
     T0 = random_rigid(rs, np.pi, 0.3)
     dT = random_rigid(rs, angle, shift)
@@ -217,21 +217,22 @@ def make_wc_pair(seed, n_match=150, n_free=50, angle=0.2, shift=0.25, h=H, margi
     rgb, nrm, dep, poses = render_room(rs, dataset, 0.0, h, poses=[T0, T1], half=half)
     N = n_match + n_free
     pts = np.zeros((1, 2, N, 2))
-    lo, hi_x, hi_y = margin, h - margin, h - margin
+    y0, y1, x0, x1 = observed_box(mask_method, h)              # the observed region lies inside face slot 1 for both mask methods
+    lo_x, hi_x, lo_y, hi_y = x0 + margin, x1 - margin, y0 + margin, y1 - margin
     got = 0
     while got < n_match:
-        px = rs.uniform(h + lo, h + hi_x, 4 * n_match)
-        py = rs.uniform(lo, hi_y, 4 * n_match)
+        px = rs.uniform(lo_x, hi_x, 4 * n_match)
+        py = rs.uniform(lo_y, hi_y, 4 * n_match)
         Pw = _ray_box(half, T0, dataset, 1, px, py, h)
         tx, ty, ok = _project(Pw, T1, dataset, 1, h)
-        ok &= (tx > h + lo) & (tx < h + hi_x) & (ty > lo) & (ty < hi_y)
+        ok &= (tx > lo_x) & (tx < hi_x) & (ty > lo_y) & (ty < hi_y)
         k = min(int(ok.sum()), n_match - got)
         pts[0, 0, got:got + k, 0], pts[0, 0, got:got + k, 1] = px[ok][:k], py[ok][:k]
         pts[0, 1, got:got + k, 0], pts[0, 1, got:got + k, 1] = tx[ok][:k], ty[ok][:k]
         got += k
     for v in range(2):
-        pts[0, v, n_match:, 0] = rs.uniform(h + lo, h + hi_x, n_free)
-        pts[0, v, n_match:, 1] = rs.uniform(lo, hi_y, n_free)
+        pts[0, v, n_match:, 0] = rs.uniform(lo_x, hi_x, n_free)
+        pts[0, v, n_match:, 1] = rs.uniform(lo_y, hi_y, n_free)
     perm = rs.permutation(N)                       # the target list is not in source order
     pts[0, 1] = pts[0, 1][perm]
     ptw = np.ones((1, 2, N))

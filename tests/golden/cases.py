@@ -30,3 +30,12 @@ WC_KW = dict(n_match=170, n_free=30, angle=0.15, shift=0.2)
 WC_S = 15
 WC_WEIGHT_SEED = 21
 WC_SIGMAS = (0.26, 0.26, 0.04, 0.1)      # sigmaAngle1, sigmaAngle2, sigmaDist, sigmaFeat for all three steps
+
+# the same kind of fixture under the other two dataset conventions (e2e_wc2.npz): Matterport = 'second' mask, S=21, face rotations
+# Rs[(i-1)%4]; ScanNet = 'kinect' mask (66x88 observed crop: smaller margin, smaller motion so that the matches stay inside), S=21, no tanh
+WC2_CASES = (
+    ("matterport", "second", 21, 1, 9100, dict(n_match=170, n_free=30, angle=0.15, shift=0.2, margin=14.0)),
+    ("matterport", "second", 21, 1, 9102, dict(n_match=170, n_free=30, angle=0.15, shift=0.2, margin=14.0)),
+    ("scannet", "kinect", 21, 0, 9200, dict(n_match=170, n_free=30, angle=0.08, shift=0.1, margin=6.0)),
+    ("scannet", "kinect", 21, 0, 9202, dict(n_match=170, n_free=30, angle=0.08, shift=0.1, margin=6.0)),
+)

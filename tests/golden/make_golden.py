@@ -6,7 +6,7 @@ regenerated from seeds, expected outputs are stored) travel with the repo.
     python tests/golden/make_golden.py            # all groups
     python tests/golden/make_golden.py matcher    # one group
 
-Groups: matcher, geometry, scnet, e2e, e2e_env, e2e_wc, stats, keypoints, metrics.  See SURVEY.md §8c for the plan.
+Groups: matcher, geometry, scnet, e2e, e2e_env, e2e_wc, e2e_wc2, stats, keypoints, metrics.  See SURVEY.md §8c for the plan.
 """
 import hashlib
 import os
@@ -43,7 +43,7 @@ def sample_idx(n, k, seed):
 
 
 from cases import (MATCH_CASES, MATCH_METHODS, GEOM_CASES, WARP_ANGLES, SCNET_CASES, E2E_CASES, E2E_N, E2E_WEIGHT_SEED,  # noqa: E402
-                   ENV_AMP, ENV_SEEDS, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED)
+                   ENV_AMP, ENV_SEEDS, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED, WC2_CASES)
 
 
 def gen_matcher():
@@ -332,6 +332,33 @@ def gen_e2e_wc():
     np.savez_compressed(os.path.join(HERE, "e2e_wc.npz"), **out)
 
 
+def gen_e2e_wc2():
+    """gen_e2e_wc under the Matterport and ScanNet conventions (cases.WC2_CASES): the reference's dataset branches of util.warping /
+    depth2pc (util.py:119-158,468-523), the face rotation Rs[(i-1)%4] of getPixel (rputil.py:88-119), the 'kinect' mask, S=21 and,
+    for ScanNet, useTanh=0 -- poses after each step + perturbation envelope, like e2e_wc.npz."""
+    out = {"amp": np.array(ENV_AMP), "n_seeds": np.array(ENV_SEEDS)}
+    sig = np.tile(np.array([WC_SIGMAS]), (3, 1))
+    nets = {}
+    for ci, (ds, mm, S, tanh, seed, kw) in enumerate(WC2_CASES):
+        if (S, tanh) not in nets:
+            nets[(S, tanh)] = ref_net(S, tanh, None, sd=weights.make_descriptor_state_dict(WC_WEIGHT_SEED, S))
+        net = nets[(S, tanh)]
+        d, pts, ptw, T = synth.make_wc_pair(seed, dataset=ds, mask_method=mm, **kw)
+        t0 = time.time()
+        trace = ref_loop(net, d, pts, ptw, ds, mm, S, sig)
+        env = np.zeros((ENV_SEEDS, 3))
+        for k in range(ENV_SEEDS):
+            tr = ref_loop(net, d, pts, ptw, ds, mm, S, sig, noise_amp=ENV_AMP, noise_seed=8500 + 100 * ci + k)
+            env[k] = [np.linalg.norm(tr[s][:3, :3] - trace[s][:3, :3]) for s in range(3)]
+        for s in range(3):
+            out[f"wc2_{ci}_R{s}"] = trace[s]
+        out[f"wc2_{ci}_T"] = T
+        out[f"wc2_env_{ci}"] = env
+        print(f"e2e_wc2 case {ci} {ds} seed {seed}: rot err vs true motion {[float(np.linalg.norm(trace[s][:3,:3]-T[:3,:3])) for s in range(3)]}"
+              f"  envelope max {env.max(0)}  ({time.time()-t0:.1f}s)", flush=True)
+    np.savez_compressed(os.path.join(HERE, "e2e_wc2.npz"), **out)
+
+
 def gen_keypoints():
     """rputil.Sampling of the reference on distance maps built like getKeypoint :182-190."""
     import torch
@@ -383,7 +410,7 @@ def gen_metrics():
 
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
-    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e", "e2e_env", "e2e_wc", "stats", "keypoints", "metrics"]
+    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e", "e2e_env", "e2e_wc", "e2e_wc2", "stats", "keypoints", "metrics"]
     for g in groups:
         t = time.time()
         globals()["gen_" + g]()

@@ -20,7 +20,7 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 
-from cases import E2E_CASES, E2E_N, E2E_WEIGHT_SEED, ENV_AMP, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED
+from cases import E2E_CASES, E2E_N, E2E_WEIGHT_SEED, ENV_AMP, WC2_CASES, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED
 from gpu_util import log
 from relativepose_amd import synth, weights
 
@@ -60,9 +60,12 @@ def test_free_running_random_weights_inside_reference_envelope(ci, golden_dir):
     log("e2e_free_running", case=ci, ds=ds, gpu_rot_err_vs_reference=errs, reference_envelope_max=e.max(0), reference_envelope_median=np.median(e, 0),
         noise_amp=ENV_AMP)
     assert int(status[0]) == 0
+    # level 0 is asserted against the reference's own perturbation envelope; after levels 1-2 that envelope is O(1) (an unrelated
+    # pose: no bound on a rotation difference could fail there), so those levels are logged above and only checked to be proper poses
+    assert errs[0] <= ENV_SLACK * e[:, 0].max(), (errs[0], ENV_SLACK * e[:, 0].max())
     for s in range(3):
-        bound = min(ENV_SLACK * e[:, s].max(), 2.0 * np.sqrt(2.0) + 1e-9)
-        assert errs[s] <= bound, (s, errs[s], bound)
+        Rg = trace[s][0].cpu().numpy()[:3, :3]
+        assert np.allclose(Rg @ Rg.T, np.eye(3), atol=1e-9) and np.linalg.det(Rg) > 0.999, s
 
 
 @pytest.mark.parametrize("ci", range(len(WC_CASES)))
@@ -83,6 +86,35 @@ def test_free_running_well_conditioned_within_1e4(ci, golden_dir):
     terr = [float(np.linalg.norm(trace[s][0].cpu().numpy()[:3, 3] - g[f"wc_{ci}_R{s}"][:3, 3])) for s in range(3)]
     e = g[f"wc_env_{ci}"]
     log("e2e_wc_free_running", case=ci, seed=WC_CASES[ci], gpu_rot_err_vs_reference=errs, gpu_trans_err_vs_reference=terr,
+        reference_envelope_max=e.max(0), rot_err_vs_true_motion=[_rot_err(trace[s][0].cpu().numpy(), T) for s in range(3)])
+    assert int(status[0]) == 0
+    assert e.max() < 1e-5, "fixture is not well-conditioned"
+    for s in range(3):
+        assert errs[s] < 1e-4, (s, errs)
+        assert terr[s] < 1e-4, (s, terr)
+
+
+@pytest.mark.parametrize("ci", range(len(WC2_CASES)))
+def test_free_running_well_conditioned_other_conventions_within_1e4(ci, golden_dir):
+    """The 1e-4 bar on the whole free-running loop under the OTHER two dataset conventions (e2e_wc2.npz): Matterport ('second' mask,
+    S=21, face rotations Rs[(i-1)%4], util.py:119-158) and ScanNet ('kinect' mask: 66x88 observed crop with the intrinsics scaling of
+    util.py:468-523, no tanh on the descriptors) -- the GPU's own pose fed back through pose_inverse -> warp_pairs -> SCNet ->
+    sample -> match, against the reference's pose after every level."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    g = np.load(os.path.join(golden_dir, "e2e_wc2.npz"))
+    ds, mm, S, tanh, seed, kw = WC2_CASES[ci]
+    d, pts, ptw, T = synth.make_wc_pair(seed, dataset=ds, mask_method=mm, **kw)
+    assert np.array_equal(T, g[f"wc2_{ci}_T"])
+    dev = torch.device("cuda:0")
+    sig = np.tile(np.array([WC_SIGMAS]), (3, 1))
+    pipe = RelativePosePipeline(_net(S, tanh, weights.make_descriptor_state_dict(WC_WEIGHT_SEED, S)), ds, mm, sig)
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    pose, status, trace = pipe.run(st)
+    errs = [_rot_err(trace[s][0].cpu().numpy(), g[f"wc2_{ci}_R{s}"]) for s in range(3)]
+    terr = [float(np.linalg.norm(trace[s][0].cpu().numpy()[:3, 3] - g[f"wc2_{ci}_R{s}"][:3, 3])) for s in range(3)]
+    e = g[f"wc2_env_{ci}"]
+    log("e2e_wc2_free_running", case=ci, dataset=ds, mask=mm, seed=seed, gpu_rot_err_vs_reference=errs, gpu_trans_err_vs_reference=terr,
         reference_envelope_max=e.max(0), rot_err_vs_true_motion=[_rot_err(trace[s][0].cpu().numpy(), T) for s in range(3)])
     assert int(status[0]) == 0
     assert e.max() < 1e-5, "fixture is not well-conditioned"

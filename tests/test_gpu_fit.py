@@ -1,6 +1,6 @@
-"""The single-workgroup fit (fit_pair_kernel: one launch per batch, Lanczos with full re-orthogonalisation for the
-leading eigenvector) against the reference goldens, against the round-1 launch-sequence fit it replaces, and its
-convergence reporting (RELPOSE_NOT_CONVERGED instead of a silently different pose)."""
+"""The fit (fit_pair_kernel: one launch per batch, Lanczos with full re-orthogonalisation for the leading eigenvector)
+against the reference goldens, its convergence reporting (RELPOSE_NOT_CONVERGED instead of a silently different pose), and the
+affinity kernel variants against each other and the oracle."""
 import os
 
 import numpy as np
@@ -89,7 +89,7 @@ def test_not_converged_is_reported_not_hidden():
 
 
 def test_exhausted_product_budget_sets_not_converged_status():
-    """RELPOSE_LZ_MAXPROD (test hook) = 8 products: no eigen-solve of a 60 %-inlier pair can reach 1e-13 in one 8-step cycle, so
+    """relpose_set_tuning(RELPOSE_TUNE_FIT_MAX_PRODUCTS, 8) (test hook) = 8 products: no eigen-solve of a 60 %-inlier pair can reach 1e-13 in one 8-step cycle, so
     the pair must come back with RELPOSE_NOT_CONVERGED (6) and a finite pose close to (but not claimed equal to) the converged one."""
     from relativepose_amd import rpmodule
     para = rpmodule.opts(0.3, 0.3, 0.04, 0.009)
@@ -100,11 +100,9 @@ def test_exhausted_product_budget_sets_not_converged_status():
             break
     else:
         pytest.skip("every candidate case converges within 8 products")
-    os.environ["RELPOSE_LZ_MAXPROD"] = "8"
-    try:
+    from relativepose_amd import _lib
+    with _lib.tuning(fit_max_products=8):
         bad = _run([(S, T)], para, debug=True)
-    finally:
-        del os.environ["RELPOSE_LZ_MAXPROD"]
     assert int(good.status[0]) == 0 and int(bad.status[0]) == 6
     assert bad.eig_iters[0].max().item() <= 8 and good.eig_iters[0].max().item() > 8
     pb = bad.pose[0].cpu().numpy()
@@ -112,32 +110,26 @@ def test_exhausted_product_budget_sets_not_converged_status():
     log("fit_forced_not_converged", rot_diff_vs_converged=float(np.linalg.norm(pb[:3, :3] - good.pose[0].cpu().numpy()[:3, :3])))
 
 
-def test_register_affinity_kernel_equals_lds_kernel():
-    """The register-resident and the Gram (MFMA candidate) affinity kernels (nt_max <= 512) against the round-1 LDS kernel they replace (kept for larger target sets):
-    identical correspondences (the float32 distance and the top-K tie rule are bit-for-bit the same), weights to round-off."""
+def test_row_and_tile_affinity_kernels_equal_lds_kernel():
+    """The register-resident (row) and the tile (fp16-MFMA candidates + exact arithmetic) affinity kernels (nt_max <= 512) against
+    the LDS kernel (the path for larger target sets): identical correspondences (the float32 distance and the top-K tie rule are
+    bit-for-bit the same), weights to round-off."""
     import torch
-    from relativepose_amd import rpmodule
+    from relativepose_amd import _lib, rpmodule
     dev = torch.device("cuda:0")
     cases = [synth.make_match_case(n, 40 + n, inlier=i, Nt=nt)[:2] for n, nt, i in ((400, 400, 0.6), (200, 130, 0.3), (64, 65, 0.6), (7, 6, 0.6), (3, 3, 0.6))]
     para = rpmodule.opts(0.3, 0.3, 0.04, 0.0095)
     kp = rpmodule.pack_keypoints(cases, dev)
-    os.environ["RELPOSE_LEGACY_AFFINITY"] = "1"
-    try:
+    with _lib.tuning(affinity_kernel="lds"):
         old = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
-    finally:
-        del os.environ["RELPOSE_LEGACY_AFFINITY"]
-    # the three current kernels: batch-size default, register kernel forced, Gram (MFMA candidate) kernel forced
-    for env in ({}, {"RELPOSE_AFFINITY_ROWS": "1"}, {"RELPOSE_AFFINITY_GRAM": "1"}):
-        os.environ.update(env)
-        try:
+    # the current kernels: batch-size default, row kernel forced, tile kernel forced
+    for sel in ("auto", "rows", "tile"):
+        with _lib.tuning(affinity_kernel=sel):
             new = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
-        finally:
-            for k in env:
-                del os.environ[k]
-        assert torch.equal(new[1], old[1]) and torch.equal(new[3], old[3]), env             # corres_j, k_eff
-        assert torch.allclose(new[2], old[2], rtol=1e-12, atol=0), env                      # corres_w (f64)
-        # wij (f32 copy): the register / Gram kernels write exact zeros below e^-75 of the row maximum (RP_AFF_WINDOW), the LDS kernel does not
-        assert torch.allclose(new[0], old[0], rtol=2e-6, atol=1e-30), env
+        assert torch.equal(new[1], old[1]) and torch.equal(new[3], old[3]), sel             # corres_j, k_eff
+        assert torch.allclose(new[2], old[2], rtol=1e-12, atol=0), sel                      # corres_w (f64)
+        # wij (f32 copy): the row / tile kernels write exact zeros below e^-75 of the row maximum (RP_AFF_WINDOW), the LDS kernel does not
+        assert torch.allclose(new[0], old[0], rtol=2e-6, atol=1e-30), sel
     # a target set larger than the register kernel takes (nt_max > 512) still goes through the LDS kernel
     big = [synth.make_match_case(40, 77, Nt=600)[:2]]
     kb = rpmodule.pack_keypoints(big, dev)
@@ -147,3 +139,72 @@ def test_register_affinity_kernel_equals_lds_kernel():
     for i in range(40):
         pos = d[2][i, ref[i]] > 0
         assert set(ref[i][pos].tolist()) <= set(cj[0, i].cpu().tolist())
+
+
+def _check_affinity_vs_oracle(cases, para, out, rows=None):
+    """corres_j (as sets over wij > 0), corres_w and the float32 wij of `out` against the numpy oracle, per pair."""
+    wij, cj, cw, keff = [t.cpu().numpy() if t is not None else None for t in out]
+    for b, (S, T) in enumerate(cases):
+        if rows is not None and b not in rows:
+            continue
+        N, Nt = S["feat"].shape[0], T["feat"].shape[0]
+        d = M.affinity(S["feat"], T["feat"], S["weight"], T["weight"], para.sigmaFeat)
+        wo = d[2]
+        K = int(keff[b])
+        assert K == min(para.topK, Nt - 1)
+        if wij is not None:
+            assert np.allclose(wij[b, :N, :Nt], wo, rtol=2e-6, atol=1e-30), b
+        co = M.topk(wo, K)[1].reshape(N, K)
+        for i in range(N):
+            so = set(int(j) for j in co[i] if wo[i, j] > 0)
+            sg = set(int(j) for j, w in zip(cj[b, i, :K], cw[b, i, :K]) if w > 0)
+            if so != sg:
+                srt = np.sort(wo[i])[::-1]
+                assert srt[K - 1] == srt[K], (b, i, sorted(so), sorted(sg))       # only an exact K / K+1 tie may differ
+            assert np.allclose(cw[b, i, :K], wo[i, cj[b, i, :K]], rtol=1e-12, atol=0), (b, i)
+
+
+def test_tile_affinity_kernel_at_production_batch_vs_oracle():
+    """The tile kernel where rp_launch_affinity picks it BY ITSELF (>= 1024 row tiles: 256 pairs x 200 keypoints = 1792 tiles, no
+    tuning override), on 256 different pairs; sampled pairs against the numpy oracle, every pair against the row kernel."""
+    import torch
+    from relativepose_amd import _lib, rpmodule
+    dev = torch.device("cuda:0")
+    cases = [synth.make_match_case(200 - (b % 3), 6000 + b, inlier=(0.6, 0.3, 0.0)[b % 3], Nt=200 - (b % 5))[:2] for b in range(256)]
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.0087)
+    kp = rpmodule.pack_keypoints(cases, dev)
+    auto = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+    with _lib.tuning(affinity_kernel="rows"):
+        rows = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+    assert torch.equal(auto[1], rows[1]) and torch.equal(auto[3], rows[3])
+    assert torch.allclose(auto[2], rows[2], rtol=1e-13, atol=0)
+    assert torch.allclose(auto[0], rows[0], rtol=1e-6, atol=1e-30)
+    _check_affinity_vs_oracle(cases, para, auto, rows={0, 1, 2, 100, 255})
+    fused = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para, want_wij=False)
+    assert torch.equal(fused[1], auto[1]) and torch.equal(fused[2], auto[2])        # the fused variant: same indices, same weights, bitwise
+
+
+def test_tile_affinity_overflow_rows_are_redone_exactly():
+    """Rows whose candidate set exceeds the tile kernel's per-lane stack -- here 150 IDENTICAL target descriptors, all tied for the
+    maximum of every row -- are marked and redone by the exact row kernel: the results still equal the oracle (ties go to the
+    smaller index), also for rows with weights the tile kernel's error bound does not cover (> 1)."""
+    import torch
+    from relativepose_amd import _lib, rpmodule
+    dev = torch.device("cuda:0")
+    S, T, _ = synth.make_match_case(200, 4242, inlier=0.5)
+    T["feat"][20:170] = T["feat"][20]                       # 150 identical descriptors: every row has >= 150 important entries
+    S2, T2, _ = synth.make_match_case(120, 4243, inlier=0.5)
+    S2["weight"][::7] = 2.0                                 # weights outside [0, 1]: 2.0 * 0.5 == 1.0 is the reference's "both observed" class
+    T2["weight"][::5] = 0.5
+    S3, T3, _ = synth.make_match_case(90, 4244, inlier=0.5)
+    cases = [(S, T), (S2, T2), (S3, T3)]
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.0087)
+    kp = rpmodule.pack_keypoints(cases, dev)
+    with _lib.tuning(affinity_kernel="tile"):
+        out = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+    _check_affinity_vs_oracle(cases, para, out)
+    with _lib.tuning(affinity_kernel="rows"):
+        ref = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+    assert torch.equal(out[1], ref[1])                                     # ties resolved like the row kernel (smaller index)
+    assert torch.allclose(out[2], ref[2], rtol=1e-13, atol=0)              # (the two kernels add the row norm up in different orders)
+    assert torch.allclose(out[0], ref[0], rtol=1e-6, atol=1e-30)

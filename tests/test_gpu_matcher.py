@@ -43,26 +43,17 @@ def _params(gm, ds, row, method="irls+sm"):
 
 
 @pytest.mark.parametrize("ci", range(len(MATCH_CASES)))
-@pytest.mark.parametrize("aff_kernel", ["rows", "gram", "rows+legacy-pairs"])
+@pytest.mark.parametrize("aff_kernel", ["rows", "tile"])
 def test_matcher_stages_vs_oracle(gm, dev, ci, aff_kernel):
-    """aff_kernel: the register-resident affinity kernel (small batches) / the Gram (MFMA candidate) kernel (large batches), forced.
-    "+legacy-pairs": the row-per-wave pair kernels (upper-triangle bitmap) instead of the tiled ones (symmetric bitmap)."""
-    legacy_pairs = aff_kernel.endswith("+legacy-pairs")
-    aff_kernel = aff_kernel.split("+")[0]
-    from relativepose_amd import rpmodule
+    """aff_kernel: the register-resident affinity kernel (small batches) / the tile kernel (fp16-MFMA candidates + exact
+    arithmetic on them; large batches), forced through relpose_set_tuning."""
+    from relativepose_amd import _lib, rpmodule
     N, Nt, seed, ds, row, inl = MATCH_CASES[ci]
     S, T, _ = synth.make_match_case(N, seed, inlier=inl, Nt=Nt)
     para, p = _params(gm, ds, row)
     pose_o, d = _oracle(S, T, p)
-    key = {"rows": "RELPOSE_AFFINITY_ROWS", "gram": "RELPOSE_AFFINITY_GRAM"}[aff_kernel]
-    os.environ[key] = "1"
-    if legacy_pairs:
-        os.environ["RELPOSE_LEGACY_PAIRS"] = "1"
-    try:
+    with _lib.tuning(affinity_kernel=aff_kernel):
         res = rpmodule.match_pairs(*rpmodule.pack_keypoints([(S, T)], dev), para, debug=True, want_wij=True)
-    finally:
-        del os.environ[key]
-        os.environ.pop("RELPOSE_LEGACY_PAIRS", None)
     status = int(res.status[0].item())
     assert status == d["status"], (status, d["status"])
     pose_g = res.pose[0].cpu().numpy()

@@ -27,6 +27,7 @@ void t_horn(const double* M, double* R) { double m[3][3], r[3][3]; for(int i=0;i
 int t_inv4(const double* A, double* o) { return rp_inv4(A, o) ? 1 : 0; }
 void t_horn_fast(const double* M, double* R) { double m[3][3], r[3][3]; for(int i=0;i<9;++i) m[i/3][i%3]=M[i];
     rp_horn_rotation_fast(m, r); for(int i=0;i<9;++i) R[i]=r[i/3][i%3]; }
+void t_div100(const float* x, float* out, int* ok, int n) { for (int i = 0; i < n; ++i) { out[i] = rp_div100_fast(x[i]); ok[i] = rp_div100_ok(x[i]) ? 1 : 0; } }
 int t_eig4_fast(const double* N, double* q) { double n[4][4]; for(int i=0;i<16;++i) n[i/4][i%4]=N[i]; return rp_sym4_max_eigvec_fast(n, q); }
 }
 '''
@@ -143,3 +144,22 @@ def test_horn_fast_path_matches_jacobi_and_oracle(shim):
         if gap > 1e-3:
             worst = max(worst, err)
     assert worst < 5e-13 and n_fast > 250
+
+
+def test_div100_fast_equals_float32_division(shim):
+    """rp_div100_fast (the affinity kernels' feat / 100): bit-equal to numpy's float32 division wherever rp_div100_ok says so --
+    random bit patterns over the whole float32 range, the range edges, zeros, and a dense sweep around typical descriptor values."""
+    rs = np.random.RandomState(0)
+    bits = rs.randint(0, 2 ** 32, size=2_000_000, dtype=np.uint64).astype(np.uint32)
+    x = np.concatenate([bits.view(np.float32), np.float32([0.0, -0.0, 1e-30, 1.0000001e-30, 9.999999e29, 1e30, 100.0, -100.0, 1.0, 3.0]),
+                        np.tanh(rs.randn(500_000)).astype(np.float32), rs.uniform(-50, 50, 500_000).astype(np.float32)])
+    x = np.ascontiguousarray(x[np.isfinite(x)])
+    out = np.empty_like(x)
+    ok = np.empty(len(x), np.int32)
+    shim.t_div100(x.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)), ok.ctypes.data_as(C.POINTER(C.c_int)),
+                  len(x))
+    ref = x / np.float32(100.0)
+    m = ok == 1
+    assert m.sum() > 2_000_000
+    assert np.array_equal(out[m].view(np.uint32), ref[m].view(np.uint32))
+    assert not ok[np.abs(x) >= 1e30].any() and not ok[(np.abs(x) <= 1e-30) & (x != 0)].any()

@@ -162,6 +162,25 @@ def test_e2e_well_conditioned_free_running_matches_reference(golden_dir):
         assert np.linalg.norm(trace[step][:3, :3] - T[:3, :3]) < 2e-2          # and it is the true relative motion, roughly
 
 
+@pytest.mark.parametrize("ci", (1, 2))
+def test_e2e_well_conditioned_other_conventions_match_reference(golden_dir, ci):
+    """The same free-running check under the Matterport ('second' mask, S=21, face rotations Rs[(i-1)%4]) and ScanNet ('kinect'
+    mask, 66x88 observed crop, no tanh) conventions (e2e_wc2.npz, cases.WC2_CASES): oracle == reference after every level."""
+    from cases import ENV_AMP, WC2_CASES, WC_SIGMAS, WC_WEIGHT_SEED
+    g = np.load(os.path.join(golden_dir, "e2e_wc2.npz"))
+    assert float(g["amp"]) == ENV_AMP
+    for k in range(len(WC2_CASES)):
+        assert g[f"wc2_env_{k}"].shape == (int(g["n_seeds"]), 3) and g[f"wc2_env_{k}"].max() < 1e-5
+    ds, mm, S, tanh, seed, kw = WC2_CASES[ci]
+    d, pts, ptw, T = synth.make_wc_pair(seed, dataset=ds, mask_method=mm, **kw)
+    assert np.array_equal(T, g[f"wc2_{ci}_T"])
+    net = SCNetOracle(weights.make_descriptor_state_dict(WC_WEIGHT_SEED, S), S, tanh)
+    _, trace = P.run_pair(net, d["rgb"][0], d["norm"][0], d["depth"][0], pts[0], ptw[0], np.tile(np.array([WC_SIGMAS]), (3, 1)), ds, mm, S)
+    for step in range(3):
+        assert np.linalg.norm(trace[step][:3, :3] - g[f"wc2_{ci}_R{step}"][:3, :3]) < 1e-6, step
+        assert np.linalg.norm(trace[step][:3, :3] - T[:3, :3]) < 2e-2
+
+
 @pytest.mark.parametrize("ds,mm,seed", GEOM_CASES)
 def test_overlap_stats_match_reference(golden_dir, ds, mm, seed):
     from oracle import stats_oracle as S
