@@ -20,7 +20,8 @@ the launch-bound matcher phase of step k runs under the SCNet forward of step k+
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
 "roofline" (dominant kernel = the MFMA implicit-GEMM conv, live HIP-event timing),
-"roofline_affinity" (the N x N affinity build against HBM peak), "pcie_inclusive"
+"roofline_affinity" (the N x N affinity build against HBM peak), "roofline_geometry"
+(unprojection / warp / keypoint sampling against HBM peak), "pcie_inclusive"
 (the same loop with every step's inputs uploaded from pinned host memory) and
 "cpu_baseline" (the numpy/torch oracle on the host cores, bounded sample, N=1 only).
 """
@@ -138,6 +139,52 @@ def affinity_roofline(N, B, dev, sigmas):
             "algorithmic_bytes_per_launch": abytes}
 
 
+def geometry_roofline(cfg, n_img, N, dev, net_out_channels, feat_off):
+    """The HBM-bound geometry stage at the bench batch (n_img = 2 x pairs panoramas): HIP-event time of back-to-back launches of
+    relpose_pano2pc, relpose_warp_pairs (scatter + gather kernels) and relpose_sample_primitives against SURVEY 8(d)'s
+    algorithmic bytes (pano2pc: read H*W*4 + write 3*H*W*4; warp: read h*h*7*4 of the observed face + write 8*H*W*4) and the bytes
+    the kernels really move (pano2pc writes float64 like the reference + a validity byte; the warp keeps a 4-byte key per pixel)."""
+    import torch
+    from relativepose_amd import synth, util
+    h, ds, mm = cfg["h"], cfg["dataset"], cfg["mask"]
+    W = 4 * h
+    d = synth.make_pairs(n_img // 2, 777, ds, h=h)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rgb, nrm, dep = t(d["rgb"].reshape(n_img, 3, h, W)), t(d["norm"].reshape(n_img, 3, h, W)), t(d["depth"].reshape(n_img, h, W))
+    x = torch.zeros(n_img, 16, h, W, dtype=torch.float32, device=dev)
+    x[:, :8].copy_(util.build_view_dev(rgb, nrm, dep, mm))
+    rs = np.random.RandomState(5)
+    poses = torch.from_numpy(np.stack([synth.random_rigid(rs, 0.5, 0.5) for _ in range(n_img)])).to(dev)
+    pts, _ = synth.make_keypoints(n_img // 2, N, 777, mm, h=h)
+    pts = t(pts.reshape(n_img, N, 2))
+    npts = torch.full((n_img,), N, dtype=torch.int32, device=dev)
+    f = torch.randn(n_img, net_out_channels, h, W, device=dev)
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "images": n_img, "pano": f"{h}x{W}", "keypoints": N}
+    for name, fn, alg, moved in (
+            ("pano2pc", lambda: util.pano2pc_dev(dep, ds), h * W * 4 + 3 * h * W * 4, h * W * 4 + 3 * h * W * 8 + h * W),
+            ("warp_pairs (scatter + gather)", lambda: util.warp_pairs_dev(x, poses, ds), h * h * 7 * 4 + 8 * h * W * 4,
+             h * h * 7 * 4 + 8 * h * W * 4 + 2 * h * W * 4),
+            ("sample_primitives", lambda: util.sample_primitives_dev(f, feat_off, nrm, dep, pts, npts, mm, ds, 0),
+             N * (4 * 8 * 4 + 4 * 32 * 4 + 48 + 128), N * (4 * 8 * 4 + 4 * 32 * 4 + 48 + 128))):
+        ms = timed(fn)
+        out[name] = {"ms_per_launch": ms, "algorithmic_bytes_per_launch": alg * n_img, "achieved": alg * n_img / (ms * 1e-3) / 1e9,
+                     "frac": alg * n_img / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_moved_per_launch": moved * n_img,
+                     "moved_GBps": moved * n_img / (ms * 1e-3) / 1e9}
+    return out
+
+
 def worker(args):
     import torch
     from relativepose_amd import distributed as D
@@ -208,7 +255,9 @@ def worker(args):
 
     if args.warmup:
         run_steps(args.warmup)
+    ncoll0 = D.COLLECTIVES["all_gather"]
     dt, (poses, status) = timed(args.steps)
+    ncoll = D.COLLECTIVES["all_gather"] - ncoll0
     dt_h2d = None
     if not args.no_h2d:
         run_steps(1, True)
@@ -230,6 +279,8 @@ def worker(args):
                           "pairs_per_step_total": total, "pairs_per_gpu": nloc, "keypoints": N, "semantic_classes": S,
                           "recurrent_levels": 3, "conv_precision": prec, "parallelism": f"pairs sharded x{world}",
                           "batches_in_flight": depth, "prepared_batches_rotated": nbatch,
+                          "shard_sizes": [D.shard_range(total, r, world)[1] - D.shard_range(total, r, world)[0] for r in range(world)],
+                          "pose_all_gathers_in_timed_region": ncoll,
                           "dist_backend": dist.get_backend() if world > 1 else None,
                           "dist_world_size": dist.get_world_size() if world > 1 else 1,
                           "collective": ("one all_gather of [steps*pairs,17] f64 (pose + status) per run" if (args.gather == "run" and total % world == 0)
@@ -270,6 +321,7 @@ def worker(args):
                                         "at_batch_1024": a_big, "at_bench_batch": a_small,
                                         "note": "headline = batch 1024 (one launch at the bench batch moves only "
                                                 f"{a_small['algorithmic_bytes_per_launch'] / 1e6:.1f} MB, i.e. less than 1 us of HBM time)"}
+            res["roofline_geometry"] = geometry_roofline(cfg, 2 * nloc, N, dev, net.out_channels, pipe.feat_off)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, N, first[0], first[1], first[2], sigmas)
         print(json.dumps(res), flush=True)

@@ -1,22 +1,21 @@
 // Spectral-matching pose module on gfx950: batched replacement of
 // RelativePoseEstimation_helper (reference RPModule/rpmodule.py:317-508).
 //
-// Kernel sequence per batch of scan pairs (all on one stream, no host sync):
-//   affinity_topk   rpmodule.py:342-379  N x N descriptor affinity (f32 distance in numpy's
-//                                         summation order, f64 weights), row norm, row top-K
-//   pair_flags      rpmodule.py:381-451  all C(C-1)/2 correspondence pairs: distance + angle tests,
-//                                         one wave per row, survivors as a bitmap (ballot)
-//   pair_scan                            CSR row pointers of the symmetric compatibility graph, status
-//   pair_fill       rpmodule.py:453-467  weights of the survivors, written in deterministic CSR order
-//   fit             rpmodule.py:212-315  IRLS + spectral rounds; one workgroup per scan pair
+// Kernel sequence per batch of scan pairs (all on one stream, no host sync; 6 dispatches):
+//   affinity (affinity.hip)  rpmodule.py:342-379  N x N descriptor affinity (f32 distance in numpy's summation order, f64 weights),
+//                                                  row norm, row top-K
+//   pair_tile        rpmodule.py:381-451  all C(C-1)/2 correspondence pairs in 64 x 64 tiles: distance screen, compacted angle test,
+//                                         survivors as a symmetric bitmap
+//   pair_scan                             CSR row pointers + segment pointers of the compatibility graph, status
+//   pair_fill_rows   rpmodule.py:453-467  weights of the survivors, written in deterministic order (segment layout)
+//   fit_pair         rpmodule.py:212-315  IRLS + spectral rounds; one workgroup per scan pair, Lanczos eigen-solver
 //
-// The fit never materialises the reference's [4M] stacked arrays: a pair's IRLS weight factorises
-// into (pair weight) x (per-correspondence reweighting product), so every weighted sum over 4M
-// elements collapses to a sum over the C correspondences with the graph's weighted degree
-// (DESIGN.md "fit").  The leading eigenvector is a power iteration on the C x C compressed
-// graph instead of ARPACK on the (Ns*Nt)^2 sparse matrix.
+// The fit never materialises the reference's [4M] stacked arrays: a pair's IRLS weight factorises into (pair weight) x
+// (per-correspondence reweighting product), so every weighted sum over 4M elements collapses to a sum over the C correspondences
+// with the graph's weighted degree (DESIGN.md "fit").  The leading eigenvector comes from Lanczos on the C x C compressed graph
+// instead of ARPACK on the (Ns*Nt)^2 sparse matrix.
 //
-// Compiled with -ffp-contract=off: the f32 distance and the f64 threshold tests must round like numpy.
+// Compiled with -ffp-contract=off: the f64 threshold tests must round like numpy.
 #include "matcher_internal.h"
 #include <limits.h>
 #include <stdio.h>
@@ -25,9 +24,6 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#define RP_FIT_THREADS 512
-#define RP_EIG_MAX_ITERS 64     // SpMV launches per spectral round (upper bound; converged pairs exit early)
-#define RP_EIG_NORM_EVERY 4    // renormalise + test convergence every 4th SpMV (|y| grows by lambda^4 at most: safe in f64)
 #define RP_EPS 1e-12
 #define RP_OFFSET 50.0
 
@@ -41,7 +37,6 @@ struct Graph {                 // per-batch device arrays of the pair-compatibil
     const int32_t* keff;       // [B]
     unsigned long long* bitmap;  // [B, Cmax, Wmax]
     int32_t* upcnt;            // [B, Cmax]
-    int32_t* lowcnt;           // [B, Cmax]
     int32_t* counters;         // [B, 4]  n_dist, M, nnz(x2), unused
     int32_t* rowptr;           // [B, Cmax+1]
     int32_t* col;              // [B, max_edges]
@@ -50,12 +45,9 @@ struct Graph {                 // per-batch device arrays of the pair-compatibil
     double* state;             // [B, 4, Cmax]  deg, gP, gN, rsum
     double* geo;               // [B, Cmax, 12]  sp, tp, sn, tn of every correspondence (gathered once per fit)
     int32_t* pairC;            // [B] number of correspondences of a pair whose fit is running, 0 otherwise
-    // Edge storage.  seg_layout == 0 (legacy launch-sequence fit): plain CSR, edge k of row c at rowptr[c] + k.
-    // seg_layout == 1 (single-workgroup fit): every row is cut into SEGMENTS of <= 32 edges; segment s = segptr[c] + k / 32
-    // lives in slot s % 64 of wave-slice s / 64, edge k % 32 of it at ((s >> 6) << 11) + ((k & 31) << 6) + (s & 63): the 64
-    // lanes of a wave, each walking its own segment, read 64 consecutive entries per step (SELL-64 over segments).
-    int32_t seg_layout;
-    int32_t sym;               // 1: bitmap holds the full symmetric adjacency (pair_tile_kernel); 0: upper triangle + upcnt / lowcnt (legacy)
+    // Edge storage: every row is cut into SEGMENTS of <= 32 edges; segment s = segptr[c] + k / 32 lives in slot s % 64 of wave-slice
+    // s / 64, edge k % 32 of it at ((s >> 6) << 11) + ((k & 31) << 6) + (s & 63): the 64 lanes of a wave, each walking its own
+    // segment, read 64 consecutive entries per step (SELL-64 over segments).  The bitmap holds the full symmetric adjacency.
     int32_t seg_cap;           // segments per pair the edge arrays are sized for (multiple of 64)
     int64_t estride;           // entries of col / wv / xe per pair
     int32_t* segptr;           // [B, Cmax+1] first segment of every row
@@ -88,39 +80,6 @@ __device__ __forceinline__ void load_corr(const RelposeKeypoints& kp, const Grap
 }
 
 // ------------------------------------------------------------------ pair consistency
-__global__ __launch_bounds__(256) void pair_flags_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK) {
-    const int b = blockIdx.y;
-    const int C = pair_C(kp, g, b);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + wave;
-    if (r >= C) return;
-    const int keff = g.keff[b];
-    Corr a;
-    load_corr(kp, g, b, topK, keff, r, a);
-    const int nch = (C + 63) >> 6;
-    int cnt_up = 0, nd = 0;
-    for (int ch = r >> 6; ch < nch; ++ch) {
-        const int c = ch * 64 + lane;
-        bool pd = false, pa = false;
-        if (c > r && c < C) {
-            Corr o;
-            load_corr(kp, g, b, topK, keff, c, o);
-            RpPairEval ev = rp_pair_eval(a.ps, a.ns, a.pt, a.nt, o.ps, o.ns, o.pt, o.nt, kc);
-            pd = ev.pass_dist; pa = ev.pass_all;
-        }
-        const unsigned long long md = __ballot(pd), ma = __ballot(pa);
-        if (lane == 0) g.bitmap[((size_t)b * g.Cmax + r) * g.Wmax + ch] = ma;
-        nd += __popcll(md);
-        cnt_up += __popcll(ma);
-        if (pa) atomicAdd(&g.lowcnt[(size_t)b * g.Cmax + c], 1);
-    }
-    if (lane == 0) {
-        g.upcnt[(size_t)b * g.Cmax + r] = cnt_up;
-        if (nd) atomicAdd(&g.counters[b * 4 + 0], nd);
-        if (cnt_up) atomicAdd(&g.counters[b * 4 + 1], cnt_up);
-    }
-}
-
 __global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Graph g, int32_t* __restrict__ status) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
@@ -134,14 +93,11 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Gr
         const int c = base + threadIdx.x;
         int v = 0;
         if (c < C) {
-            if (g.sym) {         // degree = set bits of the row; kept in upcnt for the segment pass below
-                const unsigned long long* row = g.bitmap + ((size_t)b * g.Cmax + c) * g.Wmax;
-                const int nw = (C + 63) >> 6;
-                for (int w = 0; w < nw; ++w) v += __popcll(row[w]);
-                g.upcnt[(size_t)b * g.Cmax + c] = v;
-            } else {
-                v = g.upcnt[(size_t)b * g.Cmax + c] + g.lowcnt[(size_t)b * g.Cmax + c];
-            }
+            // degree = set bits of the row; kept in upcnt for the segment pass below
+            const unsigned long long* row = g.bitmap + ((size_t)b * g.Cmax + c) * g.Wmax;
+            const int nw = (C + 63) >> 6;
+            for (int w = 0; w < nw; ++w) v += __popcll(row[w]);
+            g.upcnt[(size_t)b * g.Cmax + c] = v;
         }
         int inc = v;
 #pragma unroll
@@ -157,14 +113,14 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Gr
     }
     const int total_edges = carry_s;
     __syncthreads();
-    if (g.seg_layout) {          // first segment of every row + the row of every segment
+    {                            // first segment of every row + the row of every segment
         int32_t* sp = g.segptr + (size_t)b * (g.Cmax + 1);
         int32_t* sr = g.segrow + (size_t)b * g.seg_cap;
         if (threadIdx.x == 0) carry_s = 0;
         __syncthreads();
         for (int base = 0; base < C; base += 1024) {
             const int c = base + threadIdx.x;
-            const int deg = (c < C) ? (g.sym ? g.upcnt[(size_t)b * g.Cmax + c] : g.upcnt[(size_t)b * g.Cmax + c] + g.lowcnt[(size_t)b * g.Cmax + c]) : 0;
+            const int deg = (c < C) ? g.upcnt[(size_t)b * g.Cmax + c] : 0;
             const int v = (deg + RP_SEG - 1) / RP_SEG;
             int inc = v;
 #pragma unroll
@@ -194,74 +150,6 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Gr
         else if ((int64_t)total > g.max_edges) st = RELPOSE_EDGE_OVERFLOW;
         status[b] = st;
     }
-}
-
-__global__ __launch_bounds__(256) void pair_fill_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK,
-                                                         const int32_t* __restrict__ status) {
-    const int b = blockIdx.y;
-    if (status[b] != RELPOSE_OK) return;
-    const int C = pair_C(kp, g, b);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + wave;
-    if (c >= C) return;
-    const int keff = g.keff[b];
-    Corr me;
-    load_corr(kp, g, b, topK, keff, c, me);
-    const size_t eoff = (size_t)b * g.estride;
-    const int row_start = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
-    const int seg0 = g.seg_layout ? g.segptr[(size_t)b * (g.Cmax + 1) + c] : 0;
-    int run = row_start;
-    int nz = 0;
-    // position of the k-th edge of this row in the edge arrays
-    auto edge_pos = [&](int pos) -> size_t {
-        if (!g.seg_layout) return (size_t)pos;
-        const int k = pos - row_start;
-        return seg_edge_index(seg0 + (k >> 5), k);
-    };
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    // lower part: pairs (r, c), r < c  -- canonical orientation "1" = r, "2" = c
-    for (int ch = 0; ch * 64 < c; ++ch) {
-        const int r = ch * 64 + lane;
-        bool bit = false;
-        if (r < c) bit = (g.bitmap[((size_t)b * g.Cmax + r) * g.Wmax + (c >> 6)] >> (c & 63)) & 1ull;
-        double w = 0.0;
-        if (bit) {
-            Corr o;
-            load_corr(kp, g, b, topK, keff, r, o);
-            RpPairEval ev = rp_pair_eval(o.ps, o.ns, o.pt, o.nt, me.ps, me.ns, me.pt, me.nt, kc);
-            w = rp_pair_weight(ev, o.f, me.f, o.ws, me.ws, o.wt, me.wt, kc);
-        }
-        const unsigned long long m = __ballot(bit);
-        if (bit) {
-            const size_t pos = edge_pos(run + __popcll(m & lt));
-            g.col[eoff + pos] = r;
-            g.wv[eoff + pos] = w;
-        }
-        run += __popcll(m);
-        nz += __popcll(__ballot(bit && w != 0.0));
-    }
-    // upper part: pairs (c, c2), c2 > c
-    const int nch = (C + 63) >> 6;
-    for (int ch = c >> 6; ch < nch; ++ch) {
-        const int c2 = ch * 64 + lane;
-        const unsigned long long word = g.bitmap[((size_t)b * g.Cmax + c) * g.Wmax + ch];
-        const bool bit = (word >> lane) & 1ull;
-        double w = 0.0;
-        if (bit) {
-            Corr o;
-            load_corr(kp, g, b, topK, keff, c2, o);
-            RpPairEval ev = rp_pair_eval(me.ps, me.ns, me.pt, me.nt, o.ps, o.ns, o.pt, o.nt, kc);
-            w = rp_pair_weight(ev, me.f, o.f, me.ws, o.ws, me.wt, o.wt, kc);
-        }
-        if (bit) {
-            const size_t pos = edge_pos(run + __popcll(word & lt));
-            g.col[eoff + pos] = c2;
-            g.wv[eoff + pos] = w;
-        }
-        run += __popcll(word);
-        nz += __popcll(__ballot(bit && w != 0.0));
-    }
-    if (lane == 0 && nz) atomicAdd(&g.counters[b * 4 + 2], nz);
 }
 
 // ---- tiled pair consistency (rpmodule.py:381-451) ------------------------------------------------------------------
@@ -402,7 +290,7 @@ __global__ __launch_bounds__(256) void pair_fill_rows_kernel(RelposeKeypoints kp
     load_corr(kp, g, b, topK, keff, c, me);
     const size_t eoff = (size_t)b * g.estride;
     const int row_start = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
-    const int seg0 = g.seg_layout ? g.segptr[(size_t)b * (g.Cmax + 1) + c] : 0;
+    const int seg0 = g.segptr[(size_t)b * (g.Cmax + 1) + c];
     int nz = 0;
     for (int k = lane; k < deg; k += 64) {
         const int x = list[k];
@@ -416,7 +304,7 @@ __global__ __launch_bounds__(256) void pair_fill_rows_kernel(RelposeKeypoints kp
             const RpPairEval ev = rp_pair_eval(me.ps, me.ns, me.pt, me.nt, o.ps, o.ns, o.pt, o.nt, kc);
             w = rp_pair_weight(ev, me.f, o.f, me.ws, o.ws, me.wt, o.wt, kc);
         }
-        const size_t pos = g.seg_layout ? seg_edge_index(seg0 + (k >> 5), k) : (size_t)(row_start + k);
+        const size_t pos = seg_edge_index(seg0 + (k >> 5), k);
         g.col[eoff + pos] = x;
         g.wv[eoff + pos] = w;
         nz += (w != 0.0) ? 1 : 0;
@@ -438,302 +326,6 @@ __device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, do
     const double* g = f.geo + (size_t)c * 12;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { sp[a] = g[a]; tp[a] = g[3 + a]; sn[a] = g[6 + a]; tn[a] = g[9 + a]; }
-}
-
-// centre with position weights, Horn, residuals; optionally IRLS-reweight (rpmodule.py:236-255).
-__device__ void fit_solve(const FitCtx& f, bool reweight, double R[3][3], double t[3]) {
-    double s7[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
-        double sp[3], tp[3], sn[3], tn[3];
-        corr_geom(f, c, sp, tp, sn, tn);
-        const double wp = f.mu * f.deg[c] * f.gP[c];
-        s7[0] += wp;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { s7[1 + a] += wp * sp[a]; s7[4 + a] += wp * tp[a]; }
-    }
-    rp_block_sum<7>(s7, f.red);
-    const double den = s7[0] + RP_EPS;
-    double ms[3], mt[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { ms[a] = s7[1 + a] / den; mt[a] = s7[4 + a] / den; }
-    double m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
-        double sp[3], tp[3], sn[3], tn[3];
-        corr_geom(f, c, sp, tp, sn, tn);
-        const double d = f.deg[c];
-        const double wp = f.mu * d * f.gP[c], wn = d * f.gN[c];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb)
-                m9[a * 3 + bb] += (sp[a] - ms[a]) * ((tp[bb] - mt[bb]) * wp) + sn[a] * (tn[bb] * wn);
-    }
-    rp_block_sum<9>(m9, f.red);
-    // Horn's 4x4 eigenproblem on one wave only; R,t broadcast through LDS (red[144..155])
-    if (threadIdx.x < 64) {
-        double M[3][3], Rl[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb) M[a][bb] = m9[a * 3 + bb];
-        rp_horn_rotation(M, Rl);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                f.red[144 + a * 3 + 0] = Rl[a][0]; f.red[144 + a * 3 + 1] = Rl[a][1]; f.red[144 + a * 3 + 2] = Rl[a][2];
-                f.red[153 + a] = -((Rl[a][0] * ms[0] + Rl[a][1] * ms[1]) + Rl[a][2] * ms[2]) + mt[a];
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        R[a][0] = f.red[144 + a * 3 + 0]; R[a][1] = f.red[144 + a * 3 + 1]; R[a][2] = f.red[144 + a * 3 + 2];
-        t[a] = f.red[153 + a];
-    }
-    for (int c = threadIdx.x; c < f.C; c += blockDim.x) {
-        double sp[3], tp[3], sn[3], tn[3];
-        corr_geom(f, c, sp, tp, sn, tn);
-        double rP = 0.0, rN = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double x0 = sp[0] - ms[0], x1 = sp[1] - ms[1], x2 = sp[2] - ms[2];
-            const double ep = ((R[a][0] * x0 + R[a][1] * x1) + R[a][2] * x2) - (tp[a] - mt[a]);
-            const double en = ((R[a][0] * sn[0] + R[a][1] * sn[1]) + R[a][2] * sn[2]) - tn[a];
-            rP += ep * ep; rN += en * en;
-        }
-        rP *= f.mu;
-        f.rsum[c] = rP + rN;
-        if (reweight) { f.gP[c] = f.gP[c] / (1.0 + rP); f.gN[c] = f.gN[c] / (1.0 + rN); }
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void write_pose(double* out, const double R[3][3], const double t[3]) {
-    if (threadIdx.x == 0) {
-        for (int a = 0; a < 3; ++a) { out[a * 4 + 0] = R[a][0]; out[a * 4 + 1] = R[a][1]; out[a * 4 + 2] = R[a][2]; out[a * 4 + 3] = t[a]; }
-        out[12] = 0; out[13] = 0; out[14] = 0; out[15] = 1;
-    }
-}
-
-// ---- fit as a launch sequence over ALL pairs (no host sync; kernels of finished / failed pairs exit at once)
-//   fit_begin        status finalisation, geometry gather, degrees with the raw pair weights
-//   fit_irls         one workgroup per pair: n x {centre, Horn, residuals[, reweight]}; writes pose / trace
-//   eig_init         h = relu(50 - r), uniform start vector
-//   eig_spmv         y = A u, rows spread over the whole GPU (16 lanes per CSR row), per-block sum of squares
-//   eig_norm         u = y/|y| (fixed-order reduction of the partials), convergence flag
-//   eig_finish       x = relu(u_i u_j) w per edge, new weighted degrees
-// The host enqueues the ~80 spmv/norm launches of a spectral round back to back; each is a few us.
-struct FitState {
-    double* u;        // [B, Cmax] current unit vector
-    double* y;        // [B, Cmax] un-normalised iterate (odd products), read by eig_norm
-    double* y2;       // [B, Cmax] un-normalised iterate (even products)
-    double* h;        // [B, Cmax]
-    double* part;     // [B, nblk] per-block sum of squares of y
-    int32_t* done;    // [B] eigen iteration converged
-    int32_t* iters;   // [B]
-    int nblk;
-};
-
-__device__ __forceinline__ bool pair_active(const int32_t* status, int b) { return status[b] == RELPOSE_OK; }
-
-__global__ __launch_bounds__(256) void fit_begin_kernel(RelposeKeypoints kp, Graph g, int topK, int32_t* __restrict__ status,
-                                                         double* __restrict__ pose, double* __restrict__ trace,
-                                                         int32_t* __restrict__ counts_out) {
-    const int b = blockIdx.y;
-    const int C = pair_C(kp, g, b);
-    __shared__ int st_s;
-    if (threadIdx.x == 0) {
-        int st = status[b];
-        if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
-        st_s = st;
-    }
-    __syncthreads();
-    const int st = st_s;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0 && counts_out) {
-            counts_out[b * 4 + 0] = g.counters[b * 4 + 0];
-            counts_out[b * 4 + 1] = g.counters[b * 4 + 1];
-            counts_out[b * 4 + 2] = g.counters[b * 4 + 2] / 2;
-            counts_out[b * 4 + 3] = (kp.ns[b] >= 3 && kp.nt[b] >= 3) ? g.keff[b] : 0;
-        }
-        if (st != RELPOSE_OK) {                       // identity, like the reference's early returns
-            if (threadIdx.x < 16) pose[(size_t)b * 16 + threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;
-            if (trace && threadIdx.x < 96) trace[(size_t)b * 96 + threadIdx.x] = ((threadIdx.x % 16) % 5 == 0) ? 1.0 : 0.0;
-        }
-    }
-    if (st != RELPOSE_OK) return;
-    const int keff = g.keff[b];
-    const size_t eoff = (size_t)b * g.estride;
-    const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
-    double* geo = g.geo + (size_t)b * g.Cmax * 12;
-    double* st4 = g.state + (size_t)b * 4 * g.Cmax;
-    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + grp;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) s += g.wv[eoff + k];
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
-    if (gl == 0) { st4[c] = s; st4[g.Cmax + c] = 1.0; st4[2 * g.Cmax + c] = 1.0; st4[3 * g.Cmax + c] = 0.0; }
-    if (gl < 12) {
-        const int i = c / keff, kk = c - i * keff;
-        const size_t si = (size_t)b * kp.ns_max + i;
-        const int j = g.corres_j[si * topK + kk];
-        const size_t ti = (size_t)b * kp.nt_max + j;
-        const int a = gl % 3, what = gl / 3;
-        const double v = what == 0 ? kp.pc_s[si * 3 + a] : what == 1 ? kp.pc_t[ti * 3 + a] : what == 2 ? kp.normal_s[si * 3 + a]
-                                                                                                            : kp.normal_t[ti * 3 + a];
-        geo[(size_t)c * 12 + gl] = v;
-    }
-}
-
-// status is committed separately so that every block of fit_begin sees the same (pre-commit) value
-__global__ void fit_commit_status_kernel(RelposeKeypoints kp, Graph g, int32_t* __restrict__ status, int B) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    if (status[b] == RELPOSE_OK && g.counters[b * 4 + 2] < 1) status[b] = RELPOSE_ZERO_WEIGHT;
-    g.pairC[b] = (status[b] == RELPOSE_OK) ? pair_C(kp, g, b) : 0;      // one load replaces status/ns/nt/keff in the eig kernels
-}
-
-__global__ __launch_bounds__(RP_FIT_THREADS) void fit_irls_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int n_iter, int reweight,
-                                                                   int reset_g, const int32_t* __restrict__ status,
-                                                                   double* __restrict__ pose, double* __restrict__ trace_slot) {
-    __shared__ double red[9 * 16 + 16];
-    const int b = blockIdx.x;
-    if (!pair_active(status, b)) return;
-    FitCtx f;
-    f.b = b; f.C = pair_C(kp, g, b); f.mu = kc.mu;
-    f.deg = g.state + ((size_t)b * 4 + 0) * g.Cmax; f.gP = g.state + ((size_t)b * 4 + 1) * g.Cmax;
-    f.gN = g.state + ((size_t)b * 4 + 2) * g.Cmax; f.rsum = g.state + ((size_t)b * 4 + 3) * g.Cmax;
-    f.red = red;
-    f.geo = g.geo + (size_t)b * g.Cmax * 12;
-    if (reset_g) {
-        for (int c = threadIdx.x; c < f.C; c += blockDim.x) { f.gP[c] = 1.0; f.gN[c] = 1.0; }
-        __syncthreads();
-    }
-    double R[3][3], t[3];
-    for (int it = 0; it < n_iter; ++it) fit_solve(f, reweight != 0, R, t);
-    write_pose(pose + (size_t)b * 16, R, t);
-    if (trace_slot) write_pose(trace_slot + (size_t)b * 96, R, t);
-}
-
-__global__ __launch_bounds__(256) void eig_init_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status) {
-    const int b = blockIdx.y;
-    const int C = g.pairC[b];
-    if (C == 0) return;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) { fs.done[b] = 0; fs.iters[b] = 0; }
-    if (c >= C) return;
-    const double v = RP_OFFSET - g.state[((size_t)b * 4 + 3) * g.Cmax + c];
-    fs.h[(size_t)b * g.Cmax + c] = v < 0.0 ? 0.0 : v;
-    fs.u[(size_t)b * g.Cmax + c] = 1.0 / sqrt((double)C);
-}
-
-// a = base*(h[c]+h[cc]) (rpmodule.py:262-267 summed over the two halves); base = w, or mu*x for 'spectral' rounds > 0
-#ifndef RP_SPMV_THREADS
-#define RP_SPMV_THREADS 256     // 16 rows per workgroup (64- and 1024-thread workgroups measured slower next to the conv stream)
-#endif
-#ifndef RP_SPMV_LPR
-#define RP_SPMV_LPR 16          // lanes per CSR row
-#endif
-#define RP_SPMV_ROWS (RP_SPMV_THREADS / RP_SPMV_LPR)
-__global__ __launch_bounds__(RP_SPMV_THREADS) void eig_spmv_kernel(RelposeKeypoints kp, Graph g, FitState fs, double mu_xe,
-                                                        const int32_t* __restrict__ status, int src_sel, int dst_sel, int want_norm) {
-    __shared__ double wsum[RP_SPMV_THREADS / 64];
-    const int b = blockIdx.y;
-    const int C = g.pairC[b];
-    if (C == 0 || fs.done[b]) return;
-    if (blockIdx.x * RP_SPMV_ROWS >= C) return;
-    const size_t eoff = (size_t)b * g.estride;
-    const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
-    // buffers: 0 = u (unit vector, kept for the convergence test), 1 = y2, 2 = y (the one eig_norm reads)
-    const double* u = (src_sel == 0 ? fs.u : src_sel == 1 ? fs.y2 : fs.y) + (size_t)b * g.Cmax;
-    double* yo = (dst_sel == 1 ? fs.y2 : fs.y) + (size_t)b * g.Cmax;
-    const double* h = fs.h + (size_t)b * g.Cmax;
-    const int grp = threadIdx.x / RP_SPMV_LPR, gl = threadIdx.x % RP_SPMV_LPR;
-    const int c = blockIdx.x * RP_SPMV_ROWS + grp;
-    double s = 0.0;
-    if (c < C) {
-        const double hc = h[c];
-        for (int k = rp[c] + gl; k < rp[c + 1]; k += RP_SPMV_LPR) {
-            const int cc = g.col[eoff + k];
-            const double base = mu_xe != 0.0 ? mu_xe * g.xe[eoff + k] : g.wv[eoff + k];
-            s += (base * (hc + h[cc])) * u[cc];
-        }
-    }
-#pragma unroll
-    for (int m = RP_SPMV_LPR / 2; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
-    if (c < C && gl == 0) yo[c] = s;
-    if (!want_norm) return;
-    // per-block sum of squares (fixed order: 4 rows per wave via lanes 0,16,32,48; then 4 waves)
-    double q = (gl == 0 && c < C) ? s * s : 0.0;
-#pragma unroll
-    for (int m = RP_SPMV_LPR; m < 64; m <<= 1) q += rp_shfl_xor_d(q, m);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = q;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t;
-        if (RP_SPMV_THREADS == 256) t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        else { t = 0.0; for (int w = 0; w < RP_SPMV_THREADS / 64; ++w) t += wsum[w]; }
-        fs.part[(size_t)b * fs.nblk + blockIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(256) void eig_norm_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status) {
-    __shared__ double red[16];
-    __shared__ int flag;
-    const int b = blockIdx.x;
-    const int C = g.pairC[b];
-    if (C == 0 || fs.done[b]) return;
-    const int nb = (C + RP_SPMV_ROWS - 1) / RP_SPMV_ROWS;
-    double a[1] = {0.0};
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) a[0] += fs.part[(size_t)b * fs.nblk + i];
-    rp_block_sum<1>(a, red);
-    const double nrm = sqrt(a[0]);
-    if (threadIdx.x == 0) flag = 0;
-    __syncthreads();
-    if (!(nrm > 0.0)) {                                  // zero matrix: keep the current vector, stop
-        if (threadIdx.x == 0) fs.done[b] = 1;
-        return;
-    }
-    int moved = 0;
-    double* u = fs.u + (size_t)b * g.Cmax;
-    const double* y = fs.y + (size_t)b * g.Cmax;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double un = y[c] / nrm;
-        if (fabs(un - u[c]) > 1e-15) moved = 1;
-        u[c] = un;
-    }
-    if (moved) flag = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) { fs.iters[b] += RP_EIG_NORM_EVERY; if (!flag) fs.done[b] = 1; }
-}
-
-// x = relu(u[c1]*u[c2]) * w  (rpmodule.py:277-280) and the new weighted degrees
-__global__ __launch_bounds__(256) void eig_finish_kernel(RelposeKeypoints kp, Graph g, FitState fs, const int32_t* __restrict__ status,
-                                                          int32_t* __restrict__ eig_iters_out) {
-    const int b = blockIdx.y;
-    const int C = g.pairC[b];
-    if (C == 0) return;
-    const size_t eoff = (size_t)b * g.estride;
-    const int32_t* rp = g.rowptr + (size_t)b * (g.Cmax + 1);
-    const double* u = fs.u + (size_t)b * g.Cmax;
-    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + grp;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && eig_iters_out) *(eig_iters_out + b * 5) = fs.iters[b];
-    if (c >= C) return;
-    const double uc = u[c];
-    double s = 0.0;
-    for (int k = rp[c] + gl; k < rp[c + 1]; k += 16) {
-        double x = uc * u[g.col[eoff + k]];
-        x = (x < 0.0 ? 0.0 : x) * g.wv[eoff + k];
-        g.xe[eoff + k] = x;
-        s += x;
-    }
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) s += rp_shfl_xor_d(s, m);
-    if (gl == 0) g.state[((size_t)b * 4 + 0) * g.Cmax + c] = s;
 }
 
 // ------------------------------------------------------------------ single-workgroup fit (the default path)
@@ -1172,9 +764,9 @@ __device__ __forceinline__ void write_pose_lds(double* out, const double* Rt) {
     }
 }
 
-template <int THREADS>
+template <int THREADS, bool GVEC>       // GVEC: the three per-correspondence vectors + row / segment pointers in global memory (else LDS)
 __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK, int method,
-                                                                    double* __restrict__ lz_basis, int32_t* __restrict__ status,
+                                                                    double* __restrict__ lz_basis, double* __restrict__ gvec, int32_t* __restrict__ status,
                                                                     double* __restrict__ pose, double* __restrict__ trace,
                                                                     int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out,
                                                                     long long* __restrict__ prof, int tri_rounds) {
@@ -1209,17 +801,26 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     f.max_prod = tri_rounds >> 8;
     const long long tstart_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     f.C = C; f.Cmax = g.Cmax;
-    f.vec = (double*)smem; f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
-    f.tri = f.yy + g.Cmax; f.cbuf = f.tri + 4 * (RP_LZ_M + 1);
-    f.rp = (int32_t*)(f.cbuf + (RP_LZ_M + 1)); f.sp = f.rp + (g.Cmax + 1);
+    const int32_t* rpg = g.rowptr + (size_t)b * (g.Cmax + 1);
+    const int32_t* spg = g.segptr + (size_t)b * (g.Cmax + 1);
+    f.tri = (double*)smem; f.cbuf = f.tri + 4 * (RP_LZ_M + 1);
+    // (a compile-time choice: with a run-time one the compiler no longer knows the address space and emits FLAT accesses for the
+    // LDS layout -- measured +50 % on the whole kernel)
+    if constexpr (GVEC) {   // more correspondences than LDS holds: the three vectors in global scratch, row / segment pointers read in place
+        f.vec = gvec + (size_t)b * 3 * g.Cmax; f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
+        f.rp = const_cast<int32_t*>(rpg); f.sp = const_cast<int32_t*>(spg);
+    } else {
+        f.vec = f.cbuf + (RP_LZ_M + 1); f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
+        f.rp = (int32_t*)(f.yy + g.Cmax); f.sp = f.rp + (g.Cmax + 1);
+    }
     f.red = red;
     const size_t eoff = (size_t)b * g.estride;
     f.col = g.col + eoff; f.wv = g.wv + eoff; f.xe = g.xe + eoff;
     f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
     f.V = lz_basis + (size_t)b * (RP_LZ_M + 1) * g.Cmax;
-    const int32_t* rpg = g.rowptr + (size_t)b * (g.Cmax + 1);
-    const int32_t* spg = g.segptr + (size_t)b * (g.Cmax + 1);
-    for (int c = tid; c <= C; c += blockDim.x) { f.rp[c] = rpg[c]; f.sp[c] = spg[c]; }
+    if constexpr (!GVEC) {
+        for (int c = tid; c <= C; c += blockDim.x) { f.rp[c] = rpg[c]; f.sp[c] = spg[c]; }
+    }
     __syncthreads();
     f.nseg = f.sp[C];
     FitCtx fc;
@@ -1285,12 +886,16 @@ bool kp_ok(const RelposeKeypoints* kp, const RelposeParams* p) {
            kp->weight_s && kp->weight_t;
 }
 
-// the single-workgroup fit keeps 3 vectors + the row pointers of a pair in LDS and packs (row, column) into 32 bits
-static bool fit1_ok(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && !RP_ENV("RELPOSE_LEGACY_FIT"); }
-static size_t fit1_lds(int32_t Cmax) { return (size_t)Cmax * 24 + (size_t)(5 * (RP_LZ_M + 1)) * 8 + (size_t)(Cmax + 1) * 8 + 16; }
+// The fit keeps 3 vectors of C doubles + the row / segment pointers of a pair in LDS up to RP_FIT1_MAXC correspondences; beyond
+// that (or with RELPOSE_TUNE_FIT_GLOBAL_VECTORS) the same kernel keeps them in global scratch (gvec; rowptr / segptr in place).
+static bool fit_in_lds(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && g_rp_tune[RELPOSE_TUNE_FIT_GLOBAL_VECTORS] == 0; }
+static size_t fit_lds_bytes(int32_t Cmax, bool in_lds) {
+    return (size_t)(5 * (RP_LZ_M + 1)) * 8 + 16 + (in_lds ? (size_t)Cmax * 24 + (size_t)(Cmax + 1) * 8 : 0);
+}
+#define RP_MAX_CORRES 8192      // correspondences per pair (ns_max * topK): the fill kernel's row lists are uint16 in 8 * Cmax bytes of LDS
 
 struct WsLayout {
-    size_t corres_j, corres_w, keff, bitmap, upcnt, lowcnt, counters, rowptr, col, wv, xe, state, geo, eig, pairC, lz, segptr, segrow, part, total;
+    size_t corres_j, corres_w, keff, bitmap, upcnt, counters, rowptr, col, wv, xe, state, geo, lz, gvec, segptr, segrow, part, total;
     int32_t Cmax, Wmax, seg_cap;
     int64_t max_edges, estride;
 };
@@ -1309,24 +914,21 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.keff = take((size_t)B * 4);
     L.bitmap = take((size_t)B * L.Cmax * L.Wmax * 8);
     L.upcnt = take((size_t)B * L.Cmax * 4);
-    L.lowcnt = take((size_t)B * L.Cmax * 4);      // lowcnt and counters are contiguous: one memset
     L.counters = take((size_t)B * 4 * 4);
     L.rowptr = take((size_t)B * (L.Cmax + 1) * 4);
-    const bool seg = fit1_ok(L.Cmax);
     // segment layout: every row wastes less than one 32-entry segment; slices of 64 segments
-    L.seg_cap = seg ? (int32_t)(((L.max_edges + RP_SEG - 1) / RP_SEG + L.Cmax + 63) / 64 * 64) : 0;
-    L.estride = seg ? (int64_t)L.seg_cap * RP_SEG : L.max_edges;
+    L.seg_cap = (int32_t)(((L.max_edges + RP_SEG - 1) / RP_SEG + L.Cmax + 63) / 64 * 64);
+    L.estride = (int64_t)L.seg_cap * RP_SEG;
     L.col = take((size_t)B * L.estride * 4);
     L.wv = take((size_t)B * L.estride * 8);
     L.xe = take((size_t)B * L.estride * 8);
-    L.segptr = take(seg ? (size_t)B * (L.Cmax + 1) * 4 : 0);
-    L.segrow = take(seg ? (size_t)B * L.seg_cap * 4 : 0);
-    L.part = take(seg ? (size_t)B * L.seg_cap * 8 : 0);
+    L.segptr = take((size_t)B * (L.Cmax + 1) * 4);
+    L.segrow = take((size_t)B * L.seg_cap * 4);
+    L.part = take((size_t)B * L.seg_cap * 8);
     L.state = take((size_t)B * 4 * L.Cmax * 8);
     L.geo = take((size_t)B * L.Cmax * 12 * 8);
-    L.pairC = take((size_t)B * 4);
-    L.eig = take((size_t)B * (4 * (size_t)L.Cmax + (L.Cmax + RP_SPMV_ROWS - 1) / RP_SPMV_ROWS) * 8 + (size_t)B * 2 * 4);
-    L.lz = take(fit1_ok(L.Cmax) ? (size_t)B * (RP_LZ_M + 1) * L.Cmax * 8 : 0);      // Lanczos basis of the single-workgroup fit
+    L.lz = take((size_t)B * (RP_LZ_M + 1) * L.Cmax * 8);        // Lanczos basis
+    L.gvec = take((size_t)B * 3 * L.Cmax * 8);                  // the fit's three per-correspondence vectors when they do not live in LDS
     L.total = o;
     return L;
 }
@@ -1354,7 +956,7 @@ const char* relpose_version(void) { return "relpose-hip 0.1 (gfx950)"; }
 
 size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, int32_t topK, int64_t max_edges) {
     (void)nt_max;
-    if (B <= 0 || ns_max <= 0 || topK < 1 || topK > RP_MAXK) return 0;
+    if (B <= 0 || ns_max <= 0 || topK < 1 || topK > RP_MAXK || (int64_t)ns_max * topK > RP_MAX_CORRES) return 0;
     return ws_layout(B, ns_max, topK, max_edges).total;
 }
 
@@ -1368,6 +970,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
                         double* pose, int32_t* status, const RelposeMatchDebug* dbg, void* stream) {
     if (!kp_ok(kp, p) || !workspace || !pose || !status) return RELPOSE_EINVAL;
     if (p->method < 0 || p->method > 3) return RELPOSE_EINVAL;
+    if ((int64_t)kp->ns_max * p->topK > RP_MAX_CORRES) return RELPOSE_EINVAL;
     const WsLayout L = ws_layout(kp->B, kp->ns_max, p->topK, max_edges);
     if (workspace_bytes < L.total) return RELPOSE_ENOMEM;
     hipStream_t s = (hipStream_t)stream;
@@ -1379,106 +982,57 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     g.Cmax = L.Cmax; g.Wmax = L.Wmax; g.max_edges = L.max_edges;
     g.corres_j = cj; g.corres_w = cw; g.keff = keff;
     g.bitmap = (unsigned long long*)(ws + L.bitmap);
-    g.upcnt = (int32_t*)(ws + L.upcnt); g.lowcnt = (int32_t*)(ws + L.lowcnt); g.counters = (int32_t*)(ws + L.counters);
+    g.upcnt = (int32_t*)(ws + L.upcnt); g.counters = (int32_t*)(ws + L.counters);
     g.rowptr = (int32_t*)(ws + L.rowptr); g.col = (int32_t*)(ws + L.col);
-    g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state); g.geo = (double*)(ws + L.geo); g.pairC = (int32_t*)(ws + L.pairC);
-    g.seg_layout = fit1_ok(L.Cmax) ? 1 : 0;
+    g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state); g.geo = (double*)(ws + L.geo);
     g.seg_cap = L.seg_cap; g.estride = L.estride;
     g.segptr = (int32_t*)(ws + L.segptr); g.segrow = (int32_t*)(ws + L.segrow); g.part = (double*)(ws + L.part);
-    // tiled pair kernels (symmetric bitmap); RELPOSE_LEGACY_PAIRS = the row-per-wave kernels of round 1 (upper-triangle bitmap).
-    // The fill kernel's row lists are uint16: C <= 65536; its LDS need is 8 * Cmax bytes.
-    g.sym = (!RP_ENV("RELPOSE_LEGACY_PAIRS") && L.Cmax <= 8192) ? 1 : 0;
-    if (g.sym) RP_HIP(hipMemsetAsync(ws + L.counters, 0, (size_t)kp->B * 16, s));
-    else RP_HIP(hipMemsetAsync(ws + L.lowcnt, 0, (L.counters - L.lowcnt) + (size_t)kp->B * 16, s));
+    RP_HIP(hipMemsetAsync(ws + L.counters, 0, (size_t)kp->B * 16, s));
     int rc = rp_launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
     if (rc) return rc;
     const RpPairConsts kc = rp_make_consts(*p);
     dim3 grid_rows((L.Cmax + 3) / 4, kp->B);
-    if (g.sym) hipLaunchKernelGGL(pair_tile_kernel, dim3((unsigned)(L.Wmax * (L.Wmax + 1) / 2), kp->B), dim3(256), 0, s, *kp, g, kc, p->topK);
-    else hipLaunchKernelGGL(pair_flags_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK);
+    hipLaunchKernelGGL(pair_tile_kernel, dim3((unsigned)(L.Wmax * (L.Wmax + 1) / 2), kp->B), dim3(256), 0, s, *kp, g, kc, p->topK);
     RP_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_scan_kernel, dim3(kp->B), dim3(1024), 0, s, *kp, g, status);
     RP_CHECK_LAUNCH();
-    if (g.sym) hipLaunchKernelGGL(pair_fill_rows_kernel, grid_rows, dim3(256), (size_t)4 * L.Cmax * sizeof(unsigned short), s, *kp, g, kc, p->topK, status);
-    else hipLaunchKernelGGL(pair_fill_kernel, grid_rows, dim3(256), 0, s, *kp, g, kc, p->topK, status);
+    hipLaunchKernelGGL(pair_fill_rows_kernel, grid_rows, dim3(256), (size_t)4 * L.Cmax * sizeof(unsigned short), s, *kp, g, kc, p->topK, status);
     RP_CHECK_LAUNCH();
-    // ---- fit: launch sequence (see fit_begin_kernel)
-    FitState fs;
-    fs.nblk = (L.Cmax + RP_SPMV_ROWS - 1) / RP_SPMV_ROWS;
-    fs.u = (double*)(ws + L.eig); fs.y = fs.u + (size_t)kp->B * L.Cmax; fs.y2 = fs.y + (size_t)kp->B * L.Cmax;
-    fs.h = fs.y2 + (size_t)kp->B * L.Cmax;
-    fs.part = fs.h + (size_t)kp->B * L.Cmax;
-    fs.done = (int32_t*)(fs.part + (size_t)kp->B * fs.nblk); fs.iters = fs.done + kp->B;
+    // ---- fit: ONE launch, one workgroup per pair (fit_pair_kernel)
     double* trace = dbg ? dbg->trace : nullptr;
     int32_t* eig_iters = dbg ? dbg->eig_iters : nullptr;
     const int m = p->method;
-    if (g.seg_layout) {
-        // ---- fit: ONE launch, one 1024-thread workgroup per pair (fit_pair_kernel)
-        const size_t lds = fit1_lds(L.Cmax);
+    {
+        const bool in_lds = fit_in_lds(L.Cmax);
+        const size_t lds = fit_lds_bytes(L.Cmax, in_lds);
+        double* gvec = in_lds ? nullptr : (double*)(ws + L.gvec);
         static long long* prof = nullptr;
         if (RP_ENV("RELPOSE_FIT_PROF")) {
             if (!prof) RP_HIP(hipMalloc((void**)&prof, 64));
             RP_HIP(hipMemsetAsync(prof, 0, 64, s));
         }
-        // (multisection rounds | product budget << 8); RELPOSE_LZ_MAXPROD is a test hook: a tiny budget forces RELPOSE_NOT_CONVERGED
+        // (multisection rounds | product budget << 8); RELPOSE_TUNE_FIT_MAX_PRODUCTS is a test hook: a tiny budget forces RELPOSE_NOT_CONVERGED
         const int tri_rounds = (RP_ENV("RELPOSE_TRI_ROUNDS") ? atoi(RP_ENV("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS) |
                                ((g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] > 0 ? g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] : RP_LZ_MAXPROD) << 8);
         // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences,
-        // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 768 | 1024 overrides (experiments).
+        // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 1024 overrides (experiments build).
         const int fit_threads = RP_ENV("RELPOSE_FIT_THREADS") ? atoi(RP_ENV("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);
-        if (fit_threads == 768) {
-            RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fit_pair_kernel<768>, dim3(kp->B), dim3(768), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
-                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds);
-        } else if (fit_threads == 512) {
-            RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fit_pair_kernel<512>, dim3(kp->B), dim3(512), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
-                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds);
-        } else {
-            RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fit_pair_kernel<1024>, dim3(kp->B), dim3(1024), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), status,
-                               pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds);
+#define RP_FIT_LAUNCH(T_, G_)                                                                                                          \
+        {                                                                                                                              \
+            RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<T_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+            hipLaunchKernelGGL((fit_pair_kernel<T_, G_>), dim3(kp->B), dim3(T_), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), gvec,  \
+                               status, pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds);                          \
         }
+        if (fit_threads == 512) { if (in_lds) RP_FIT_LAUNCH(512, false) else RP_FIT_LAUNCH(512, true) }
+        else { if (in_lds) RP_FIT_LAUNCH(1024, false) else RP_FIT_LAUNCH(1024, true) }
+#undef RP_FIT_LAUNCH
         RP_CHECK_LAUNCH();
-        if (prof) {       // debug only: synchronises
+        if (prof) {       // experiments build only: synchronises
             long long h[8];
             RP_HIP(hipStreamSynchronize(s));
             RP_HIP(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
             fprintf(stderr, "[fit prof, pair 0, cycles] products %lld (%lld calls) reorth+norm %lld tridiag %lld irls %lld finish %lld setup %lld\n", h[0], h[6], h[1], h[2], h[4], h[5], h[7]);
         }
-    } else {
-    // ---- legacy fit for > RP_FIT1_MAXC correspondences per pair: launch sequence over the whole GPU (see fit_begin_kernel)
-    dim3 grid16((L.Cmax + 15) / 16, kp->B);
-    hipLaunchKernelGGL(fit_begin_kernel, dim3((L.Cmax + 15) / 16, kp->B), dim3(256), 0, s, *kp, g, p->topK, status, pose, trace, dbg ? dbg->counts : nullptr);
-    hipLaunchKernelGGL(fit_commit_status_kernel, dim3((kp->B + 63) / 64), dim3(64), 0, s, *kp, g, status, kp->B);
-    RP_CHECK_LAUNCH();
-    const bool irls0 = (m == RELPOSE_FIT_IRLS_SM || m == RELPOSE_FIT_IRLS);
-    hipLaunchKernelGGL(fit_irls_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), 0, s, *kp, g, kc, irls0 ? 5 : 1, irls0 ? 1 : 0, 0, status, pose,
-                       trace);
-    RP_CHECK_LAUNCH();
-    if (m == RELPOSE_FIT_IRLS_SM || m == RELPOSE_FIT_SPECTRAL) {
-        const bool sm = (m == RELPOSE_FIT_IRLS_SM);
-        for (int round = 0; round < 5; ++round) {
-            hipLaunchKernelGGL(eig_init_kernel, dim3((L.Cmax + 255) / 256, kp->B), dim3(256), 0, s, *kp, g, fs, status);
-            const double mu_xe = (!sm && round > 0) ? p->mu : 0.0;
-            for (int it = 0; it < RP_EIG_MAX_ITERS; ++it) {
-                // 4 products per normalisation: u -> y2 -> y -> y2 -> y, then eig_norm: u = y/|y|
-                const int j = it % RP_EIG_NORM_EVERY;
-                const int src = (j == 0) ? 0 : ((j & 1) ? 1 : 2), dst = (j & 1) ? 2 : 1;
-                const bool last = (j == RP_EIG_NORM_EVERY - 1);
-                hipLaunchKernelGGL(eig_spmv_kernel, dim3(fs.nblk, kp->B), dim3(RP_SPMV_THREADS), 0, s, *kp, g, fs, mu_xe, status, src, dst, last ? 1 : 0);
-                if (last) hipLaunchKernelGGL(eig_norm_kernel, dim3(kp->B), dim3(256), 0, s, *kp, g, fs, status);
-            }
-            hipLaunchKernelGGL(eig_finish_kernel, grid16, dim3(256), 0, s, *kp, g, fs, status, eig_iters ? eig_iters + round : nullptr);
-            hipLaunchKernelGGL(fit_irls_kernel, dim3(kp->B), dim3(RP_FIT_THREADS), 0, s, *kp, g, kc, sm ? 5 : 1, sm ? 1 : 0, 1, status, pose,
-                               trace ? trace + (round + 1) * 16 : nullptr);
-            RP_CHECK_LAUNCH();
-        }
-    } else if (trace) {
-        for (int q = 1; q < 6; ++q)
-            RP_HIP(hipMemcpy2DAsync(trace + q * 16, 96 * sizeof(double), pose, 16 * sizeof(double), 16 * sizeof(double), kp->B,
-                                    hipMemcpyDeviceToDevice, s));
-    }
     }
     if (dbg && dbg->corres_j)
         RP_HIP(hipMemcpyAsync(dbg->corres_j, cj, (size_t)kp->B * kp->ns_max * p->topK * 4, hipMemcpyDeviceToDevice, s));

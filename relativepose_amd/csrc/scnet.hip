@@ -535,6 +535,75 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
         }
 }
 
+// ---- 16-bit operand modes of the tile kernels (SPLIT 2 = f16x3, 3 = f16; the split modes of conv_igemm_kernel) -------------------------
+// A staged LDS row keeps the 144-byte stride of the fp32 tiles: [32 x fp16 hi | 32 x fp16 lo | pad] -- the geometry (row indices, tap
+// offsets, conflict-free b128 fragment reads) is unchanged; the values are converted ONCE, when the tile is staged, and every
+// (tap, 16-channel step) of a chunk is one v_mfma_f32_32x32x16_f16 per product term (3 terms, or 1 for plain f16) with the fragment
+// read straight from LDS.  The packed weights of these modes are already in the same [hi | lo] k-tile format (finalize).
+template <int SPLIT>
+__device__ __forceinline__ void rp_tile_store_a(float* row, int kq, rp_v2f v01, rp_v2f v23) {
+    if constexpr (SPLIT == 0) *reinterpret_cast<float4*>(row + kq * 4) = make_float4(v01.x, v01.y, v23.x, v23.y);
+    else {
+        typedef typename SplitT<SPLIT>::v4 h4_;
+        const rp_f4v vf_ = {v01.x, v01.y, v23.x, v23.y};
+        const h4_ hi_ = __builtin_convertvector(vf_, h4_);
+        h4_* ar_ = reinterpret_cast<h4_*>(row);
+        ar_[kq] = hi_;
+        if (SPLIT != 3) ar_[8 + kq] = __builtin_convertvector(vf_ - __builtin_convertvector(hi_, rp_f4v), h4_);
+    }
+}
+// one 32-channel chunk of one tap for MI x NI accumulators: a_rows[i] / b_rows[j] are LDS float indices of the lane's fragment rows
+template <int SPLIT, int MI, int NI>
+__device__ __forceinline__ void rp_tile_mma(floatx16 (&acc)[MI][NI], const float* At, const int (&a_rows)[MI], const float* Bt, const int (&b_rows)[NI]) {
+    if constexpr (SPLIT == 0) {
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            float4 a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&At[a_rows[i] + kc * 8]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bt[b_rows[j] + kc * 8]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    } else {
+        typedef typename SplitT<SPLIT>::v8 h8;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            h8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = *reinterpret_cast<const h8*>(&At[a_rows[i] + st * 8]);
+                if (SPLIT != 3) al[i] = *reinterpret_cast<const h8*>(&At[a_rows[i] + 16 + st * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                bh[j] = *reinterpret_cast<const h8*>(&Bt[b_rows[j] + st * 8]);
+                if (SPLIT != 3) bl[j] = *reinterpret_cast<const h8*>(&Bt[b_rows[j] + 16 + st * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr (SPLIT == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    }
+}
+
 // ---- stride-2 4x4 transposed conv, the four sub-pixel phases of a spatial patch in ONE workgroup -------------------------
 // conv_igemm_kernel treats every (phase, tap) of a transposed conv as its own k-tile: a 32-channel chunk of the input is
 // gathered from global memory, BatchNorm-transformed and stored to LDS 16 times per output patch (4 phases x 2x2 taps), which
@@ -553,7 +622,7 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
 // blockIdx.z = N tile of NI * 32 output columns (Cout 64 as two tiles of 32: three workgroups per CU instead of two).
 // PAIR (TC == 8, 4 waves): the workgroup takes TWO 8 x 8 patches (consecutive in patch order, possibly in the two images of one
 // BatchNorm group) with separate 10 x 10 halo tiles -- 56-wide grids tile into 8 x 8 but not into 8 x 16 (deconv3).
-template <int MI, int NI, int NW, int TC, bool PAIR = false>
+template <int MI, int NI, int NW, int TC, bool PAIR = false, int SPLIT = 0>
 __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void deconv_tile_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int NT = NW * 64, TR = 32 / TC;
     constexpr int PR = PAIR ? 8 : (TC == 16 ? TR * MI * NW : TR), PW = PAIR ? 8 : (TC == 16 ? 16 : TC * NW), HW2 = PW + 2;
@@ -675,7 +744,7 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
             if ((it + 1) * PSTEP <= NPIX || tid / KQ + it * PSTEP < NPIX)                                     \
-                *reinterpret_cast<float4*>(&At[a_lds0 + it * PSTEP * LDK]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+                rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LDK], kqa, v01, v23);              \
         }                                                                                                     \
     }
 #define RP_DT_LOAD_B(P, C0)                                                                                    \
@@ -706,23 +775,12 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int aoff = aoffs[p][t];
+                int ar_[MI], br_[NI];
 #pragma unroll
-                for (int kc = 0; kc < BK / 8; ++kc) {
-                    float4 a[MI], b[NI];
+                for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&At[arow[i] + aoff + kc * 8]);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bt[brow + (t * NI + j) * 32 * LDK + kc * 8]);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NI; ++j) {
-                            acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[p][i][j], 0, 0, 0);
-                            acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[p][i][j], 0, 0, 0);
-                            acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[p][i][j], 0, 0, 0);
-                            acc[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[p][i][j], 0, 0, 0);
-                        }
-                }
+                for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LDK;
+                rp_tile_mma<SPLIT, MI, NI>(acc[p], At, ar_, Bt, br_);
             }
             __syncthreads();                                          // every wave is done with this phase's weights (and, p == 3, the halo tile)
             if (p < 3 || !last) RP_DT_STORE_B()
@@ -740,6 +798,15 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
     const int patch = blockIdx.x;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
+        if constexpr (SPLIT == 2 || SPLIT == 3) {          // undo the power-of-two weight pre-scale of the phase (exact)
+            const float wsc = dh[p].wscale;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][i][j][r] *= wsc;
+        }
         if (dh[p].stat_part) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
@@ -784,7 +851,7 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
 // stored to LDS ONCE and the plane's 4 taps are LDS offsets {0, 1} x {0, 1} into that tile (conv_igemm_kernel gathers the PR x PW rows
 // of every one of the 16 taps: 3.3-3.5x the global loads and transforms).  The weight tile of one tap is staged per k-step as before.
 // Geometry as in deconv_tile_kernel: TC == 16: patch 2 MI NW x 16 outputs, tiles stacked; PAIR: two 8 x 8 patches (56-wide grids).
-template <int MI, int NI, int TC, bool PAIR>
+template <int MI, int NI, int TC, bool PAIR, int SPLIT = 0>
 __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int NW = 4, NT = 256, TR = 32 / TC;
     constexpr int PR = PAIR ? 8 : TR * MI * NW, PW = PAIR ? 8 : 16, HW1 = PW + 1;
@@ -900,7 +967,7 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
             if ((it + 1) * PSTEP <= NPIX || tid / KQ + it * PSTEP < NPIX)                                     \
-                *reinterpret_cast<float4*>(&At[a_lds0 + it * PSTEP * LDK]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+                rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LDK], kqa, v01, v23);              \
         }                                                                                                     \
     }
 #define RP_S2_LOAD_B(S)                                                                                        \
@@ -930,22 +997,13 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
             if (sidx + 1 < nstep) RP_S2_LOAD_B(sidx + 1)
             if (tt == 0 && !lastp) RP_S2_LOAD_A((cp + 1) >> 2, (cp + 1) & 3)
             const int aoff = ((tt >> 1) * HW1 + (tt & 1)) * LDK;
+            {
+                int ar_[MI], br_[NI];
 #pragma unroll
-            for (int kc = 0; kc < BK / 8; ++kc) {
-                float4 a[MI], b[NI];
+                for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const float4*>(&At[arow[i] + aoff + kc * 8]);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bt[brow + j * 32 * LDK + kc * 8]);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < NI; ++j) br_[j] = brow + j * 32 * LDK;
+                rp_tile_mma<SPLIT, MI, NI>(acc, At, ar_, Bt, br_);
             }
             __syncthreads();
             if (sidx + 1 < nstep) RP_S2_STORE_B()
@@ -959,6 +1017,14 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
 #undef RP_S2_LOAD_B
 #undef RP_S2_STORE_B
 
+    if constexpr (SPLIT == 2 || SPLIT == 3) {          // undo the power-of-two weight pre-scale (exact)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= d.wscale;
+    }
     // epilogue: one BatchNorm record per workgroup (stat_bm = rows per workgroup, slot 0), then the NHWC stores
     if (d.stat_part) {
         double* red = reinterpret_cast<double*>(&At[0]);              // [NW][NI * 32][2]
@@ -1004,7 +1070,7 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
 // chunk and plane (conv_igemm_kernel: 4 x 128 rows).  Any Wp; a tile may span two images / two BatchNorm groups (scale / shift of both
 // groups in registers, selected per staged position).  Used for split-K layers only: the epilogue writes partial sums
 // [ks][M][cout_pad], reduced (and BatchNorm statistics taken) by the existing kernels.
-template <int NI>
+template <int NI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int BM = 128, SMAX = 224, PSTEP = 256 / KQ, A_SLOTS = SMAX / PSTEP, B_ROWS = NI * 32, B_SLOTS = B_ROWS / PSTEP;
     static_assert(BK == 32 && SMAX % PSTEP == 0 && B_ROWS % PSTEP == 0, "slot layout");
@@ -1049,11 +1115,11 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
 #pragma unroll
     for (int it = 0; it < B_SLOTS; ++it) b_off[it] = ((n0 + tid / KQ + it * PSTEP) * d.K + kqa * 4) * 4;
     const int b_lds0 = (tid / KQ) * LDK + kqa * 4;
-    floatx16 acc[NI];
+    floatx16 acc[1][NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
     const int mrow = min(m0 + 32 * wave + l31, d.M - 1);                        // this lane's MFMA row (rows past M are never stored)
     const int arow = (pos_of(mrow) - pmin) * LDK + h * 4;
     const int brow = l31 * LDK + h * 4;
@@ -1097,7 +1163,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
             const rp_v2f mk_ = {okf_, okf_};                                                                  \
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
-            *reinterpret_cast<float4*>(&At[a_lds0 + it * PSTEP * LDK]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+            rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LDK], kqa, v01, v23);                  \
         }                                                                                                     \
     }
 #define RP_ST_LOAD_B(S)                                                                                        \
@@ -1133,19 +1199,12 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
                     if (((cp + 1) & 3) == 0) RP_ST_LOAD_SS((cp + 1) >> 2)
                 }
                 const int aoff = ((tt >> 1) * W1 + (tt & 1)) * LDK;
+                {
+                    const int ar_[1] = {arow + aoff};
+                    int br_[NI];
 #pragma unroll
-                for (int kc = 0; kc < BK / 8; ++kc) {
-                    float4 b[NI];
-                    const float4 a = *reinterpret_cast<const float4*>(&At[arow + aoff + kc * 8]);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const float4*>(&Bt[brow + j * 32 * LDK + kc * 8]);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[j].x, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[j].y, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[j].z, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[j].w, acc[j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < NI; ++j) br_[j] = brow + j * 32 * LDK;
+                    rp_tile_mma<SPLIT, 1, NI>(acc, At, ar_, Bt, br_);
                 }
                 __syncthreads();
                 if (sidx + 1 < s_end) RP_ST_STORE_B()
@@ -1162,13 +1221,14 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
 #undef RP_ST_LOAD_B
 #undef RP_ST_STORE_B
     // partial sums of this K slice (an empty slice writes zeros): reduced in fixed order by splitk_reduce_kernel
+    const float wsc = (SPLIT == 2 || SPLIT == 3) ? d.wscale : 1.f;             // (16-bit modes: the power-of-two weight pre-scale, exact)
     float* po = d.partial + (size_t)ks * d.M * d.cout_pad;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m >= d.M) continue;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) rp_stg(po + (size_t)m * d.cout_pad + n0 + j * 32 + l31, acc[j][r]);
+        for (int j = 0; j < NI; ++j) rp_stg(po + (size_t)m * d.cout_pad + n0 + j * 32 + l31, acc[0][j][r] * wsc);
     }
 }
 
@@ -2179,7 +2239,7 @@ void Builder::end_group() {
         dt_cfg = Wg % 16 == 0 ? (cp == 32 ? 2 : 1) : ((Wg == 56 && dt_strip) ? 3 : ((Wg % 8 == 0 && !no_pair) ? 4 : -1));
         if (dt_var >= 0 && dt_var <= 2 && Wg % 16 == 0 && !(dt_var == 0 && cp != 32) && !(dt_var == 1 && cp != 64)) dt_cfg = dt_var;
         const int PRt = dt_cfg == 0 ? 16 : (dt_cfg == 3 ? 4 : 8), PWt = dt_cfg == 3 ? 56 : (dt_cfg == 4 ? 8 : 16);
-        dtile = !no_dt && dt_cfg >= 0 && net->prec == 0 && (cp == 32 || cp == 64) && count % 4 == 0;
+        dtile = !no_dt && dt_cfg >= 0 && net->prec != 1 && (cp == 32 || cp == 64) && count % 4 == 0;
         for (int i = first; i < first + count && dtile; ++i) {
             const ConvDesc& d = plan->descs[i];
             const ConvDesc& d0 = plan->descs[first + ((i - first) & ~3)];
@@ -2195,7 +2255,7 @@ void Builder::end_group() {
     {
         static const bool no_s2 = RP_ENV("RELPOSE_NO_CONV_S2") != nullptr;
         const ConvDesc& d0 = plan->descs[first];
-        if (!no_s2 && !dtile && net->prec == 0) {
+        if (!no_s2 && !dtile && net->prec != 1) {
             static const bool s2_small = RP_ENV("RELPOSE_S2_SMALL") != nullptr;     // experiment: 8 x 16 patches, 4 workgroups per CU
             if (cp == 64 && d0.Hp % 16 == 0 && d0.Wp % 16 == 0) s2_cfg = s2_small ? 2 : 0;
             else if (cp == 128 && d0.Hp % 8 == 0 && d0.Wp % 8 == 0 && ((d0.Hp / 8) * (d0.Wp / 8) * 2) % 2 == 0 && n % 2 == 0) s2_cfg = 1;
@@ -2250,13 +2310,13 @@ void Builder::end_group() {
         }
     }
     if (s2_cfg >= 0) {
-        Op o; o.type = OP_CONV_S2; o.first = first; o.count = count; o.cfg = s2_cfg;
+        Op o; o.type = OP_CONV_S2; o.first = first; o.count = count; o.cfg = s2_cfg; o.split = net->prec;
         o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count, 1);
         plan->ops.push_back(o);
         return;
     }
     if (dtile) {
-        Op o; o.type = OP_DECONV_TILE; o.first = first; o.count = count; o.cfg = dt_cfg;
+        Op o; o.type = OP_DECONV_TILE; o.first = first; o.count = count; o.cfg = dt_cfg; o.split = net->prec;
         o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count / 4, dt_cfg >= 2 ? cp / 32 : 1);
         plan->ops.push_back(o);
         return;
@@ -2265,13 +2325,13 @@ void Builder::end_group() {
         static const bool no_strip = RP_ENV("RELPOSE_NO_CONV_STRIP") != nullptr;
         const ConvDesc& d = plan->descs[first];
         const int hw = d.Hp * d.Wp;
-        bool ok = !no_strip && net->prec == 0 && count == 1 && ksplit > 1 && cfg == 0 && cp % 128 == 0 && d.osy == 1 && d.osx == 1 && d.sy == 2 && d.sx == 2 &&
+        bool ok = !no_strip && net->prec != 1 && count == 1 && ksplit > 1 && cfg == 0 && cp % 128 == 0 && d.osy == 1 && d.osx == 1 && d.sy == 2 && d.sx == 2 &&
                   d.ntaps == 16 && d.offy[0] == -1 && d.offx[0] == -1 && d.offy[15] == 2 && d.offx[15] == 2 && d.nsrc == 1 && d.src[0].sstride != 0 && !d.bias &&
                   d.Hin == 2 * d.Hp && d.Win == 2 * d.Wp && hw >= 128;
         // staged positions of a 128-pixel tile: 127 + row wraps + one image crossing + the taps' reach
         ok = ok && 127 + (127 + d.Wp - 1) / d.Wp + (d.Wp + 1) + (d.Wp + 1) + 2 <= 224;
         if (ok) {
-            Op o; o.type = OP_CONV_STRIP; o.first = first; o.count = 1; o.cfg = 0;
+            Op o; o.type = OP_CONV_STRIP; o.first = first; o.count = 1; o.cfg = 0; o.split = net->prec;
             o.grid = dim3((unsigned)((d.M + 127) / 128), (cp / 128) * ksplit, 1);
             plan->ops.push_back(o);
             Op r; r.type = OP_REDUCE; r.first = first; r.count = count; r.cfg = 0; r.grid = dim3(256, 1, count);
@@ -2643,21 +2703,47 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
             mark(-1);
         } else if (op.type == OP_CONV_STRIP) {
             mark(1);
-            hipLaunchKernelGGL((conv_s2_strip_kernel<4>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+            // (op.split: 0 = fp32 products, 2 = f16x3, 3 = f16 -- the tile kernels stage 16-bit operands themselves; bf16x3 stays on conv_igemm_kernel)
+#define RP_TILE_SPLIT(LAUNCH_)                                            \
+            do {                                                          \
+                if (op.split == 2) { LAUNCH_(2); }                        \
+                else if (op.split == 3) { LAUNCH_(3); }                   \
+                else { LAUNCH_(0); }                                      \
+            } while (0)
+#define RP_L_STRIP(SP_) hipLaunchKernelGGL((conv_s2_strip_kernel<4, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
+            RP_TILE_SPLIT(RP_L_STRIP);
+#undef RP_L_STRIP
             mark(-1);
         } else if (op.type == OP_CONV_S2) {
             mark(1);
-            if (op.cfg == 0) hipLaunchKernelGGL((conv_s2_tile_kernel<2, 2, 16, false>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
-            else if (op.cfg == 2) hipLaunchKernelGGL((conv_s2_tile_kernel<1, 2, 16, false>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
-            else hipLaunchKernelGGL((conv_s2_tile_kernel<1, 4, 8, true>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
+#define RP_L_S2A(SP_) hipLaunchKernelGGL((conv_s2_tile_kernel<2, 2, 16, false, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
+#define RP_L_S2B(SP_) hipLaunchKernelGGL((conv_s2_tile_kernel<1, 2, 16, false, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
+#define RP_L_S2C(SP_) hipLaunchKernelGGL((conv_s2_tile_kernel<1, 4, 8, true, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
+            if (op.cfg == 0) RP_TILE_SPLIT(RP_L_S2A);
+            else if (op.cfg == 2) RP_TILE_SPLIT(RP_L_S2B);
+            else RP_TILE_SPLIT(RP_L_S2C);
+#undef RP_L_S2A
+#undef RP_L_S2B
+#undef RP_L_S2C
             mark(-1);
         } else if (op.type == OP_DECONV_TILE) {
             mark(1);
-            if (op.cfg == 0) hipLaunchKernelGGL((deconv_tile_kernel<2, 1, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
-            else if (op.cfg == 1) hipLaunchKernelGGL((deconv_tile_kernel<1, 2, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
-            else if (op.cfg == 2) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 16>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
-            else if (op.cfg == 4) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 8, true>), op.grid, dim3(256), 0, s, plan->d_descs + op.first);
-            else hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 7, 8>), op.grid, dim3(448), 0, s, plan->d_descs + op.first);
+#define RP_L_DT0(SP_) hipLaunchKernelGGL((deconv_tile_kernel<2, 1, 4, 16, false, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
+#define RP_L_DT1(SP_) hipLaunchKernelGGL((deconv_tile_kernel<1, 2, 4, 16, false, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
+#define RP_L_DT2(SP_) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 16, false, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
+#define RP_L_DT4(SP_) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 8, true, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
+#define RP_L_DT3(SP_) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 7, 8, false, SP_>), op.grid, dim3(448), 0, s, plan->d_descs + op.first)
+            if (op.cfg == 0) RP_TILE_SPLIT(RP_L_DT0);
+            else if (op.cfg == 1) RP_TILE_SPLIT(RP_L_DT1);
+            else if (op.cfg == 2) RP_TILE_SPLIT(RP_L_DT2);
+            else if (op.cfg == 4) RP_TILE_SPLIT(RP_L_DT4);
+            else RP_TILE_SPLIT(RP_L_DT3);
+#undef RP_L_DT0
+#undef RP_L_DT1
+#undef RP_L_DT2
+#undef RP_L_DT3
+#undef RP_L_DT4
+#undef RP_TILE_SPLIT
             mark(-1);
         } else if (op.type == OP_CONV1) {
             mark(1);

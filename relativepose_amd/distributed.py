@@ -32,6 +32,9 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+COLLECTIVES = {"all_gather": 0}      # data-path collectives issued by this process (bench.py reports the count)
+
+
 def gather_poses(pose_local, status_local, total, world):
     """all_gather of per-rank [b_r,4,4] poses and [b_r] status into [total,4,4] / [total] on every rank
     (ragged blocks are padded to the largest block)."""
@@ -46,6 +49,7 @@ def gather_poses(pose_local, status_local, total, world):
     buf[:b, 16] = status_local.to(torch.float64)
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
+    COLLECTIVES["all_gather"] += 1
     poses, status = [], []
     for r in range(world):
         lo, hi = shard_range(total, r, world)

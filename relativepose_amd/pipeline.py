@@ -8,8 +8,8 @@ B scan pairs and kept on the device from the input panoramas to the 4x4 poses:
         compose + sample keypoint primitives          evaluation.py:246-253, getMatchingPrimitive
         spectral matching + robust fit -> R_hat        RelativePoseEstimation_helper
 
-Keypoints are an input (the reference detects them with cv2 SIFT + random
-sampling, rputil.getKeypoint; not part of this build -- SURVEY.md §8a a6.3).
+Keypoints are an input of this batched pipeline (the reference detects them per level with cv2 SIFT + feature-guided + random
+sampling, rputil.getKeypoint: built in relativepose_amd.rputil around a SIFT-detector hook).
 """
 import os
 

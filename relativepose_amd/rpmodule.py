@@ -10,10 +10,9 @@ rputil.py for the hot-path entry points:
   RelativePoseEstimationViaCompletion rpmodule.py:569  (the recurrent completion / matching loop for one scan pair)
   match_pairs                        batched device API the helper is built on
 
-Keypoint DETECTION (rputil.getKeypoint / getKeypoint_kinect: cv2 SIFT + feature-guided + random sampling,
-rputil.py:141-353) is not part of this build (third-party OpenCV-contrib, RNG driven).  The
-shims call a *keypoint provider* with the reference's own getKeypoint signature instead; install one with
-``set_keypoint_provider`` -- e.g. the reference's getKeypoint itself, or ``fixed_keypoints(...)`` for injected points.
+Keypoints come from rputil.getKeypoint / getKeypoint_kinect (rputil.py:141-353; everything but the cv2 SIFT detector is built, the
+detector is a hook: rputil.set_sift_detector) or from a *keypoint provider* with the same signature installed with
+``set_keypoint_provider`` -- e.g. ``fixed_keypoints(...)`` for injected points (parity tests, bench).
 
 Degenerate inputs return identity like the reference; status codes say why.
 """
@@ -193,13 +192,21 @@ def fixed_keypoints(pts, ptsW, ptt, pttW):
 
 
 def getKeypoint(rgbS, rgbT, featS, featT, *rest):
-    if _keypoint_provider is None:
-        raise RuntimeError("relativepose_amd: keypoint detection (cv2 SIFT, rputil.getKeypoint) is not part of this build; "
-                           "install a provider with rpmodule.set_keypoint_provider(fn)")
-    return _keypoint_provider(rgbS, rgbT, featS, featT, *rest)
+    """rputil.getKeypoint (rputil.py:141-237) -- or the installed provider (set_keypoint_provider; the parity tests and the bench inject
+    fixed keypoints).  Without a provider the reference-named assembly in rputil runs: SIFT through rputil.set_sift_detector / cv2,
+    everything else on the GPU."""
+    if _keypoint_provider is not None:
+        return _keypoint_provider(rgbS, rgbT, featS, featT, *rest)
+    from . import rputil
+    return rputil.getKeypoint(rgbS, rgbT, featS, featT)
 
 
-getKeypoint_kinect = getKeypoint
+def getKeypoint_kinect(rgbS, rgbT, featS, featT, rgbS_full=None, rgbT_full=None):
+    """rputil.getKeypoint_kinect (rputil.py:240-353), or the installed provider."""
+    if _keypoint_provider is not None:
+        return _keypoint_provider(rgbS, rgbT, featS, featT, rgbS_full, rgbT_full)
+    from . import rputil
+    return rputil.getKeypoint_kinect(rgbS, rgbT, featS, featT, rgbS_full, rgbT_full)
 
 
 def getMatchingPrimitive(dataS, dataT, dataset, representation, doCompletion):

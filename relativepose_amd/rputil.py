@@ -6,7 +6,11 @@
   Sampling        rputil.py:355-371    NMS keypoint sampling on distance maps
   feature_distance_map_dev             the descriptor-to-map distance of getKeypoint :182-190
 
-SIFT detection (getKeypoint's cv2 part) is not built: see rpmodule.set_keypoint_provider."""
+  getKeypoint / getKeypoint_kinect  rputil.py:141-353  everything AROUND the SIFT detector: descriptor sampling at the detected points,
+                                   feature-guided augmentation (distance maps + NMS on the GPU), random fill, weights
+
+SIFT detection itself (cv2.xfeatures2d, third-party) is a hook: set_sift_detector(fn), fn(gray uint8 [h,w]) -> [[x, y], ...]; when
+cv2 with xfeatures2d is importable it is the default."""
 import numpy as np
 
 from . import _lib
@@ -83,3 +87,138 @@ def getPixel(depth, normal, pts, dataset='suncg', representation='skybox'):
     _lib.check(_lib.lib().relpose_get_pixel(_lib.ptr(d), _lib.ptr(n), _lib.ptr(p), k, h, dataset_id(dataset), _lib.ptr(pc), _lib.ptr(nn),
                                             _lib.stream_ptr()), "relpose_get_pixel")
     return pc.cpu().numpy().T, nn.cpu().numpy()
+
+
+# ---- keypoint assembly (rputil.py:141-353) ------------------------------------------------------------------------------------
+_sift_detector = None
+
+
+def set_sift_detector(fn):
+    """fn(gray: uint8 [h, w]) -> array-like [[x, y], ...] (sub-pixel, image coordinates of `gray`): the detector behind getKeypoint
+    / getKeypoint_kinect (the reference: cv2.xfeatures2d.SIFT_create(contrastThreshold=0.02).detectAndCompute, rputil.py:152-156).
+    Returns the previous detector."""
+    global _sift_detector
+    old, _sift_detector = _sift_detector, fn
+    return old
+
+
+def _detect(gray):
+    if _sift_detector is not None:
+        return np.asarray(_sift_detector(gray), dtype=np.float64).reshape(-1, 2)
+    try:
+        import cv2
+        sift = cv2.xfeatures2d.SIFT_create(contrastThreshold=0.02)
+    except Exception as e:
+        raise RuntimeError("relativepose_amd.rputil: no SIFT detector (cv2.xfeatures2d is not importable); install one with "
+                           "rputil.set_sift_detector(fn)") from e
+    kps, _ = sift.detectAndCompute(gray, None)
+    return np.array([k.pt for k in kps], dtype=np.float64).reshape(-1, 2)
+
+
+def bgr2gray(img):
+    """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) for uint8 images: OpenCV's 14-bit fixed-point weights (B 1868, G 9617, R 4899)."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+    b, g, r = (img[..., k].astype(np.int64) for k in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def _v(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).float()
+
+
+def _augment(query_desc, feat_other, topk, W, H):
+    """rputil.py:186-196: for every query descriptor (columns of query_desc [C, n]) the `topk` NMS minima of its squared distance
+    to every pixel of the other view's feature map (dense distance map + Sampling, both on the GPU), as [n*topk, 2] pixel coords,
+    points on the last row / column dropped."""
+    if query_desc.shape[1] == 0:
+        return np.zeros((0, 2))
+    dist = feature_distance_map_dev(query_desc.t().contiguous(), feat_other)
+    aug = sampling_dev(dist, topk).cpu().numpy().reshape(-1, 2)
+    return aug[(aug[:, 0] < W - 1) * (aug[:, 1] < H - 1)]
+
+
+def _finish(pts, ptt, inside, W, H, marker):
+    ptsNorm, pttNorm = pts.astype('float').copy(), ptt.astype('float').copy()
+    ptsNorm[:, 0] /= W; ptsNorm[:, 1] /= H
+    pttNorm[:, 0] /= W; pttNorm[:, 1] /= H
+    ptsW, pttW = np.ones(len(pts)), np.ones(len(ptt))
+    ptsW[~inside(pts)] *= marker
+    pttW[~inside(ptt)] *= marker
+    return pts, ptsNorm, ptsW, ptt, pttNorm, pttW
+
+
+def _keypoints_common(pts, ptt, feats, featt, inside, n_match, n_random_draw, n_random_keep, marker=0.99, topk=2):
+    """The part of getKeypoint / getKeypoint_kinect behind the detector (rputil.py:169-237 / :284-353), same order of np.random calls
+    as the reference (choice, choice, rand, rand, choice): detected points -> descriptors -> cross-view augmentation -> random points of
+    the unobserved region with their augmentation -> weights (1 inside the observed region, `marker` outside)."""
+    import torch
+    dev = _lib.require_gpu()
+    feats, featt = feats.to(dev, torch.float32).contiguous(), featt.to(dev, torch.float32).contiguous()
+    C, H, W = feats.shape
+    nrm = lambda p: p.astype('float') / np.array([W, H], dtype=np.float64)
+    fs0 = interpolate(feats, _v(nrm(pts)))
+    ft0 = interpolate(featt, _v(nrm(ptt)))
+    fsselect = np.random.choice(range(pts.shape[0]), min(n_match, pts.shape[0]))
+    ftselect = np.random.choice(range(ptt.shape[0]), min(n_match, ptt.shape[0]))
+    sel = lambda f, idx: f[:, torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(dev)]
+    pttAug = _augment(sel(fs0, fsselect), featt, topk, W, H)
+    ptsAug = _augment(sel(ft0, ftselect), feats, topk, W, H)
+    pts = np.concatenate((pts, ptsAug))
+    ptt = np.concatenate((ptt, pttAug))
+    xs = (np.random.rand(n_random_draw) * W).astype('int').clip(0, W - 2)
+    ys = (np.random.rand(n_random_draw) * H).astype('int').clip(0, H - 2)
+    ptsrnd = np.stack((xs, ys), 1)
+    ptsrnd = ptsrnd[~inside(ptsrnd)]
+    fs0 = interpolate(feats, _v(nrm(ptsrnd)))
+    fsselect = np.random.choice(range(ptsrnd.shape[0]), min(n_random_keep, ptsrnd.shape[0]))
+    pttAug = _augment(sel(fs0, fsselect), featt, topk, W, H)
+    pts = np.concatenate((pts, ptsrnd[fsselect]))
+    ptt = np.concatenate((ptt, pttAug))
+    return _finish(pts, ptt, inside, W, H, marker)
+
+
+def getKeypoint(rs, rt, feats, featt):
+    """rputil.py:141-237, same signature and return value: rs / rt uint8 BGR panoramas [h, 4h, 3], feats / featt torch [32, h, 4h]
+    -> (pts, ptsNorm, ptsW, ptt, pttNorm, pttW) or 6 x None when a view has no detections.  SIFT runs on the observed face only
+    (columns [h, 2h)); np.random is drawn in the reference's order (seed it for reproducible keypoints)."""
+    H = feats.shape[1]
+    W = feats.shape[2]
+    pts = _detect(np.ascontiguousarray(bgr2gray(rs)[:, H:2 * H]))
+    if not len(pts):
+        return None, None, None, None, None, None
+    pts[:, 0] += H
+    ptt = _detect(np.ascontiguousarray(bgr2gray(rt)[:, H:2 * H]))
+    if not len(ptt):
+        return None, None, None, None, None, None
+    ptt[:, 0] += H
+    inside = lambda p: (p[:, 0] >= H) * (p[:, 0] <= H * 2)
+    return _keypoints_common(pts, ptt, feats, featt, inside, n_match=30, n_random_draw=30, n_random_keep=30)
+
+
+def getKeypoint_kinect(rs, rt, feats, featt, rs_full, rt_full):
+    """rputil.py:240-353, same signature: SIFT on the full 640x480 kinect frames rs_full / rt_full, detections mapped into the 88x66
+    observed crop of the panorama, 300 of them drawn (with replacement, like the reference's np.random.choice), then the common
+    assembly with 120 random draws / 100 kept."""
+    H = feats.shape[1]
+    W = feats.shape[2]
+    KW, KH, FW, FH = 640, 480, 88, 66
+    x0, y0 = H + H // 2 - FW // 2, H // 2 - FH // 2
+
+    def detect(full):
+        p = _detect(bgr2gray(full))
+        if len(p):
+            p[:, 0] = p[:, 0] / KW * FW + x0
+            p[:, 1] = p[:, 1] / KH * FH + y0
+        return p
+    pts = detect(rs_full)
+    if not len(pts):
+        return None, None, None, None, None, None
+    ptt = detect(rt_full)
+    if not len(ptt):
+        return None, None, None, None, None, None
+    pts = pts[np.random.choice(range(len(pts)), 300), :]
+    ptt = ptt[np.random.choice(range(len(ptt)), 300), :]
+    inside = lambda p: ((p[:, 0] >= x0) * (p[:, 0] <= H + H // 2 + FW // 2) * (p[:, 1] >= y0) * (p[:, 1] <= H // 2 + FH // 2))
+    return _keypoints_common(pts, ptt, feats, featt, inside, n_match=30, n_random_draw=120, n_random_keep=100)

@@ -238,3 +238,31 @@ def make_wc_pair(seed, n_match=150, n_free=50, angle=0.2, shift=0.25, h=H, margi
     ptw = np.ones((1, 2, N))
     data = {"rgb": rgb[None], "norm": nrm[None], "depth": dep[None], "R": poses[None]}
     return data, pts, ptw, np.linalg.inv(T1) @ T0
+
+
+def make_keypoint_case(seed, kind="second", h=H):
+    """Inputs of rputil.getKeypoint ('second') / getKeypoint_kinect ('kinect') with the SIFT detections given: two uint8 BGR panoramas,
+    two smooth [32,h,4h] float32 feature maps (low-resolution noise, bilinearly upsampled: every distance map has well-separated
+    minima), seeded sub-pixel detections in the detector's image coordinates (the observed face [h,h] / the 640x480 kinect frame),
+    and the two full kinect frames (None for 'second').  Returns (rs, rt, feats, featt, det_s, det_t, rs_full, rt_full)."""
+    rs_ = np.random.RandomState(seed)
+    w = 4 * h
+
+    def smooth(c):
+        lo = rs_.randn(c, h // 8 + 1, w // 8 + 1)
+        ys, xs = np.linspace(0, h // 8, h), np.linspace(0, w // 8, w)
+        y0, x0 = np.minimum(ys.astype(int), h // 8 - 1), np.minimum(xs.astype(int), w // 8 - 1)
+        fy, fx = (ys - y0)[None, :, None], (xs - x0)[None, None, :]
+        a, b = lo[:, y0][:, :, x0], lo[:, y0][:, :, x0 + 1]
+        c_, d = lo[:, y0 + 1][:, :, x0], lo[:, y0 + 1][:, :, x0 + 1]
+        return np.ascontiguousarray(((a * (1 - fx) + b * fx) * (1 - fy) + (c_ * (1 - fx) + d * fx) * fy).astype(np.float32))
+    feats, featt = smooth(32), smooth(32)
+    rs = rs_.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    rt = rs_.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    if kind == "kinect":
+        rs_full = rs_.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+        rt_full = rs_.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+        det = lambda n: np.stack((rs_.uniform(2, 636, n), rs_.uniform(2, 476, n)), 1)
+        return rs, rt, feats, featt, det(57), det(43), rs_full, rt_full
+    det = lambda n: np.stack((rs_.uniform(1, h - 3, n), rs_.uniform(1, h - 3, n)), 1)
+    return rs, rt, feats, featt, det(41), det(25), None, None

@@ -8,6 +8,7 @@ MATCH_CASES = [  # (N, Nt, seed, dataset, param row, inlier fraction)
     (2, 2, 19, "suncg", 0, 0.6), (6, 4, 20, "suncg", 0, 0.6), (30, 30, 21, "suncg", 0, 0.0),
 ]
 MATCH_METHODS = ("irls+sm", "horn87", "irls", "spectral")
+MATCH_BIG = (1000, 1000, 77, "suncg", 0, 0.8, 0.002)      # (N, Nt, seed, dataset, param row, inlier fraction, noise): matcher_big.npz
 
 GEOM_CASES = (("suncg", "second", 100), ("matterport", "second", 200), ("scannet", "kinect", 300))
 WARP_ANGLES = (0.3, 1.5, 3.141592653589793)
@@ -34,8 +35,11 @@ WC_SIGMAS = (0.26, 0.26, 0.04, 0.1)      # sigmaAngle1, sigmaAngle2, sigmaDist, 
 # the same kind of fixture under the other two dataset conventions (e2e_wc2.npz): Matterport = 'second' mask, S=21, face rotations
 # Rs[(i-1)%4]; ScanNet = 'kinect' mask (66x88 observed crop: smaller margin, smaller motion so that the matches stay inside), S=21, no tanh
 WC2_CASES = (
-    ("matterport", "second", 21, 1, 9100, dict(n_match=170, n_free=30, angle=0.15, shift=0.2, margin=14.0)),
-    ("matterport", "second", 21, 1, 9102, dict(n_match=170, n_free=30, angle=0.15, shift=0.2, margin=14.0)),
+    ("matterport", "second", 21, 1, 9106, dict(n_match=170, n_free=30, angle=0.15, shift=0.2, margin=14.0)),
+    ("matterport", "second", 21, 1, 9108, dict(n_match=170, n_free=30, angle=0.15, shift=0.2, margin=14.0)),
     ("scannet", "kinect", 21, 0, 9200, dict(n_match=170, n_free=30, angle=0.08, shift=0.1, margin=6.0)),
     ("scannet", "kinect", 21, 0, 9202, dict(n_match=170, n_free=30, angle=0.08, shift=0.1, margin=6.0)),
 )
+
+# rputil.getKeypoint / getKeypoint_kinect minus the SIFT detector (getkeypoint.npz): (kind, seed) for synth.make_keypoint_case
+GK_CASES = (("second", 31), ("second", 32), ("kinect", 33), ("kinect", 34))

@@ -6,7 +6,7 @@ regenerated from seeds, expected outputs are stored) travel with the repo.
     python tests/golden/make_golden.py            # all groups
     python tests/golden/make_golden.py matcher    # one group
 
-Groups: matcher, geometry, scnet, e2e, e2e_env, e2e_wc, e2e_wc2, stats, keypoints, metrics.  See SURVEY.md §8c for the plan.
+Groups: matcher, matcher_big, geometry, scnet, e2e, e2e_env, e2e_wc, e2e_wc2, stats, keypoints, getkeypoint, metrics.  See SURVEY.md §8c for the plan.
 """
 import hashlib
 import os
@@ -64,6 +64,22 @@ def gen_matcher():
             out[f"pose_{ci}_{method}"] = pose
     out["params_suncg"], out["params_matterport"], out["params_scannet"] = (params[k] for k in ("suncg", "matterport", "scannet"))
     np.savez_compressed(os.path.join(HERE, "matcher.npz"), **out)
+
+
+def gen_matcher_big():
+    """One pair with N = 1000 keypoints per view (5000 correspondences, 12.5 M candidate pairs -- beyond what the fit keeps in LDS):
+    the reference helper's pose (cases.MATCH_BIG)."""
+    from cases import MATCH_BIG
+    R = ref_loader.load()
+    rp, ru = R["rpmodule"], R["rputil"]
+    params = load_params()
+    N, Nt, seed, ds, row, inl, noise = MATCH_BIG
+    S, T, G = synth.make_match_case(N, seed, inlier=inl, noise=noise, Nt=Nt)
+    para = ru.opts(*params[ds][row])
+    t = time.time()
+    pose = rp.RelativePoseEstimation_helper(S, T, para)
+    print(f"matcher_big N={N}: {time.time()-t:.1f}s, rot err vs ground truth {np.linalg.norm(pose[:3,:3]-G[:3,:3]):.2e}")
+    np.savez_compressed(os.path.join(HERE, "matcher_big.npz"), pose=pose, params=params[ds][row])
 
 
 def _views(ds, seed, method):
@@ -377,6 +393,39 @@ def gen_keypoints():
     np.savez_compressed(os.path.join(HERE, "keypoints.npz"), **out)
 
 
+def gen_getkeypoint():
+    """rputil.getKeypoint / getKeypoint_kinect of the REFERENCE (rputil.py:141-353) with its cv2 dependency replaced by a stub that
+    returns FIXED detections (cases.GK_CASES: seeded sub-pixel points in the observed region) and the fixed-point BGR->gray
+    conversion; np.random seeded right before the call.  Inputs are regenerated from seeds by the test (synth.make_keypoint_case)."""
+    import types
+    import torch
+    from cases import GK_CASES
+    R = ref_loader.load()
+    ru = R["rputil"]
+    from relativepose_amd import rputil as mine
+    out = {}
+    for ci, (kind, seed) in enumerate(GK_CASES):
+        rs, rt, feats, featt, det_s, det_t, rs_full, rt_full = synth.make_keypoint_case(seed, kind)
+        queue = [det_s, det_t]
+
+        class FakeSift:
+            def detectAndCompute(self, gray, mask):
+                pts = queue.pop(0)
+                return [types.SimpleNamespace(pt=(float(x), float(y))) for x, y in pts], None
+        ru.cv2.COLOR_BGR2GRAY = 6
+        ru.cv2.cvtColor = lambda img, code: mine.bgr2gray(img)
+        ru.cv2.xfeatures2d = types.SimpleNamespace(SIFT_create=lambda **kw: FakeSift())
+        np.random.seed(seed)
+        if kind == "kinect":
+            res = ru.getKeypoint_kinect(rs, rt, torch.from_numpy(feats), torch.from_numpy(featt), rs_full, rt_full)
+        else:
+            res = ru.getKeypoint(rs, rt, torch.from_numpy(feats), torch.from_numpy(featt))
+        for name, a in zip(("pts", "ptsNorm", "ptsW", "ptt", "pttNorm", "pttW"), res):
+            out[f"gk_{ci}_{name}"] = np.asarray(a)
+        print(f"getkeypoint case {ci} {kind}: {len(res[0])} source / {len(res[3])} target keypoints, weights==1: {int((res[2]==1).sum())}/{int((res[5]==1).sum())}")
+    np.savez_compressed(os.path.join(HERE, "getkeypoint.npz"), **out)
+
+
 def gen_stats():
     """util.parse_data + util.point_cloud_overlap of the reference on synthetic pairs."""
     R = ref_loader.load()
@@ -410,7 +459,7 @@ def gen_metrics():
 
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
-    groups = sys.argv[1:] or ["matcher", "geometry", "scnet", "e2e", "e2e_env", "e2e_wc", "e2e_wc2", "stats", "keypoints", "metrics"]
+    groups = sys.argv[1:] or ["matcher", "matcher_big", "geometry", "scnet", "e2e", "e2e_env", "e2e_wc", "e2e_wc2", "stats", "keypoints", "getkeypoint", "metrics"]
     for g in groups:
         t = time.time()
         globals()["gen_" + g]()

@@ -70,6 +70,29 @@ def test_bench_gpus2_spawns_its_own_ranks():
     assert r["config"]["pairs_per_step_total"] == 8 and r["status_ok_fraction"] == 1.0
 
 
+def test_bench_eight_rank_plumbing_ragged_and_even():
+    """Eight ranks -- the world size the scaling run uses -- through the one-device gloo hook (no 8-GPU node is available to the build):
+    (a) configs[3]'s 256 pairs split evenly, --gather run: ONE all_gather in the whole timed region; (b) a ragged split (250 pairs =
+    six shards of 31 and two of 32... i.e. blocks differing by one pair), one gather per step.  Checked: every pair is owned exactly
+    once, the collective counts, the whole-job value.  (Small keypoint count: eight processes time-slice one GPU.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RELPOSE_DIST_BACKEND="gloo", RELPOSE_FORCE_DEVICE="0")
+    for total, steps, want_gathers in ((256, 2, 1), (250, 2, 2)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "3", "--scaling", "strong", "--total-pairs", str(total),
+                              "--steps", str(steps), "--warmup", "0", "--keypoints", "40", "--batches", "2", "--no-aux", "--no-h2d"],
+                             capture_output=True, text=True, timeout=2400, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        r = json.loads(lines[0])
+        c = r["config"]
+        assert r["n_gpus"] == 8 and c["dist_world_size"] == 8 and r["scaling"] == "strong"
+        assert sum(c["shard_sizes"]) == total == c["pairs_per_step_total"] and max(c["shard_sizes"]) - min(c["shard_sizes"]) <= 1
+        assert c["pose_all_gathers_in_timed_region"] == want_gathers, c
+        assert r["status_ok_fraction"] == 1.0
+        assert abs(r["value"] - total * steps / (r["ms_per_step"] * steps / 1e3)) < 1e-6 * r["value"]
+
+
 def test_bench_refuses_more_gpus_than_visible():
     import torch
     n = torch.cuda.device_count()
