@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librelpose_hip.so")
+LIB_PATH = os.environ.get("RELPOSE_LIB_PATH") or os.path.join(HERE, "librelpose_hip.so")     # (override: experiment builds, tools/build_variant.py)
 
 c_void_p, c_int, c_int64, c_size_t, c_double, c_char_p = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_double, C.c_char_p
 

@@ -363,27 +363,64 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     double* tri;                // [4 * (RP_LZ_M + 1)] alpha, beta, s, scratch of the tridiagonal solve
     const int32_t* col; const double* wv; double* xe;      // this pair's edges (global, segment layout)
     const int32_t* segrow; double* part;
+    double* part2;              // partial sums of the products done with helper workgroups (only ever written write-through)
     double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
     int C, Cmax, nseg, tri_rounds, max_prod;
+    struct FitCtl* ctl;         // helper workgroups (G > 1): the pair's control block, the published vectors [2][Cmax] (u, then h)
+    double* xu;
+    int G;
+    unsigned* epoch;            // LDS: products published so far (leader)
 };
+
+// ---- helper workgroups for the matrix-vector products ----------------------------------------------------------------------------
+// The products are 66 % (N = 200) to 79 % (N = 400) of the fit and one CU's vector-memory + LDS-gather + f64 pipes are what bounds
+// them, so G - 1 HELPER workgroups per scan pair take chunks of segments of every product.  The leader (blockIdx.x == 0) runs the
+// whole fit as before; per product it publishes the vector (write-through stores, then an epoch word), everyone -- leader included --
+// claims chunks of 512 segments with a compare-and-swap on {epoch, next chunk}, writes the per-segment partial sums write-through and
+// counts the chunk done; the leader waits for all chunks and adds the partials up per row in segment order.  Properties:
+//   * identical results for any G and any timing: a partial sum belongs to a segment, not to whoever computed it;
+//   * no co-residency assumption: the leader never waits for a workgroup that has not claimed work (a helper that starts late, or
+//     never, just takes nothing; a helper that sees no leader within ~20 ms gives up), and it takes every chunk itself if alone;
+//   * cross-CU visibility by the write-through / L1-bypassing forms only (8-byte relaxed agent-scope atomics for payload and
+//     control words, vmcnt(0) before every publish: cdna_hip_programming.md Guideline 16, R1); all polled words are zeroed by a
+//     memset node in front of the launch.
+struct FitCtl {
+    unsigned long long claim;   // {epoch << 32 | next chunk}
+    unsigned long long done;    // {epoch << 32 | chunks finished}
+    unsigned epoch;             // 0 = leader not there yet, 0xffffffff = fit finished
+    unsigned hh_epoch;          // incremented whenever h is re-published
+    unsigned nchunks, C;        // of the running product
+    unsigned long long pad[4];
+};
+#define RP_FIT_DONE 0xffffffffu
+#define RP_FIT_CHUNK 512        // segments per chunk
+typedef unsigned long long rp_u64;
+__device__ __forceinline__ void rp_st_sc1(double* p, double v) { __hip_atomic_store((rp_u64*)p, (rp_u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double rp_ld_sc1(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const rp_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void rp_st_sc1(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned rp_ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rp_st_sc1(rp_u64* p, rp_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ rp_u64 rp_ld_sc1(const rp_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rp_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // One pass over the pair's edges: thread <-> segment (<= 32 edges of one row, read with stride 64 so that a wave's loads
 // are 64 consecutive entries), sequential accumulation per segment, then every row adds up its segments in order.
 //   MODE 0: val = w                                   (weighted degrees)
 //   MODE 1: val = (base * (h[r] + h[cc])) * u[cc]      (rpmodule.py:262-267; base = w, or mu * xe for 'spectral' rounds > 0)
 //   MODE 2: val = x = relu(u[r] * u[cc]) * w           (rpmodule.py:277-280); x is stored to xe when store_x
-template <int MODE>
-__device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_xe, bool store_x) {
+// RP_SEG_DEPTH = register batches of 8 edges in flight per lane: 4 (the whole segment) in the 512-thread kernel, 2 in the 1024-thread one (128 VGPRs)
+template <int MODE, int RP_SEG_DEPTH, bool SC1>
+__device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, bool store_x) {
     const double* base = (MODE == 1 && mu_xe != 0.0) ? f.xe : f.wv;
     constexpr int U = 8;                                  // edges per register batch; two batches in flight
-    for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) {
+    {
         const int r = f.segrow[sgm];
         const int k0 = (sgm - f.sp[r]) * RP_SEG;
         const int len = min(RP_SEG, (f.rp[r + 1] - f.rp[r]) - k0);
         const size_t e0 = seg_edge_index(sgm, 0);
         const double hr = (MODE == 1) ? f.hh[r] : 0.0, ur = (MODE == 2) ? f.vec[r] : 0.0;
         double acc = 0.0;
-        int cc[2][U]; double w[2][U];
+        int cc[RP_SEG_DEPTH][U]; double w[RP_SEG_DEPTH][U];
         // per-lane predication throughout: lanes whose segment is shorter issue neither the loads nor the LDS gathers of the
         // dead slots (gating whole batches with a ballot, or processing all 32 slots branch-free, measured 20-30 % slower)
         auto load = [&](int buf, int kb) {
@@ -415,22 +452,113 @@ __device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_x
             }
         };
         static_assert(RP_SEG == 4 * U, "seg_pass is unrolled for 4 batches");
-        load(0, 0);
-        if (len > U) load(1, U);
-        consume(0, 0);
-        if (len > 2 * U) load(0, 2 * U);
-        if (len > U) consume(1, U);
-        if (len > 3 * U) load(1, 3 * U);
-        if (len > 2 * U) consume(0, 2 * U);
-        if (len > 3 * U) consume(1, 3 * U);
-        *(RP_GLOBAL double*)(f.part + sgm) = acc;
+        if (RP_SEG_DEPTH == 4) {          // the whole segment in flight (64 loads per lane) before the first gather
+            load(0, 0);
+            if (len > U) load(1, U);
+            if (len > 2 * U) load(2, 2 * U);
+            if (len > 3 * U) load(3, 3 * U);
+            consume(0, 0);
+            if (len > U) consume(1, U);
+            if (len > 2 * U) consume(2, 2 * U);
+            if (len > 3 * U) consume(3, 3 * U);
+        } else {
+            load(0, 0);
+            if (len > U) load(1, U);
+            consume(0, 0);
+            if (len > 2 * U) load(0, 2 * U);
+            if (len > U) consume(1, U);
+            if (len > 3 * U) load(1 % RP_SEG_DEPTH, 3 * U);
+            if (len > 2 * U) consume(0, 2 * U);
+            if (len > 3 * U) consume(1 % RP_SEG_DEPTH, 3 * U);
+        }
+        if (SC1) rp_st_sc1(f.part2 + sgm, acc);            // (helpers / a leader with helpers: write-through, read by the leader's row sums)
+        else *(RP_GLOBAL double*)(f.part + sgm) = acc;
     }
-    __syncthreads();
+}
+// every row adds up its segments' partial sums in segment order
+template <bool SC1>
+__device__ __forceinline__ void seg_row_sums(const Fit1& f, double* out) {
     for (int r = threadIdx.x; r < f.C; r += blockDim.x) {
         double acc = 0.0;
-        for (int sgm = f.sp[r]; sgm < f.sp[r + 1]; ++sgm) acc += *(RP_GLOBAL const double*)(f.part + sgm);
+        for (int sgm = f.sp[r]; sgm < f.sp[r + 1]; ++sgm) acc += SC1 ? rp_ld_sc1(f.part2 + sgm) : *(RP_GLOBAL const double*)(f.part + sgm);
         out[r] = acc;
     }
+    __syncthreads();
+}
+template <int MODE, int RP_SEG_DEPTH>
+__device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_xe, bool store_x) {
+    for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<MODE, RP_SEG_DEPTH, false>(f, sgm, mu_xe, store_x);
+    __syncthreads();
+    seg_row_sums<false>(f, out);
+}
+
+// claim-and-process loop of one product (leader and helpers): chunks of RP_FIT_CHUNK segments, claimed with a CAS on {epoch, next}.
+// Shape matters: ONE thread-0 block per iteration (count the finished chunk, claim the next), every barrier and the loop exit in
+// wave-uniform control flow (the chunk index goes through readfirstlane).  With a second thread-0 block at the end of the body the
+// compiler threads thread 0 from there straight into the next claim, the loop becomes irreducible, and wave 0's other lanes reach the
+// barrier -- and read the chunk index -- before lane 0 has claimed anything (seen as a memory fault on a garbage chunk index).
+template <int DEPTH>
+__device__ __forceinline__ void fit_work_loop(const Fit1& f, unsigned e, unsigned nchunks, int* s_chunk) {
+    int prev = -1;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            if (prev >= 0) __hip_atomic_fetch_add(&f.ctl->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (its stores were drained below)
+            int got = -1;
+            rp_u64 cur = rp_ld_sc1(&f.ctl->claim);
+            while ((unsigned)(cur >> 32) == e && (unsigned)cur < nchunks) {
+                const rp_u64 old = atomicCAS(&f.ctl->claim, cur, cur + 1);      // (device scope, relaxed)
+                if (old == cur) { got = (int)(unsigned)cur; break; }
+                cur = old;
+            }
+            *s_chunk = got;
+        }
+        __syncthreads();
+        const int ch = __builtin_amdgcn_readfirstlane(*s_chunk);
+        if (ch < 0) break;
+        for (int sgm = ch * RP_FIT_CHUNK + threadIdx.x; sgm < min(f.nseg, (ch + 1) * RP_FIT_CHUNK); sgm += blockDim.x)
+            seg_body<1, DEPTH, true>(f, sgm, 0.0, false);
+        rp_drain_stores();
+        __syncthreads();        // every wave's partial sums are out (and everyone has read *s_chunk) before thread 0 counts the chunk
+        prev = ch;
+    }
+    __syncthreads();            // *s_chunk may be rewritten by the caller
+}
+
+// the leader's product with helpers: publish u (f.vec), work, wait, row sums.  (h is published by fit_publish_h once per round.)
+template <int DEPTH>
+__device__ __forceinline__ void fit_dist_product(const Fit1& f, double* out, int* s_chunk) {
+    for (int c = threadIdx.x; c < f.C; c += blockDim.x) rp_st_sc1(f.xu + c, f.vec[c]);
+    rp_drain_stores();
+    __syncthreads();
+    const unsigned e = *f.epoch + 1, nchunks = (unsigned)((f.nseg + RP_FIT_CHUNK - 1) / RP_FIT_CHUNK);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *f.epoch = e;
+        rp_st_sc1(&f.ctl->claim, (rp_u64)e << 32);
+        rp_st_sc1(&f.ctl->done, (rp_u64)e << 32);
+        rp_st_sc1(&f.ctl->nchunks, nchunks);
+        rp_drain_stores();
+        rp_st_sc1(&f.ctl->epoch, e);
+    }
+    __syncthreads();
+    fit_work_loop<DEPTH>(f, e, nchunks, s_chunk);
+    if (threadIdx.x == 0) {
+        const rp_u64 want = ((rp_u64)e << 32) | nchunks;
+        const long long t0 = (long long)__builtin_readcyclecounter();
+        while (rp_ld_sc1(&f.ctl->done) != want) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((long long)__builtin_readcyclecounter() - t0 > (1ll << 32)) break;      // (~2 s: a claimed chunk always completes; never a hang)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    seg_row_sums<true>(f, out);
+}
+__device__ __forceinline__ void fit_publish_h(const Fit1& f) {
+    for (int c = threadIdx.x; c < f.C; c += blockDim.x) rp_st_sc1(f.xu + f.Cmax + c, f.hh[c]);
+    rp_drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) { rp_st_sc1(&f.ctl->hh_epoch, rp_ld_sc1(&f.ctl->hh_epoch) + 1); rp_drain_stores(); }
     __syncthreads();
 }
 
@@ -524,6 +652,7 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
 
 // Leading eigenvector of the pair's matrix (seg_pass MODE 1) into f.vec, starting from the unit vector already in f.vec;
 // returns the number of products.  *converged = 0 when the residual estimate stays above tolerance.
+template <int DEPTH>
 __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
     const int C = f.C, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     int nprod = 0;
@@ -536,7 +665,8 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
         bool done = false;
         for (int j = 0; j < RP_LZ_M && !done; ++j) {
             long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
-            seg_pass<1>(f, f.yy, mu_xe, false);                                    // yy = A v_j   (barriers inside)
+            if (f.G > 1) fit_dist_product<DEPTH>(f, f.yy, (int*)(f.epoch + 1));               // yy = A v_j with the helper workgroups
+            else seg_pass<1, DEPTH>(f, f.yy, mu_xe, false);                                // yy = A v_j   (barriers inside)
             ++nprod;
             long long t1_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
             // classical Gram-Schmidt against v_0..v_j (its coefficient of v_j is alpha_j); a second pass only when the
@@ -769,13 +899,57 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
                                                                     double* __restrict__ lz_basis, double* __restrict__ gvec, int32_t* __restrict__ status,
                                                                     double* __restrict__ pose, double* __restrict__ trace,
                                                                     int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out,
-                                                                    long long* __restrict__ prof, int tri_rounds) {
+                                                                    long long* __restrict__ prof, int tri_rounds, FitCtl* __restrict__ ctl_all,
+                                                                    double* __restrict__ xu_all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[160];
     __shared__ double Rt[12];
     __shared__ int st_s;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned cl_s[2];        // helper-workgroup protocol: [0] products published (leader), [1] claimed chunk / epoch broadcast
+    constexpr int DEPTH = 2;            // (4 = the whole segment in flight: measured 13 % slower at 512 threads, spills at 1024)
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int G = gridDim.x;            // workgroups per scan pair: 1 leader + G - 1 helpers for the matrix-vector products
     const int C = pair_C(kp, g, b);
+    FitCtl* ctl = ctl_all + b;
+    if (blockIdx.x > 0) {
+        // ---- helper: wait for products, take chunks, leave when the leader says so (or never shows up)
+        if constexpr (!GVEC) {
+            Fit1 f;
+            f.C = C; f.Cmax = g.Cmax;
+            f.ctl = ctl; f.xu = xu_all + (size_t)b * (2 * (size_t)g.Cmax + g.seg_cap); f.part2 = f.xu + 2 * (size_t)g.Cmax; f.G = G;
+            f.vec = (double*)smem; f.hh = f.vec + g.Cmax;                        // the published u and h
+            f.rp = g.rowptr + (size_t)b * (g.Cmax + 1); f.sp = g.segptr + (size_t)b * (g.Cmax + 1);      // (global: read in place)
+            const size_t eoffh = (size_t)b * g.estride;
+            f.col = g.col + eoffh; f.wv = g.wv + eoffh; f.xe = g.xe + eoffh;
+            f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
+            unsigned last = 0, hseen = 0;
+            for (;;) {
+                if (tid == 0) {
+                    const long long t0 = (long long)__builtin_readcyclecounter();
+                    unsigned ep;
+                    while ((ep = rp_ld_sc1(&ctl->epoch)) == last) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if ((long long)__builtin_readcyclecounter() - t0 > (last == 0 ? (1ll << 26) : (1ll << 32))) { ep = RP_FIT_DONE; break; }   // no leader within ~30 ms: leave
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    cl_s[1] = ep;
+                }
+                __syncthreads();
+                const unsigned ep = (unsigned)__builtin_amdgcn_readfirstlane((int)cl_s[1]);
+                __syncthreads();
+                if (ep == RP_FIT_DONE) return;
+                last = ep;
+                f.nseg = f.sp[C];
+                const unsigned he = rp_ld_sc1(&ctl->hh_epoch), nchunks = rp_ld_sc1(&ctl->nchunks);
+                for (int c = tid; c < C; c += blockDim.x) f.vec[c] = rp_ld_sc1(f.xu + c);
+                if (he != hseen) { for (int c = tid; c < C; c += blockDim.x) f.hh[c] = rp_ld_sc1(f.xu + g.Cmax + c); hseen = he; }
+                __syncthreads();
+                fit_work_loop<DEPTH>(f, ep, nchunks, (int*)&cl_s[1]);
+            }
+        }
+        return;
+    }
+    if (tid == 0) cl_s[0] = 0;
     if (tid == 0) {
         int st = status[b];
         if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
@@ -789,6 +963,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     }
     __syncthreads();
     if (st_s != RELPOSE_OK) {                             // identity, like the reference's early returns
+        if (tid == 0 && G > 1) rp_st_sc1(&ctl->epoch, RP_FIT_DONE);
         if (tid == 0) status[b] = st_s;
         if (tid < 16) pose[(size_t)b * 16 + tid] = (tid % 5 == 0) ? 1.0 : 0.0;
         if (trace && tid < 96) trace[(size_t)b * 96 + tid] = ((tid % 16) % 5 == 0) ? 1.0 : 0.0;
@@ -798,9 +973,10 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     Fit1 f;
     f.prof = prof;
     f.tri_rounds = tri_rounds & 0xff;
-    f.max_prod = tri_rounds >> 8;
+    f.max_prod = (tri_rounds >> 8) & 0xffff;
     const long long tstart_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     f.C = C; f.Cmax = g.Cmax;
+    f.ctl = ctl; f.xu = xu_all + (size_t)b * (2 * (size_t)g.Cmax + g.seg_cap); f.part2 = f.xu + 2 * (size_t)g.Cmax; f.G = G; f.epoch = &cl_s[0];
     const int32_t* rpg = g.rowptr + (size_t)b * (g.Cmax + 1);
     const int32_t* spg = g.segptr + (size_t)b * (g.Cmax + 1);
     f.tri = (double*)smem; f.cbuf = f.tri + 4 * (RP_LZ_M + 1);
@@ -841,7 +1017,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             const int a = gl % 3, what = gl / 3;
             geo[idx] = what == 0 ? kp.pc_s[si * 3 + a] : what == 1 ? kp.pc_t[ti * 3 + a] : what == 2 ? kp.normal_s[si * 3 + a] : kp.normal_t[ti * 3 + a];
         }
-        seg_pass<0>(f, f.yy, 0.0, false);
+        seg_pass<0, DEPTH>(f, f.yy, 0.0, false);
         for (int c = tid; c < C; c += blockDim.x) { fc.deg[c] = f.yy[c]; fc.gP[c] = 1.0; fc.gN[c] = 1.0; fc.rsum[c] = 0.0; }
         __syncthreads();
     }
@@ -859,12 +1035,13 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
         for (int round = 0; round < 5; ++round) {
             for (int c = tid; c < C; c += blockDim.x) { const double v = RP_OFFSET - fc.rsum[c]; f.hh[c] = v < 0.0 ? 0.0 : v; }
             __syncthreads();
+            if (G > 1) fit_publish_h(f);
             int conv = 1;
-            const int np = lanczos_top(f, (!sm && round > 0) ? kc.mu : 0.0, &conv);       // rounds > 0: warm start from f.vec
+            const int np = lanczos_top<DEPTH>(f, (!sm && round > 0) ? kc.mu : 0.0, &conv);       // rounds > 0: warm start from f.vec
             all_converged &= conv;
             if (eig_iters_out && tid == 0) eig_iters_out[b * 5 + round] = np;
             long long tf_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
-            seg_pass<2>(f, f.yy, 0.0, !sm);                                    // x per edge, new weighted degrees
+            seg_pass<2, DEPTH>(f, f.yy, 0.0, !sm);                                    // x per edge, new weighted degrees
             if (f.prof && tid == 0 && b == 0) f.prof[5] += (long long)__builtin_readcyclecounter() - tf_;
             for (int c = tid; c < C; c += blockDim.x) { fc.deg[c] = f.yy[c]; fc.gP[c] = 1.0; fc.gN[c] = 1.0; }
             __syncthreads();
@@ -877,6 +1054,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     } else if (trace) {
         for (int q = 1; q < 6; ++q) write_pose_lds(trace + (size_t)b * 96 + q * 16, Rt);
     }
+    if (tid == 0 && G > 1) rp_st_sc1(&ctl->epoch, RP_FIT_DONE);          // helpers leave
     if (tid == 0) status[b] = all_converged ? RELPOSE_OK : RELPOSE_NOT_CONVERGED;
 }
 
@@ -895,7 +1073,7 @@ static size_t fit_lds_bytes(int32_t Cmax, bool in_lds) {
 #define RP_MAX_CORRES 8192      // correspondences per pair (ns_max * topK): the fill kernel's row lists are uint16 in 8 * Cmax bytes of LDS
 
 struct WsLayout {
-    size_t corres_j, corres_w, keff, bitmap, upcnt, counters, rowptr, col, wv, xe, state, geo, lz, gvec, segptr, segrow, part, total;
+    size_t corres_j, corres_w, keff, bitmap, upcnt, counters, rowptr, col, wv, xe, state, geo, lz, gvec, segptr, segrow, part, ctl, xu, total;
     int32_t Cmax, Wmax, seg_cap;
     int64_t max_edges, estride;
 };
@@ -929,6 +1107,9 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.geo = take((size_t)B * L.Cmax * 12 * 8);
     L.lz = take((size_t)B * (RP_LZ_M + 1) * L.Cmax * 8);        // Lanczos basis
     L.gvec = take((size_t)B * 3 * L.Cmax * 8);                  // the fit's three per-correspondence vectors when they do not live in LDS
+    L.ctl = take((size_t)B * sizeof(FitCtl));                   // helper workgroups: control block per pair (zeroed per call)
+    L.xu = take((size_t)B * (2 * (size_t)L.Cmax + L.seg_cap) * 8);     // ... the published vectors u, h and the products' partial sums
+                                                                // (memory that is only ever written write-through: see FitCtl)
     L.total = o;
     return L;
 }
@@ -1017,11 +1198,23 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
         // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences,
         // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 1024 overrides (experiments build).
         const int fit_threads = RP_ENV("RELPOSE_FIT_THREADS") ? atoi(RP_ENV("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);
+        // helper workgroups per pair for the matrix-vector products (see FitCtl): 1 + helpers <= 8, all pairs' workgroups within one
+        // wave of the chip (256 CUs); only where the products dominate (more than 1024 correspondences per pair, i.e. N > 200 keypoints),
+        // never for the 'spectral' method (its per-round edge weights are written by the leader with plain stores) or the global layout.
+        // RELPOSE_TUNE_FIT_CLUSTER forces a size (1 = none).
+        int G = 1;
+        if (in_lds && m != RELPOSE_FIT_SPECTRAL) {
+            const int want = g_rp_tune[RELPOSE_TUNE_FIT_CLUSTER];
+            if (want > 0) G = want > 8 ? 8 : want;
+            else if (L.Cmax > 1024) { G = 8; while (G > 1 && (long long)kp->B * G > 256) G >>= 1; }
+        }
+        if (G > 1) RP_HIP(hipMemsetAsync(ws + L.ctl, 0, (size_t)kp->B * sizeof(FitCtl), s));
 #define RP_FIT_LAUNCH(T_, G_)                                                                                                          \
         {                                                                                                                              \
             RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<T_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-            hipLaunchKernelGGL((fit_pair_kernel<T_, G_>), dim3(kp->B), dim3(T_), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), gvec,  \
-                               status, pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds);                          \
+            hipLaunchKernelGGL((fit_pair_kernel<T_, G_>), dim3(G, kp->B), dim3(T_), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), gvec,  \
+                               status, pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds, (FitCtl*)(ws + L.ctl),      \
+                               (double*)(ws + L.xu));                                                                                   \
         }
         if (fit_threads == 512) { if (in_lds) RP_FIT_LAUNCH(512, false) else RP_FIT_LAUNCH(512, true) }
         else { if (in_lds) RP_FIT_LAUNCH(1024, false) else RP_FIT_LAUNCH(1024, true) }

@@ -50,6 +50,26 @@ def test_lanczos_fit_matches_reference_goldens_in_both_vector_layouts(golden_dir
     assert worst < 1e-9                    # converged eigenvectors: same answer as ARPACK to round-off, not just inside the bar
 
 
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_fit_helper_workgroups_change_nothing(G):
+    """Helper workgroups for the matrix-vector products (relpose_set_tuning(RELPOSE_TUNE_FIT_CLUSTER, G): the leader publishes the
+    Lanczos vector, G - 1 helpers claim chunks of segments, the leader adds the per-segment partial sums up in segment order): poses,
+    status and product counts are BITWISE those of the single-workgroup fit, for a ragged batch of pairs incl. degenerate ones, and
+    repeated calls agree (the partial sum of a segment does not depend on who computed it)."""
+    import torch
+    from relativepose_amd import _lib, rpmodule
+    cases = [synth.make_match_case(n, 800 + n, inlier=i)[:2] for n, i in ((200, 0.6), (400, 0.3), (120, 0.1), (2, 0.6), (300, 0.6), (30, 0.0))]
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.009)
+    with _lib.tuning(fit_cluster=1):
+        one = _run(cases, para, debug=True)
+    with _lib.tuning(fit_cluster=G):
+        many = _run(cases, para, debug=True)
+        again = _run(cases, para, debug=True)
+    assert torch.equal(one.pose, many.pose) and torch.equal(one.status, many.status) and torch.equal(one.eig_iters, many.eig_iters)
+    assert torch.equal(many.pose, again.pose) and torch.equal(one.trace, many.trace)
+    assert int(one.status[3]) == 1 and int((one.status == 0).sum()) >= 4
+
+
 def test_thousand_keypoints_fit_converges_and_matches_reference(golden_dir):
     """N = 1000 keypoints per view: 5000 correspondences (more than the fit's LDS layout holds: vectors in global scratch), 12.5 M
     candidate pairs.  The same Lanczos solver with the same residual test runs there -- status 0 means CONVERGED -- and the pose equals
