@@ -352,7 +352,7 @@ __device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, do
 #define RP_FIT1_MAXC 4500       // LDS: 3 vectors of C doubles + 2 x (C + 1) ints
 
 struct Fit1 {                   // LDS layout + per-pair pointers of the single-workgroup fit
-    long long* prof;            // optional [8] cycle counters of block 0 (RELPOSE_FIT_PROF=1)
+    long long* prof;            // optional [16] cycle counters of block 0 (RELPOSE_FIT_PROF=1, experiments build)
     double* vec;                // [C] current Lanczos vector / eigenvector (gather source of the products)
     double* hh;                 // [C] h = relu(50 - r)
     double* yy;                 // [C] product output
@@ -369,39 +369,44 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     struct FitCtl* ctl;         // helper workgroups (G > 1): the pair's control block, the published vectors [2][Cmax] (u, then h)
     double* xu;
     int G;
-    unsigned* epoch;            // LDS: products published so far (leader)
+    unsigned* epoch;            // LDS (leader): [0] products published so far, [1] h versions published, [2] claimed chunk
 };
 
 // ---- helper workgroups for the matrix-vector products ----------------------------------------------------------------------------
 // The products are 66 % (N = 200) to 79 % (N = 400) of the fit and one CU's vector-memory + LDS-gather + f64 pipes are what bounds
 // them, so G - 1 HELPER workgroups per scan pair take chunks of segments of every product.  The leader (blockIdx.x == 0) runs the
-// whole fit as before; per product it publishes the vector (write-through stores, then an epoch word), everyone -- leader included --
-// claims chunks of 512 segments with a compare-and-swap on {epoch, next chunk}, writes the per-segment partial sums write-through and
-// counts the chunk done; the leader waits for all chunks and adds the partials up per row in segment order.  Properties:
+// whole fit as before; per product it publishes the vector (write-through stores), then ONE control word {product number, h version,
+// next chunk}; everyone -- leader included -- claims chunks (nseg / G segments each) with a compare-and-swap on that word, writes
+// the per-segment partial sums write-through and counts the chunk done; the leader waits for all chunks and adds the partials up
+// per row in segment order.  Properties:
 //   * identical results for any G and any timing: a partial sum belongs to a segment, not to whoever computed it;
 //   * no co-residency assumption: the leader never waits for a workgroup that has not claimed work (a helper that starts late, or
-//     never, just takes nothing; a helper that sees no leader within ~20 ms gives up), and it takes every chunk itself if alone;
+//     never, just takes nothing; a helper that sees no leader within ~30 ms gives up), and it takes every chunk itself if alone;
+//   * a helper loads the vector while its claim is in flight: a successful claim means the product is still running, so the leader
+//     cannot have started to overwrite the vector (it waits for every claimed chunk first);
 //   * cross-CU visibility by the write-through / L1-bypassing forms only (8-byte relaxed agent-scope atomics for payload and
-//     control words, vmcnt(0) before every publish: cdna_hip_programming.md Guideline 16, R1); all polled words are zeroed by a
-//     memset node in front of the launch.
+//     control words, vmcnt(0) before every publish: cdna_hip_programming.md Guideline 16, R1), in memory that is NEVER touched by
+//     ordinary stores: the partial sums of these products have their own array (part2) -- the leader's plain-stored partials of the
+//     other passes sit dirty in its XCD's L2 and would shadow (and later overwrite) what a helper on another XCD wrote through;
+//     all polled words are zeroed by a memset node in front of the launch.
 struct FitCtl {
-    unsigned long long claim;   // {epoch << 32 | next chunk}
-    unsigned long long done;    // {epoch << 32 | chunks finished}
-    unsigned epoch;             // 0 = leader not there yet, 0xffffffff = fit finished
-    unsigned hh_epoch;          // incremented whenever h is re-published
-    unsigned nchunks, C;        // of the running product
-    unsigned long long pad[4];
+    unsigned long long claim;   // {product << 40 | h version << 32 | next chunk}; product 0 = leader not there yet, 0xffffff = fit finished
+    unsigned long long done;    // {product << 40 | chunks finished}
+    unsigned long long pad[6];
 };
-#define RP_FIT_DONE 0xffffffffu
-#define RP_FIT_CHUNK 512        // segments per chunk
+#define RP_FIT_DONE 0xffffffu
 typedef unsigned long long rp_u64;
 __device__ __forceinline__ void rp_st_sc1(double* p, double v) { __hip_atomic_store((rp_u64*)p, (rp_u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double rp_ld_sc1(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const rp_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ __forceinline__ void rp_st_sc1(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned rp_ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rp_st_sc1(rp_u64* p, rp_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ rp_u64 rp_ld_sc1(const rp_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rp_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Chunks of the distributed products: chunk 0 is the LEADER's (never claimed: it starts on it the moment the product is published,
+// some microseconds before a helper has seen the control word and loaded the vector) and twice as long as the others, which are
+// claimed in order; sizes are whole 128-byte lines of partial sums.  With everybody there, every workgroup does one chunk.
+__device__ __forceinline__ int fit_chunk_size(int nseg, int G) { return max(64, ((nseg + G) / (G + 1) + 63) & ~63); }
+__device__ __forceinline__ int fit_chunk_count(int nseg, int csz) { return 1 + max(0, (nseg - 2 * csz + csz - 1) / csz); }
+__device__ __forceinline__ int fit_chunk_begin(int ch, int csz) { return ch == 0 ? 0 : (ch + 1) * csz; }
 
 // One pass over the pair's edges: thread <-> segment (<= 32 edges of one row, read with stride 64 so that a wave's loads
 // are 64 consecutive entries), sequential accumulation per segment, then every row adds up its segments in order.
@@ -475,13 +480,38 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
         else *(RP_GLOBAL double*)(f.part + sgm) = acc;
     }
 }
-// every row adds up its segments' partial sums in segment order
+// every row adds up its segments' partial sums in segment order (SC1: from part2 with L1-bypassing loads -- their latency is a
+// trip to the memory side, so two rows x 8 partial sums are in flight per thread)
 template <bool SC1>
 __device__ __forceinline__ void seg_row_sums(const Fit1& f, double* out) {
-    for (int r = threadIdx.x; r < f.C; r += blockDim.x) {
-        double acc = 0.0;
-        for (int sgm = f.sp[r]; sgm < f.sp[r + 1]; ++sgm) acc += SC1 ? rp_ld_sc1(f.part2 + sgm) : *(RP_GLOBAL const double*)(f.part + sgm);
-        out[r] = acc;
+    if (SC1) {
+        for (int r0 = threadIdx.x; r0 < f.C; r0 += 2 * blockDim.x) {
+            const int r1 = r0 + blockDim.x;
+            const bool two = r1 < f.C;
+            const int a0 = f.sp[r0], a1 = f.sp[r0 + 1], b0 = two ? f.sp[r1] : 0, b1 = two ? f.sp[r1 + 1] : 0;
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int k = 0; a0 + k < a1 || b0 + k < b1; k += 8) {
+                double v[8], w[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    v[q] = a0 + k + q < a1 ? rp_ld_sc1(f.part2 + a0 + k + q) : 0.0;
+                    w[q] = b0 + k + q < b1 ? rp_ld_sc1(f.part2 + b0 + k + q) : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (a0 + k + q < a1) acc0 += v[q];
+                    if (b0 + k + q < b1) acc1 += w[q];
+                }
+            }
+            out[r0] = acc0;
+            if (two) out[r1] = acc1;
+        }
+    } else {
+        for (int r = threadIdx.x; r < f.C; r += blockDim.x) {
+            double acc = 0.0;
+            for (int sgm = f.sp[r]; sgm < f.sp[r + 1]; ++sgm) acc += *(RP_GLOBAL const double*)(f.part + sgm);
+            out[r] = acc;
+        }
     }
     __syncthreads();
 }
@@ -492,31 +522,49 @@ __device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_x
     seg_row_sums<false>(f, out);
 }
 
-// claim-and-process loop of one product (leader and helpers): chunks of RP_FIT_CHUNK segments, claimed with a CAS on {epoch, next}.
+// claim-and-process loop of one product (leader and helpers).  word = the product's control word with next chunk = 1.
 // Shape matters: ONE thread-0 block per iteration (count the finished chunk, claim the next), every barrier and the loop exit in
 // wave-uniform control flow (the chunk index goes through readfirstlane).  With a second thread-0 block at the end of the body the
 // compiler threads thread 0 from there straight into the next claim, the loop becomes irreducible, and wave 0's other lanes reach the
 // barrier -- and read the chunk index -- before lane 0 has claimed anything (seen as a memory fault on a garbage chunk index).
-template <int DEPTH>
-__device__ __forceinline__ void fit_work_loop(const Fit1& f, unsigned e, unsigned nchunks, int* s_chunk) {
+//   LEADER: starts with chunk 0, then takes whatever is unclaimed and leaves when every other chunk is counted done;
+//   helpers: LOADER() = their vector loads, issued while the first claim is in flight; they leave when nothing is left to claim.
+template <int DEPTH, bool LEADER, class LOADER>
+__device__ __forceinline__ void fit_work_loop(const Fit1& f, rp_u64 word, int* s_chunk, LOADER loader) {
+    const int csz = fit_chunk_size(f.nseg, f.G);
+    const unsigned nchunks = (unsigned)fit_chunk_count(f.nseg, csz);
     int prev = -1;
-    for (;;) {
+    for (int it = 0;; ++it) {
         if (threadIdx.x == 0) {
-            if (prev >= 0) __hip_atomic_fetch_add(&f.ctl->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (its stores were drained below)
+            if (prev > 0) __hip_atomic_fetch_add(&f.ctl->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (its stores were drained below; chunk 0 is not counted)
             int got = -1;
-            rp_u64 cur = rp_ld_sc1(&f.ctl->claim);
-            while ((unsigned)(cur >> 32) == e && (unsigned)cur < nchunks) {
-                const rp_u64 old = atomicCAS(&f.ctl->claim, cur, cur + 1);      // (device scope, relaxed)
-                if (old == cur) { got = (int)(unsigned)cur; break; }
-                cur = old;
+            if (LEADER && it == 0) got = 0;
+            else {
+                const long long t0 = (long long)__builtin_readcyclecounter();
+                rp_u64 cur = (!LEADER && it == 0) ? word : rp_ld_sc1(&f.ctl->claim);
+                for (;;) {
+                    if ((cur >> 32) != (word >> 32)) break;                              // (helpers: the product is over)
+                    if ((unsigned)cur < nchunks) {
+                        const rp_u64 old = atomicCAS(&f.ctl->claim, cur, cur + 1);      // (device scope, relaxed)
+                        if (old == cur) { got = (int)(unsigned)cur; break; }
+                        cur = old;
+                        continue;
+                    }
+                    if (!LEADER) break;                                                 // nothing left to claim
+                    // leader: every chunk is claimed; wait until the nchunks - 1 claimed ones are counted done
+                    if (rp_ld_sc1(&f.ctl->done) == ((word >> 40 << 40) | (rp_u64)(nchunks - 1))) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((long long)__builtin_readcyclecounter() - t0 > (1ll << 32)) break;      // (~2 s: a claimed chunk always completes; never a hang)
+                }
             }
             *s_chunk = got;
         }
+        if (it == 0) loader();
         __syncthreads();
         const int ch = __builtin_amdgcn_readfirstlane(*s_chunk);
         if (ch < 0) break;
-        for (int sgm = ch * RP_FIT_CHUNK + threadIdx.x; sgm < min(f.nseg, (ch + 1) * RP_FIT_CHUNK); sgm += blockDim.x)
-            seg_body<1, DEPTH, true>(f, sgm, 0.0, false);
+        const int s0 = fit_chunk_begin(ch, csz), s1 = min(f.nseg, fit_chunk_begin(ch + 1, csz));
+        for (int sgm = s0 + threadIdx.x; sgm < s1; sgm += blockDim.x) seg_body<1, DEPTH, true>(f, sgm, 0.0, false);
         rp_drain_stores();
         __syncthreads();        // every wave's partial sums are out (and everyone has read *s_chunk) before thread 0 counts the chunk
         prev = ch;
@@ -524,41 +572,28 @@ __device__ __forceinline__ void fit_work_loop(const Fit1& f, unsigned e, unsigne
     __syncthreads();            // *s_chunk may be rewritten by the caller
 }
 
-// the leader's product with helpers: publish u (f.vec), work, wait, row sums.  (h is published by fit_publish_h once per round.)
+// the leader's product with helpers: publish u (f.vec), work + wait, row sums.  (h is published by fit_publish_h once per round.)
 template <int DEPTH>
 __device__ __forceinline__ void fit_dist_product(const Fit1& f, double* out, int* s_chunk) {
+    const bool pr = f.prof && threadIdx.x == 0 && blockIdx.y == 0;
+    const long long ta_ = pr ? (long long)__builtin_readcyclecounter() : 0;
+    const unsigned e = f.epoch[0] + 1;
+    const rp_u64 word = ((rp_u64)e << 40) | ((rp_u64)(f.epoch[1] & 0xff) << 32) | 1ull;
     for (int c = threadIdx.x; c < f.C; c += blockDim.x) rp_st_sc1(f.xu + c, f.vec[c]);
+    if (threadIdx.x == 0) rp_st_sc1(&f.ctl->done, (rp_u64)e << 40);
     rp_drain_stores();
     __syncthreads();
-    const unsigned e = *f.epoch + 1, nchunks = (unsigned)((f.nseg + RP_FIT_CHUNK - 1) / RP_FIT_CHUNK);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *f.epoch = e;
-        rp_st_sc1(&f.ctl->claim, (rp_u64)e << 32);
-        rp_st_sc1(&f.ctl->done, (rp_u64)e << 32);
-        rp_st_sc1(&f.ctl->nchunks, nchunks);
-        rp_drain_stores();
-        rp_st_sc1(&f.ctl->epoch, e);
-    }
-    __syncthreads();
-    fit_work_loop<DEPTH>(f, e, nchunks, s_chunk);
-    if (threadIdx.x == 0) {
-        const rp_u64 want = ((rp_u64)e << 32) | nchunks;
-        const long long t0 = (long long)__builtin_readcyclecounter();
-        while (rp_ld_sc1(&f.ctl->done) != want) {
-            __builtin_amdgcn_s_sleep(2);
-            if ((long long)__builtin_readcyclecounter() - t0 > (1ll << 32)) break;      // (~2 s: a claimed chunk always completes; never a hang)
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
+    if (threadIdx.x == 0) { f.epoch[0] = e; rp_st_sc1(&f.ctl->claim, word); }
+    const long long tb_ = pr ? (long long)__builtin_readcyclecounter() : 0;
+    fit_work_loop<DEPTH, true>(f, word, s_chunk, [] {});
+    const long long td_ = pr ? (long long)__builtin_readcyclecounter() : 0;
     seg_row_sums<true>(f, out);
+    if (pr) { f.prof[8] += tb_ - ta_; f.prof[9] += td_ - tb_; f.prof[11] += (long long)__builtin_readcyclecounter() - td_; }
 }
 __device__ __forceinline__ void fit_publish_h(const Fit1& f) {
     for (int c = threadIdx.x; c < f.C; c += blockDim.x) rp_st_sc1(f.xu + f.Cmax + c, f.hh[c]);
     rp_drain_stores();
-    __syncthreads();
-    if (threadIdx.x == 0) { rp_st_sc1(&f.ctl->hh_epoch, rp_ld_sc1(&f.ctl->hh_epoch) + 1); rp_drain_stores(); }
+    if (threadIdx.x == 0) f.epoch[1] += 1;      // (the version travels in the next product's control word)
     __syncthreads();
 }
 
@@ -665,7 +700,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
         bool done = false;
         for (int j = 0; j < RP_LZ_M && !done; ++j) {
             long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
-            if (f.G > 1) fit_dist_product<DEPTH>(f, f.yy, (int*)(f.epoch + 1));               // yy = A v_j with the helper workgroups
+            if (f.G > 1) fit_dist_product<DEPTH>(f, f.yy, (int*)(f.epoch + 2));               // yy = A v_j with the helper workgroups
             else seg_pass<1, DEPTH>(f, f.yy, mu_xe, false);                                // yy = A v_j   (barriers inside)
             ++nprod;
             long long t1_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -709,7 +744,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
             }
             const double beta = sqrt(nrm_after);
             if (tid == 0) { f.tri[j] = alpha; f.tri[(RP_LZ_M + 1) + j] = beta; }
-            if (f.prof && tid == 0 && blockIdx.x == 0) { f.prof[0] += t1_ - t0_; f.prof[1] += (long long)__builtin_readcyclecounter() - t1_; f.prof[6] += 1; }
+            if (f.prof && tid == 0 && blockIdx.y == 0) { f.prof[0] += t1_ - t0_; f.prof[1] += (long long)__builtin_readcyclecounter() - t1_; f.prof[6] += 1; }
             m = j + 1;
             beta_last = beta;
             const double anorm = fabs(alpha) + beta;
@@ -729,7 +764,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 }
                 __syncthreads();
                 theta = f.red[159];
-                if (f.prof && tid == 0 && blockIdx.x == 0) f.prof[2] += (long long)__builtin_readcyclecounter() - t2_;
+                if (f.prof && tid == 0 && blockIdx.y == 0) f.prof[2] += (long long)__builtin_readcyclecounter() - t2_;
                 const double resid = invariant ? 0.0 : beta_last * fabs(f.tri[2 * (RP_LZ_M + 1) + m - 1]);
                 if (invariant || m == RP_LZ_M || resid <= RP_LZ_TOL * fabs(theta) || nprod >= f.max_prod) {
                     done = true;
@@ -905,7 +940,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     __shared__ double red[160];
     __shared__ double Rt[12];
     __shared__ int st_s;
-    __shared__ unsigned cl_s[2];        // helper-workgroup protocol: [0] products published (leader), [1] claimed chunk / epoch broadcast
+    __shared__ unsigned cl_s[3];        // helper-workgroup protocol: leader [0] products / [1] h versions published; helper [0] control word seen; [2] claimed chunk
     constexpr int DEPTH = 2;            // (4 = the whole segment in flight: measured 13 % slower at 512 threads, spills at 1024)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int G = gridDim.x;            // workgroups per scan pair: 1 leader + G - 1 helpers for the matrix-vector products
@@ -922,34 +957,35 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             const size_t eoffh = (size_t)b * g.estride;
             f.col = g.col + eoffh; f.wv = g.wv + eoffh; f.xe = g.xe + eoffh;
             f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
-            unsigned last = 0, hseen = 0;
+            f.nseg = f.sp[C];
+            unsigned last = 0, hseen = 0;       // product number / h version seen last
             for (;;) {
                 if (tid == 0) {
                     const long long t0 = (long long)__builtin_readcyclecounter();
-                    unsigned ep;
-                    while ((ep = rp_ld_sc1(&ctl->epoch)) == last) {
-                        __builtin_amdgcn_s_sleep(8);
-                        if ((long long)__builtin_readcyclecounter() - t0 > (last == 0 ? (1ll << 26) : (1ll << 32))) { ep = RP_FIT_DONE; break; }   // no leader within ~30 ms: leave
+                    rp_u64 w;
+                    while ((unsigned)((w = rp_ld_sc1(&ctl->claim)) >> 40) == last) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((long long)__builtin_readcyclecounter() - t0 > (last == 0 ? (1ll << 26) : (1ll << 32))) { w = (rp_u64)RP_FIT_DONE << 40; break; }   // no leader within ~30 ms: leave
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    cl_s[1] = ep;
+                    cl_s[0] = (unsigned)(w >> 32); cl_s[1] = (unsigned)w;
                 }
                 __syncthreads();
-                const unsigned ep = (unsigned)__builtin_amdgcn_readfirstlane((int)cl_s[1]);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)cl_s[0]);       // {product, h version}
+                const unsigned cl_next = (unsigned)__builtin_amdgcn_readfirstlane((int)cl_s[1]);  // next unclaimed chunk as polled
                 __syncthreads();
-                if (ep == RP_FIT_DONE) return;
-                last = ep;
-                f.nseg = f.sp[C];
-                const unsigned he = rp_ld_sc1(&ctl->hh_epoch), nchunks = rp_ld_sc1(&ctl->nchunks);
-                for (int c = tid; c < C; c += blockDim.x) f.vec[c] = rp_ld_sc1(f.xu + c);
-                if (he != hseen) { for (int c = tid; c < C; c += blockDim.x) f.hh[c] = rp_ld_sc1(f.xu + g.Cmax + c); hseen = he; }
-                __syncthreads();
-                fit_work_loop<DEPTH>(f, ep, nchunks, (int*)&cl_s[1]);
+                if ((hi >> 8) == RP_FIT_DONE) return;
+                last = hi >> 8;
+                const bool newh = (hi & 0xff) != hseen;
+                hseen = hi & 0xff;
+                fit_work_loop<DEPTH, false>(f, ((rp_u64)hi << 32) | (unsigned)cl_next, (int*)&cl_s[2], [&] {
+                    for (int c = tid; c < C; c += blockDim.x) f.vec[c] = rp_ld_sc1(f.xu + c);
+                    if (newh) for (int c = tid; c < C; c += blockDim.x) f.hh[c] = rp_ld_sc1(f.xu + g.Cmax + c);
+                });
             }
         }
         return;
     }
-    if (tid == 0) cl_s[0] = 0;
+    if (tid == 0) { cl_s[0] = 0; cl_s[1] = 0; }
     if (tid == 0) {
         int st = status[b];
         if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
@@ -963,7 +999,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     }
     __syncthreads();
     if (st_s != RELPOSE_OK) {                             // identity, like the reference's early returns
-        if (tid == 0 && G > 1) rp_st_sc1(&ctl->epoch, RP_FIT_DONE);
+        if (tid == 0 && G > 1) rp_st_sc1(&ctl->claim, (rp_u64)RP_FIT_DONE << 40);
         if (tid == 0) status[b] = st_s;
         if (tid < 16) pose[(size_t)b * 16 + tid] = (tid % 5 == 0) ? 1.0 : 0.0;
         if (trace && tid < 96) trace[(size_t)b * 96 + tid] = ((tid % 16) % 5 == 0) ? 1.0 : 0.0;
@@ -1054,7 +1090,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     } else if (trace) {
         for (int q = 1; q < 6; ++q) write_pose_lds(trace + (size_t)b * 96 + q * 16, Rt);
     }
-    if (tid == 0 && G > 1) rp_st_sc1(&ctl->epoch, RP_FIT_DONE);          // helpers leave
+    if (tid == 0 && G > 1) rp_st_sc1(&ctl->claim, (rp_u64)RP_FIT_DONE << 40);          // helpers leave
     if (tid == 0) status[b] = all_converged ? RELPOSE_OK : RELPOSE_NOT_CONVERGED;
 }
 
@@ -1189,8 +1225,8 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
         double* gvec = in_lds ? nullptr : (double*)(ws + L.gvec);
         static long long* prof = nullptr;
         if (RP_ENV("RELPOSE_FIT_PROF")) {
-            if (!prof) RP_HIP(hipMalloc((void**)&prof, 64));
-            RP_HIP(hipMemsetAsync(prof, 0, 64, s));
+            if (!prof) RP_HIP(hipMalloc((void**)&prof, 128));
+            RP_HIP(hipMemsetAsync(prof, 0, 128, s));
         }
         // (multisection rounds | product budget << 8); RELPOSE_TUNE_FIT_MAX_PRODUCTS is a test hook: a tiny budget forces RELPOSE_NOT_CONVERGED
         const int tri_rounds = (RP_ENV("RELPOSE_TRI_ROUNDS") ? atoi(RP_ENV("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS) |
@@ -1198,15 +1234,18 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
         // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences,
         // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 1024 overrides (experiments build).
         const int fit_threads = RP_ENV("RELPOSE_FIT_THREADS") ? atoi(RP_ENV("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);
-        // helper workgroups per pair for the matrix-vector products (see FitCtl): 1 + helpers <= 8, all pairs' workgroups within one
-        // wave of the chip (256 CUs); only where the products dominate (more than 1024 correspondences per pair, i.e. N > 200 keypoints),
-        // never for the 'spectral' method (its per-round edge weights are written by the leader with plain stores) or the global layout.
+        // helper workgroups per pair for the matrix-vector products (see FitCtl): a LATENCY tool.  Alone on the chip the matcher of 32
+        // N = 400 pairs drops from 7.7 to 5.1 ms with 7 helpers per pair, but helpers sit on a CU each for the whole fit, mostly
+        // polling, and inside the pipeline they take those CUs from the SCNet kernels of the other slot: configs[2] 462 -> 400 pairs/s,
+        // configs[1] 497 -> 475 with 3 helpers (measured, round 3).  So by default only small batches -- at most 64 workgroups, a
+        // quarter of the chip -- get helpers (up to 7 beyond 1024 correspondences per pair, up to 3 from 512), never the 'spectral'
+        // method (its per-round edge weights are written by the leader with plain stores) or the global layout.
         // RELPOSE_TUNE_FIT_CLUSTER forces a size (1 = none).
         int G = 1;
         if (in_lds && m != RELPOSE_FIT_SPECTRAL) {
             const int want = g_rp_tune[RELPOSE_TUNE_FIT_CLUSTER];
             if (want > 0) G = want > 8 ? 8 : want;
-            else if (L.Cmax > 1024) { G = 8; while (G > 1 && (long long)kp->B * G > 256) G >>= 1; }
+            else if (L.Cmax >= 512) { G = L.Cmax > 1024 ? 8 : 4; while (G > 1 && (long long)kp->B * G > 64) G >>= 1; }
         }
         if (G > 1) RP_HIP(hipMemsetAsync(ws + L.ctl, 0, (size_t)kp->B * sizeof(FitCtl), s));
 #define RP_FIT_LAUNCH(T_, G_)                                                                                                          \
@@ -1221,10 +1260,10 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
 #undef RP_FIT_LAUNCH
         RP_CHECK_LAUNCH();
         if (prof) {       // experiments build only: synchronises
-            long long h[8];
+            long long h[16];
             RP_HIP(hipStreamSynchronize(s));
             RP_HIP(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[fit prof, pair 0, cycles] products %lld (%lld calls) reorth+norm %lld tridiag %lld irls %lld finish %lld setup %lld\n", h[0], h[6], h[1], h[2], h[4], h[5], h[7]);
+            fprintf(stderr, "[fit prof, pair 0, cycles] products %lld (%lld calls) reorth+norm %lld tridiag %lld irls %lld finish %lld setup %lld | with helpers: publish %lld own chunks %lld wait %lld row sums %lld\n", h[0], h[6], h[1], h[2], h[4], h[5], h[7], h[8], h[9], h[10], h[11]);
         }
     }
     if (dbg && dbg->corres_j)

@@ -64,9 +64,11 @@ def test_fit_helper_workgroups_change_nothing(G):
         one = _run(cases, para, debug=True)
     with _lib.tuning(fit_cluster=G):
         many = _run(cases, para, debug=True)
-        again = _run(cases, para, debug=True)
-    assert torch.equal(one.pose, many.pose) and torch.equal(one.status, many.status) and torch.equal(one.eig_iters, many.eig_iters)
-    assert torch.equal(many.pose, again.pose) and torch.equal(one.trace, many.trace)
+        assert torch.equal(one.pose, many.pose) and torch.equal(one.status, many.status) and torch.equal(one.eig_iters, many.eig_iters)
+        assert torch.equal(one.trace, many.trace)
+        for _ in range(8):          # (who computes which chunk changes from call to call)
+            again = _run(cases, para, debug=True)
+            assert torch.equal(many.pose, again.pose) and torch.equal(many.trace, again.trace) and torch.equal(many.eig_iters, again.eig_iters)
     assert int(one.status[3]) == 1 and int((one.status == 0).sum()) >= 4
 
 
