@@ -5,9 +5,9 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this.  The shipped path is the HIP library; it never calls into here.
 
 Follows /root/reference/RPModule/rpmodule.py (lines cited per function) and
-RPModule/rputil.py:11-22 (``opts``).  Pinned against the reference itself by
-tests/golden/make_golden.py (fixtures in tests/golden/*.npz) and, when
-/root/reference is present, by tests/test_oracle_vs_reference.py.
+RPModule/rputil.py:11-22 (``opts``).  Pinned against the reference itself: tests/golden/make_golden.py imports the
+reference (in the build container) and stores its outputs for seeded inputs in
+tests/golden/*.npz; tests/test_oracle_golden.py asserts this oracle equals them.
 
 Each stage returns its intermediates so the HIP stages can be checked one by
 one.  Numeric types follow the reference exactly: descriptors/dij float32,
