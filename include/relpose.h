@@ -239,6 +239,15 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
  * tail_stream == stream is relpose_scnet_forward. */
 int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
                            void* workspace, size_t workspace_bytes, void* stream, void* tail_stream);
+/* relpose_scnet_forward2 with flags.  RELPOSE_FWD_ZERO_WARP: the caller guarantees that channels 8:16 of EVERY image are zero -- level 0
+ * of the recurrence, where the pose estimate is the identity and util.warping returns zeros (util.py:95-96, evaluation.py:232-236).
+ * The three warped-view encoder streams (conv1*..conv3* on rgb_t2s / norm_t2s / depth_t2s, mymodel.py:278-288) then produce the same
+ * activations for every image, so conv2* / conv3* of those streams run for the first BatchNorm group only and their conv3 outputs
+ * (+ BatchNorm scale / shift) are copied to the other images before conv4: results are bitwise those of the flag-less forward.
+ * With the flag set and a non-zero warped view the output is undefined. */
+enum { RELPOSE_FWD_ZERO_WARP = 1 };
+int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
+                           void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags);
 
 /* Debug: copy a raw (pre-BatchNorm) layer output of the last forward, NHWC float32, to out (device).
  * Returns the number of floats written (or needed if out is NULL), <0 if unknown. */

@@ -1714,6 +1714,27 @@ __global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(const ConvDesc*
     ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
 }
 
+// RELPOSE_FWD_ZERO_WARP: the warped-stream channel blocks (odd blocks of `blk` channels) of buffer a [n][hw][C] were computed for images
+// 0 and 1 only; image i >= 2 gets a copy of image i & 1, BatchNorm group g >= 1 the {scale, shift} of group 0 for those channels.
+__global__ __launch_bounds__(256) void bcast_warped_kernel(float* __restrict__ a, int n, int hw, int C, int blk, float2* __restrict__ ss, int G) {
+    const int q4 = 3 * blk / 4;                                   // float4 per pixel to copy
+    const size_t total = (size_t)(n - 2) * hw * q4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % q4);
+        const size_t pi = i / q4;
+        const int px = (int)(pi % hw), img = 2 + (int)(pi / hw);
+        const int ch = (2 * (q / (blk / 4)) + 1) * blk + 4 * (q % (blk / 4));
+        const float4 v = *reinterpret_cast<const float4*>(a + ((size_t)(img & 1) * hw + px) * C + ch);      // (a: a kernel argument, global loads)
+        *reinterpret_cast<float4*>(a + ((size_t)img * hw + px) * C + ch) = v;
+    }
+    const int tsz = (G - 1) * 3 * blk;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tsz; i += gridDim.x * blockDim.x) {
+        const int q = i % (3 * blk), g = 1 + i / (3 * blk);
+        const int ch = (2 * (q / blk) + 1) * blk + q % blk;
+        ss[(size_t)g * C + ch] = ss[ch];
+    }
+}
+
 // ---- bilinear resize, align_corners=False (mymodel.py:261,379) --------------------------------------
 __device__ __forceinline__ void lin_coef(int dst, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
     float src = scale * (dst + 0.5f) - 0.5f;
@@ -2079,7 +2100,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7, OP_CONV_STRIP = 8 };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7, OP_CONV_STRIP = 8, OP_BCAST = 9 };
 struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0, split = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
@@ -2102,6 +2123,8 @@ struct Builder {
     Plan* plan;
     int rc = 0;
     int group_first = -1;
+    bool zero_warp = false;     // RELPOSE_FWD_ZERO_WARP plan
+    int nimg = 0;               // images of the members added by conv() (0 = n): RELPOSE_FWD_ZERO_WARP plans run the warped streams on 2
 
     float* buf(const std::string& b);
     float2* ssb(const std::string& b);
@@ -2167,7 +2190,7 @@ void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, con
         d.src[0] = s0; d.nsrc = 1;
         if (s1) { d.src[1] = *s1; d.nsrc = 2; }
         d.Cin = s0.C + (s1 ? s1->C : 0);
-        d.Nimg = n; d.Hin = Hin; d.Win = Hin;
+        d.Nimg = nimg > 0 ? nimg : n; d.Hin = Hin; d.Win = Hin;
         if (L.kind == 1) {
             d.sy = d.sx = 1; d.osy = d.osx = L.stride; d.py = P.py; d.px = P.px;
             d.Hp = (Hout - P.py + L.stride - 1) / L.stride; d.Wp = (Hout - P.px + L.stride - 1) / L.stride;
@@ -2182,7 +2205,7 @@ void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, con
         d.y = buf(out); d.Hout = Hout; d.Wout = Hout; d.ycstride = (out == "OUT") ? net->cf : O.C; d.ychoff = ochoff;
         d.bias = (L.kind == 2) ? net->d_w + L.bias_off : nullptr;
         d.tanh_out = (L.kind == 2 && layer == "deconv1f" && net->use_tanh) ? 1 : 0;
-        d.M = n * d.Hp * d.Wp; d.K = P.K;
+        d.M = d.Nimg * d.Hp * d.Wp; d.K = P.K;
         d.ksplit = 1; d.kt_per = d.K / BK; d.partial = nullptr;
         {   // K order: tap-inner for the 2x2-tap phases of transposed convs (RELPOSE_TAP_INNER=0 none / 2 every conv: experiments)
             static const int ti = RP_ENV("RELPOSE_TAP_INNER") ? atoi(RP_ENV("RELPOSE_TAP_INNER")) : 1;
@@ -2202,7 +2225,7 @@ void Builder::end_group() {
     if ((int)plan->descs.size() > MAX_DESCS) { rc = RELPOSE_EINVAL; return; }
     const int cp = plan->descs[first].cout_pad;
     int big_m = 0;
-    for (int i = first; i < first + count; ++i) big_m = std::max(big_m, plan->descs[i].M / n * 64);   // at the nominal batch
+    for (int i = first; i < first + count; ++i) big_m = std::max(big_m, plan->descs[i].M / plan->descs[i].Nimg * 64);   // at the nominal batch
     // tile configs: 0 = 128x128 (4 waves), 3 = 256x128 (8 waves, 4 waves/SIMD at 2 blocks/CU), 1 = 256x64, 2 = 256x32
     // (3 measured within 1 % of 0 on conv3/conv4/deconv4-6 but needs twice the split-K: off unless RELPOSE_8WAVE is set)
     static const bool tile128 = RP_ENV("RELPOSE_TILE128") != nullptr;      // experiment: 128-row tiles, 4 workgroups per CU
@@ -2279,7 +2302,7 @@ void Builder::end_group() {
         min_kt = std::min(min_kt, d.K / BK);
         // the split factor must not depend on the batch size (results are bitwise batch-invariant), so the
         // tile count is evaluated at a nominal batch of 64 images (32 scan pairs)
-        tiles += (long)((d.M / n * 64 + BMt - 1) / BMt) * (cp / BNt);
+        tiles += (long)((d.M / d.Nimg * 64 + BMt - 1) / BMt) * (cp / BNt);
     }
     // split along K until the launch has >= ~3000 tiles (>= 4 waves of resident blocks), keeping >= 8 k-tiles per slice
     int ksplit = 1;
@@ -2385,12 +2408,33 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     R.stats("A1");
     R.plan->ops.back().cfg = 1;                   // partial records already written by conv1_direct_kernel
     R.plan->head_count = (int)R.plan->ops.size();
-    R.begin_group();
-    for (int q = 0; q < 6; ++q) R.conv(std::string("conv2") + mods[q / 2], R.src("A1", q * 32, 32), nullptr, 224, "A2", q * 64);
-    R.end_group(); R.stats("A2");
-    R.begin_group();
-    for (int q = 0; q < 6; ++q) R.conv(std::string("conv3") + mods[q / 2], R.src("A2", q * 64, 64), nullptr, 112, "A3", q * 128);
-    R.end_group(); R.stats("A3");
+    if (!R.zero_warp) {
+        R.begin_group();
+        for (int q = 0; q < 6; ++q) R.conv(std::string("conv2") + mods[q / 2], R.src("A1", q * 32, 32), nullptr, 224, "A2", q * 64);
+        R.end_group(); R.stats("A2");
+        R.begin_group();
+        for (int q = 0; q < 6; ++q) R.conv(std::string("conv3") + mods[q / 2], R.src("A2", q * 64, 64), nullptr, 112, "A3", q * 128);
+        R.end_group(); R.stats("A3");
+    } else {
+        // level 0: the warped view is all zeros, so the warped streams (odd q) see the same input in every image -- conv1 of zeros is
+        // an exact 0 everywhere -- and their conv2 / conv3 run for the first BatchNorm group (2 images) only: same kernels, same tiles,
+        // same BatchNorm records as in the full plan, hence bitwise the same values; OP_BCAST then copies the conv3 outputs and their
+        // {scale, shift} to the other images / groups (the A2 blocks of the warped streams are read by those conv3 members only)
+        for (int L = 2; L <= 3; ++L) {
+            const std::string name = L == 2 ? "conv2" : "conv3", in = L == 2 ? "A1" : "A2", out = L == 2 ? "A2" : "A3";
+            const int cin = L == 2 ? 32 : 64, cout = L == 2 ? 64 : 128, Hin = L == 2 ? 224 : 112;
+            for (int stream = 0; stream < 2; ++stream) {
+                R.nimg = stream ? 2 : 0;
+                R.begin_group();
+                for (int q = stream; q < 6; q += 2) R.conv(name + mods[q / 2], R.src(in, q * cin, cin), nullptr, Hin, out, q * cout);
+                R.end_group();
+            }
+            R.nimg = 0;
+            R.stats(out);
+            if (R.plan->ops.back().type != OP_STATS_FUSED) R.rc = RELPOSE_EINVAL;     // (the records of the 2-image members: fused statistics only)
+        }
+        { Op o; o.type = OP_BCAST; o.first = o.count = o.cfg = 0; o.buf = "A3"; R.plan->ops.push_back(o); }
+    }
     one("conv4", R.src("A3", 0, 768), nullptr, 56, "A4", 0); R.stats("A4");
     one("conv5", R.src("A4", 0, 256), nullptr, 28, "A5", 0); R.stats("A5");
     one("conv6", R.src("A5", 0, 512), nullptr, 14, "A6", 0); R.stats("A6");
@@ -2605,11 +2649,20 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
 
 int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                            size_t workspace_bytes, void* stream, void* tail_stream) {
-    if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0) return RELPOSE_EINVAL;
+    return relpose_scnet_forward3(net, x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, 0);
+}
+
+int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
+                           size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags) {
+    if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0 || n >= (1 << 24)) return RELPOSE_EINVAL;
+    if (flags & ~RELPOSE_FWD_ZERO_WARP) return RELPOSE_EINVAL;
     const int G = n / 2;
+    // (nothing to share with one BatchNorm group; the tile kernels' patch pairing wants the 2-image members' patch count even as well)
+    const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2;
+    const int plan_key = (int)n | (zero_warp ? 1 << 24 : 0);
     Plan* plan = nullptr;
     {
-        auto it = net->plans.find(std::make_pair(workspace, (int)n));
+        auto it = net->plans.find(std::make_pair(workspace, plan_key));
         if (it != net->plans.end()) plan = (Plan*)it->second;
     }
     if (!plan) {
@@ -2619,13 +2672,13 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
         plan = new Plan();
         plan->n = n; plan->ws = workspace;
         char* ws = (char*)workspace;
-        Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan;
+        Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan; B.zero_warp = zero_warp;
         B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk); B.statp = (double*)(ws + o.statp);
         build_plan(net, n, B);
         if (B.rc) { delete plan; return B.rc; }
         RP_HIP(hipMalloc((void**)&plan->d_descs, MAX_DESCS * sizeof(ConvDesc)));
         RP_HIP(hipMemcpy(plan->d_descs, plan->descs.data(), plan->descs.size() * sizeof(ConvDesc), hipMemcpyHostToDevice));
-        net->plans[std::make_pair(workspace, (int)n)] = plan;
+        net->plans[std::make_pair(workspace, plan_key)] = plan;
     }
     net->last_n = n;
     // two-stream mode: the HBM-bound head (resize_in, conv1) and tail (heads, resize_out) run on tail_stream, the MFMA-bound middle on `stream`
@@ -2760,6 +2813,11 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
             mark(2);
             hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((B.C + 31) / 32, G), dim3(1024), 0, s, plan->d_descs + op.first, op.count, op.cfg,
                                B.C, 2 * B.H * B.H, net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
+            mark(-2);
+        } else if (op.type == OP_BCAST) {
+            const Buf& B = net->bufs[op.buf];
+            mark(2);
+            hipLaunchKernelGGL(bcast_warped_kernel, dim3(2048), dim3(256), 0, s, act + B.off * n, n, B.H * B.H, B.C, B.C / 6, ssp + B.ss_off * G, G);
             mark(-2);
         } else if (op.type == OP_HEADS) {
             HeadsDesc hd;

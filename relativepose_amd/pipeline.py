@@ -250,17 +250,17 @@ class RelativePosePipeline:
                     # forwards need separate workspaces: one per stream (= per in-flight slot).
                     f = torch.empty(x.shape[0], self.net.out_channels, x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
                     with torch.cuda.stream(ns):
-                        self.net.forward(x, out=f, tail_stream=ms, ws_key=ms.cuda_stream)
+                        self.net.forward(x, out=f, tail_stream=ms, ws_key=ms.cuda_stream, zero_warp=(step == 0))
                 else:
                     with torch.cuda.stream(ns):
-                        f = self.net(x)
+                        f = self.net.forward(x, zero_warp=(step == 0))
                         done = torch.cuda.Event()
                         done.record()
                     ms.wait_event(done)
                     f.record_stream(ms)        # allocated under the net stream, consumed on the batch stream
                 yield                                            # one yield per level: the other batches enqueue theirs
             else:
-                f = self.net(x)
+                f = self.net.forward(x, zero_warp=(step == 0))
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
                                                     self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
@@ -287,7 +287,8 @@ class RelativePosePipeline:
             inv = util.pose_inverse_dev(R_hat)
             poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
             util.warp_pairs_dev(x, poses, self.dataset)       # x[:, 8:] = partner view warped by the pose estimate
-            f = self.net(x)
+            # level 0 starts from the identity: util.warping returns zeros (util.py:95-96) for every image, which SCNet can exploit
+            f = self.net.forward(x, zero_warp=(step == 0 and R_forced is None))
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
                                                     self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)

@@ -151,6 +151,32 @@ def test_scnet_batched_groups_equal_single_pairs():
         assert torch.equal(y1, yb[2 * i:2 * i + 2]), i      # deterministic kernels: bitwise equal
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+def test_scnet_zero_warp_plan_is_bitwise_the_full_forward(prec):
+    """Level 0 of the recurrence (util.py:95-96: the identity pose warps to zeros): with channels 8:16 zero in every image the
+    RELPOSE_FWD_ZERO_WARP plan -- warped-view streams of conv2 / conv3 on the first BatchNorm group only, conv3 outputs + scale / shift
+    copied to the other images -- must give BITWISE the flag-less forward, for the output and for the raw A3 / A4 activations; also
+    when the zero-warp forward runs first on a fresh workspace (no left-overs of a full forward to hide behind) and for one pair (n = 2:
+    the flag is a no-op)."""
+    import torch
+    tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
+    net, _ = make_net(S, tanh, seed)
+    net.set_precision(prec)
+    xs = [torch.from_numpy(oracle_scnet_input(700 + i, ds, mm)).cuda() for i in range(4)]
+    x = torch.cat(xs)
+    x[:, 8:] = 0
+    yz = net.forward(x, zero_warp=True).clone()                       # first forward of this workspace
+    a3z, a4z = net.read_tap("A3").clone(), net.read_tap("A4").clone()
+    y = net.forward(x).clone()
+    a3, a4 = net.read_tap("A3").clone(), net.read_tap("A4").clone()
+    assert torch.equal(a3z, a3) and torch.equal(a4z, a4)
+    assert torch.equal(yz, y)
+    assert torch.equal(net.forward(x, zero_warp=True), y)             # and after a full forward
+    y1 = net.forward(x[:2].contiguous(), zero_warp=True)
+    assert torch.equal(y1, y[:2])
+    log("scnet_zero_warp", prec=prec, images=int(x.shape[0]), bitwise=True)
+
+
 def test_scnet_rejects_odd_batch_like_reference():
     import torch
     tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
