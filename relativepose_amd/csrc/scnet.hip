@@ -98,6 +98,8 @@ struct ConvDesc {
     double* stat_part;     // [mtiles][2 group slots][CoutPad][2] per-tile BatchNorm partial sums (or null)
     int cout_pad;
     int stat_bm;           // rows per tile of the kernel that writes stat_part (bn_finalize_fused_kernel walks the records with it)
+    int shared_slices;     // RELPOSE_FWD_ZERO_WARP, conv_s2_strip_kernel: bit ks = K slice ks is the same for every image pair: computed for
+                           // images 0, 1 only, and the split-K reduce reads row (img & 1, pixel) of it for every image
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, slope * v); }   // slope in (0,1]
@@ -1080,6 +1082,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ks = blockIdx.y / d.ntiles_n, n0 = (blockIdx.y - ks * d.ntiles_n) * NI * 32;
     const int m0 = blockIdx.x * BM, hw = d.Hp * d.Wp, W1 = d.Wp + 1, H1 = d.Hp + 1, img_pos = H1 * W1;
+    if (((d.shared_slices >> ks) & 1) && m0 >= 2 * hw) return;              // a shared slice: only the first image pair's rows are ever read
     auto pos_of = [&](int m) { const int img = m / hw, rem = m - img * hw; const int y = rem / d.Wp; return (img * H1 + y) * W1 + (rem - y * d.Wp); };
     const int pmin = pos_of(m0);
     const int nvalid = pos_of(min(m0 + BM, d.M) - 1) + W1 + 2 - pmin;          // staged positions (host guarantees <= SMAX)
@@ -1241,11 +1244,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvDesc* __re
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / q4), c4 = (int)(idx - (size_t)m * q4) * 4;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int img = m / hw, rem = m - img * hw;
+        const int msh = (img & 1) * hw + rem;                     // the row of a shared slice (ConvDesc::shared_slices)
         for (int ks = 0; ks < d.ksplit; ++ks) {
-            const float4 v = rp_ldg4(d.partial + ((size_t)ks * d.M + m) * d.cout_pad + c4);
+            const float4 v = rp_ldg4(d.partial + ((size_t)ks * d.M + (((d.shared_slices >> ks) & 1) ? msh : m)) * d.cout_pad + c4);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        const int img = m / hw, rem = m - img * hw;
         const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
         const size_t pix = ((size_t)img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
         float* yo = d.y + pix * d.ycstride + d.ychoff + c4;
@@ -1387,7 +1391,7 @@ __global__ __launch_bounds__(256, 2) void conv1_direct_kernel(const float* __res
 constexpr int C1T_PS = 17;                          // LDS pixel stride (floats)
 constexpr int C1T_XIN = 10 * 34 * C1T_PS;
 __global__ __launch_bounds__(256, 3) void conv1_mfma_kernel(const float* __restrict__ x0, const float* __restrict__ w1,
-                                                          float* __restrict__ a1, double* __restrict__ stat, int n) {
+                                                          float* __restrict__ a1, double* __restrict__ stat, int n, int zero_warp) {
     __shared__ __attribute__((aligned(16))) float wl[6 * 9 * 4 * 32];
     __shared__ __attribute__((aligned(16))) float xin[C1T_XIN];      // later reused for the per-wave statistics [4][192][2] f64
     static_assert(C1T_XIN * 4 >= 4 * 192 * 2 * 8, "statistics scratch aliases the input tile");
@@ -1411,6 +1415,9 @@ __global__ __launch_bounds__(256, 3) void conv1_mfma_kernel(const float* __restr
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int m = q >> 1, sft = (q & 1) * 8;
+        // RELPOSE_FWD_ZERO_WARP: the warped-view blocks (odd q) are exact zeros in every image and only the first image pair's are read
+        // (conv2 of those streams runs for one BatchNorm group): no MFMAs, no stores, zero statistics records for the other images
+        if (zero_warp && img >= 2 && (q & 1)) { st_s[q] = 0.0; st_q[q] = 0.0; continue; }
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -1566,11 +1573,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const ConvDesc
         const int c4 = cq * 4;
         for (int m = r0 + rl; m < r1; m += nrl) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int img = m / hw, rem = m - img * hw;
+            const int msh = (img & 1) * hw + rem;                 // the row of a shared slice (ConvDesc::shared_slices)
             for (int ks = 0; ks < d.ksplit; ++ks) {
-                const float4 v = rp_ldg4(d.partial + ((size_t)ks * d.M + m) * d.cout_pad + c4);
+                const float4 v = rp_ldg4(d.partial + ((size_t)ks * d.M + (((d.shared_slices >> ks) & 1) ? msh : m)) * d.cout_pad + c4);
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
-            const int img = m / hw, rem = m - img * hw;
             const int yp = rem / d.Wp, xp = rem - yp * d.Wp;
             const size_t pix = ((size_t)img * d.Hout + yp * d.osy + d.py) * d.Wout + xp * d.osx + d.px;
             float* yo = d.y + pix * d.ycstride + d.ychoff + c4;
@@ -2100,11 +2108,12 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7, OP_CONV_STRIP = 8, OP_BCAST = 9 };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7, OP_CONV_STRIP = 8, OP_BCAST = 9, OP_NOP = 10 };
 struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0, split = 0; int ninner = 1, mt_max = 1; };
 
 struct Plan {
     int n = 0; void* ws = nullptr;
+    bool zero_warp = false;      // RELPOSE_FWD_ZERO_WARP plan
     std::vector<ConvDesc> descs;
     std::vector<Op> ops;
     size_t splitk_floats = 0;
@@ -2124,6 +2133,8 @@ struct Builder {
     int rc = 0;
     int group_first = -1;
     bool zero_warp = false;     // RELPOSE_FWD_ZERO_WARP plan
+    int force_ksplit = 0, shared_slices = 0;   // conv4: 6 K slices = the six 128-channel stream blocks of A3 (in EVERY plan: same numerics);
+                                                // zero-warp plans mark the warped streams' slices shared (ConvDesc::shared_slices)
     int nimg = 0;               // images of the members added by conv() (0 = n): RELPOSE_FWD_ZERO_WARP plans run the warped streams on 2
 
     float* buf(const std::string& b);
@@ -2307,6 +2318,7 @@ void Builder::end_group() {
     // split along K until the launch has >= ~3000 tiles (>= 4 waves of resident blocks), keeping >= 8 k-tiles per slice
     int ksplit = 1;
     while (!dtile && s2_cfg < 0 && tiles * ksplit < 3000 && ksplit < 64 && min_kt / (ksplit * 2) >= 8) ksplit *= 2;
+    if (force_ksplit && !dtile && s2_cfg < 0) ksplit = force_ksplit;
     size_t pf = 0;
     for (int i = first; i < first + count; ++i) {
         ConvDesc& d = plan->descs[i];
@@ -2354,6 +2366,7 @@ void Builder::end_group() {
         // staged positions of a 128-pixel tile: 127 + row wraps + one image crossing + the taps' reach
         ok = ok && 127 + (127 + d.Wp - 1) / d.Wp + (d.Wp + 1) + (d.Wp + 1) + 2 <= 224;
         if (ok) {
+            if (shared_slices && (d.Cin / BK) % ksplit == 0) plan->descs[first].shared_slices = shared_slices;     // (slices = whole channel ranges here)
             Op o; o.type = OP_CONV_STRIP; o.first = first; o.count = 1; o.cfg = 0; o.split = net->prec;
             o.grid = dim3((unsigned)((d.M + 127) / 128), (cp / 128) * ksplit, 1);
             plan->ops.push_back(o);
@@ -2435,7 +2448,13 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
         }
         { Op o; o.type = OP_BCAST; o.first = o.count = o.cfg = 0; o.buf = "A3"; R.plan->ops.push_back(o); }
     }
+    R.force_ksplit = 6; R.shared_slices = R.zero_warp ? 0x2a : 0;      // slice ks = stream block ks of A3 (odd = warped view)
+    const size_t conv4_desc = R.plan->descs.size();
     one("conv4", R.src("A3", 0, 768), nullptr, 56, "A4", 0); R.stats("A4");
+    R.force_ksplit = 0; R.shared_slices = 0;
+    // (the strip kernel took the shared slices: nothing reads the warped blocks of A3 beyond the first image pair, no copies needed)
+    if (R.zero_warp && !R.rc && R.plan->descs[conv4_desc].shared_slices)
+        for (Op& o : R.plan->ops) if (o.type == OP_BCAST) o.type = OP_NOP;
     one("conv5", R.src("A4", 0, 256), nullptr, 28, "A5", 0); R.stats("A5");
     one("conv6", R.src("A5", 0, 512), nullptr, 14, "A6", 0); R.stats("A6");
     one("conv7", R.src("A6", 0, 512), nullptr, 7, "A7", 0); R.stats("A7");
@@ -2670,7 +2689,7 @@ int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_
         if (workspace_bytes < o.total) return RELPOSE_ENOMEM;
         if (net->plans.size() >= 16) free_plan(net);      // callers keep a few long-lived workspaces; bound the cache
         plan = new Plan();
-        plan->n = n; plan->ws = workspace;
+        plan->n = n; plan->ws = workspace; plan->zero_warp = zero_warp;
         char* ws = (char*)workspace;
         Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan; B.zero_warp = zero_warp;
         B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk); B.statp = (double*)(ws + o.statp);
@@ -2701,6 +2720,7 @@ int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_
     int op_index = -1;
     for (const Op& op : plan->ops) {
         ++op_index;
+        if (op.type == OP_NOP) continue;
         if (op_index == plan->head_count && s != (hipStream_t)stream) {      // head done: the convolutions continue on `stream`
             if (!plan->head_ev) RP_HIP(hipEventCreateWithFlags(&plan->head_ev, hipEventDisableTiming));
             RP_HIP(hipEventRecord(plan->head_ev, s));
@@ -2806,7 +2826,7 @@ int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_
                                    act + net->bufs["A1"].off * n, partial, n);
             else
                 hipLaunchKernelGGL(conv1_mfma_kernel, dim3(196 * n), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
-                                   act + net->bufs["A1"].off * n, partial, n);
+                                   act + net->bufs["A1"].off * n, partial, n, plan->zero_warp ? 1 : 0);
             mark(-1);
         } else if (op.type == OP_STATS_FUSED) {
             const Buf& B = net->bufs[op.buf];
