@@ -73,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-aux", action="store_true", help="skip the roofline / affinity side measurements (profiling runs)")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3", "f16"], default=None,
                     help="conv arithmetic (default: the config's; f32 = exact fp32 MFMA = the parity configuration)")
+    ap.add_argument("--pose-outputs", action="store_true",
+                    help="opt-in: SCNet computes only the heads the pose loop reads (normal, depth, features; RELPOSE_FWD_POSE_OUTPUTS) -- "
+                         "same poses, no completed rgb / semantic maps; NOT the BASELINE metric (the default computes every output)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
     ap.add_argument("--batches", type=int, default=4, help="distinct prepared batches rotated through the in-flight slots")
@@ -216,7 +219,8 @@ def worker(args):
     net.load_state_dict(weights.make_state_dict(7, S))
     net.set_precision(prec)
     Cc = N * 5
-    pipe = RelativePosePipeline(net, ds, mm, sigmas, max_edges=min(Cc * (Cc - 1), (1 << 20) * max(1, (N // 200) ** 2)))
+    pipe = RelativePosePipeline(net, ds, mm, sigmas, max_edges=min(Cc * (Cc - 1), (1 << 20) * max(1, (N // 200) ** 2)),
+                                outputs="pose" if args.pose_outputs else "all")
     batches, first = [], None
     for j in range(nbatch):
         seed = 1000 * (args.config + 1) + lo + 100000 * j      # seed = 1000*config + pair index; slot j>0: other pairs
@@ -279,6 +283,8 @@ def worker(args):
                           "pairs_per_step_total": total, "pairs_per_gpu": nloc, "keypoints": N, "semantic_classes": S,
                           "recurrent_levels": 3, "conv_precision": prec, "parallelism": f"pairs sharded x{world}",
                           "batches_in_flight": depth, "prepared_batches_rotated": nbatch,
+                          "scnet_outputs": "pose path only (normal, depth, features): opt-in, NOT the BASELINE metric" if args.pose_outputs else "all (like the reference)",
+                          "level0_zero_warp_plan": True,
                           "shard_sizes": [D.shard_range(total, r, world)[1] - D.shard_range(total, r, world)[0] for r in range(world)],
                           "pose_all_gathers_in_timed_region": ncoll,
                           "dist_backend": dist.get_backend() if world > 1 else None,

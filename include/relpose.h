@@ -244,8 +244,12 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
  * The three warped-view encoder streams (conv1*..conv3* on rgb_t2s / norm_t2s / depth_t2s, mymodel.py:278-288) then produce the same
  * activations for every image, so conv2* / conv3* of those streams run for the first BatchNorm group only and their conv3 outputs
  * (+ BatchNorm scale / shift) are copied to the other images before conv4: results are bitwise those of the flag-less forward.
- * With the flag set and a non-zero warped view the output is undefined. */
-enum { RELPOSE_FWD_ZERO_WARP = 1 };
+ * With the flag set and a non-zero warped view the output is undefined.
+ * RELPOSE_FWD_POSE_OUTPUTS: compute only the outputs the pose path consumes -- normal (channels 3:6), depth (6) and the 32 feature
+ * channels (7+S:), evaluation.py:246-253 / rpmodule.py:629-636 -- and skip the decoder branches that feed nothing else (deconv3/2/1 of the
+ * rgb and semantic heads, mymodel.py:312-316,364-368); channels 0:3 and 7:7+S of `out` are written as zeros, the other channels are
+ * bitwise those of the full forward.  Opt-in for callers that only want poses; never the default. */
+enum { RELPOSE_FWD_ZERO_WARP = 1, RELPOSE_FWD_POSE_OUTPUTS = 2 };
 int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
                            void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags);
 

@@ -1484,7 +1484,7 @@ struct HeadsDesc {
 };
 constexpr int HEADS_W = 4352;
 
-template <int S>
+template <int S, bool POSE = false>      // POSE (RELPOSE_FWD_POSE_OUTPUTS): the n, d and f heads only; rgb and semantic channels are written as zeros
 __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     __shared__ __attribute__((aligned(16))) float wl[HEADS_W];
     __shared__ float2 ssl[320];                        // scale/shift of this block's BatchNorm group
@@ -1533,22 +1533,24 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
         }                                                                                                \
     }
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {                      // rgb, n, d: 32 channels of D2 + 32 skip channels of A1
+    for (int m = POSE ? 1 : 0; m < 3; ++m) {           // rgb, n, d: 32 channels of D2 + 32 skip channels of A1
         RP_HEAD_LINE(pd + m * 32, m * 32, (m * 32) * 4, 4, 1, a3, m * 4)
         RP_HEAD_LINE(pa + m * 64, 224 + m * 32, (96 + m * 32) * 4, 4, 1, a3, m * 4)
     }
+    if (!POSE) {
 #pragma unroll
-    for (int l = 0; l < 2; ++l) RP_HEAD_LINE(pd + 96 + l * 32, 96 + l * 32, 768 + l * 32 * 24, 24, 6, as_, 0)           // s
+        for (int l = 0; l < 2; ++l) RP_HEAD_LINE(pd + 96 + l * 32, 96 + l * 32, 768 + l * 32 * 24, 24, 6, as_, 0)       // s
+    }
 #pragma unroll
     for (int l = 0; l < 2; ++l) RP_HEAD_LINE(pd + 160 + l * 32, 160 + l * 32, 2304 + l * 32 * 32, 32, 8, af, 0)         // f
 #undef RP_HEAD_LINE
     // bias, tanh, store (cf is even: 8-byte stores; a lane's cf floats are contiguous in the NHWC output)
     float r[cf + 1];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) { r[o] = a3[o] + hd.bias[o]; r[3 + o] = a3[4 + o] + hd.bias[3 + o]; }
+    for (int o = 0; o < 3; ++o) { r[o] = POSE ? 0.f : a3[o] + hd.bias[o]; r[3 + o] = a3[4 + o] + hd.bias[3 + o]; }
     r[6] = a3[8] + hd.bias[6];
 #pragma unroll
-    for (int o = 0; o < S; ++o) r[7 + o] = as_[o] + hd.bias[7 + o];
+    for (int o = 0; o < S; ++o) r[7 + o] = POSE ? 0.f : as_[o] + hd.bias[7 + o];
 #pragma unroll
     for (int k = 0; k < 32; ++k) { const float v = af[k] + hd.bias[7 + S + k]; r[7 + S + k] = hd.use_tanh ? tanhf(v) : v; }
     float* o = hd.out + pix * cf;
@@ -2114,6 +2116,7 @@ struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int ssl
 struct Plan {
     int n = 0; void* ws = nullptr;
     bool zero_warp = false;      // RELPOSE_FWD_ZERO_WARP plan
+    bool pose_only = false;      // RELPOSE_FWD_POSE_OUTPUTS plan
     std::vector<ConvDesc> descs;
     std::vector<Op> ops;
     size_t splitk_floats = 0;
@@ -2133,6 +2136,7 @@ struct Builder {
     int rc = 0;
     int group_first = -1;
     bool zero_warp = false;     // RELPOSE_FWD_ZERO_WARP plan
+    bool pose_only = false;     // RELPOSE_FWD_POSE_OUTPUTS plan: no rgb / semantic decoder branches
     int force_ksplit = 0, shared_slices = 0;   // conv4: 6 K slices = the six 128-channel stream blocks of A3 (in EVERY plan: same numerics);
                                                 // zero-warp plans mark the warped streams' slices shared (ConvDesc::shared_slices)
     int nimg = 0;               // images of the members added by conv() (0 = n): RELPOSE_FWD_ZERO_WARP plans run the warped streams on 2
@@ -2469,21 +2473,25 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     sk = R.src("A5", 0, 512); one("deconv5", R.src("D6", 0, 512), &sk, 14, "D5", 0); R.stats("D5");
     sk = R.src("A4", 0, 256); one("deconv4", R.src("D5", 0, 256), &sk, 28, "D4", 0); R.stats("D4");
     // heads (mymodel.py:309-376): rgb/n/d with skips from the self stream, s/f without
+    // (RELPOSE_FWD_POSE_OUTPUTS: the rgb and semantic branches feed nothing the pose path reads; their blocks of D3 / D2 stay unwritten)
+    auto wanted = [&](int m) { return !R.pose_only || (m != 0 && m != 3); };
     R.begin_group();
     for (int m = 0; m < 5; ++m) {
+        if (!wanted(m)) continue;
         if (m < 3) { sk = R.src("A3", 2 * m * 128, 128); R.conv(std::string("deconv3") + heads[m], R.src("D4", 0, 128), &sk, 56, "D3", m * 64); }
         else R.conv(std::string("deconv3") + heads[m], R.src("D4", 0, 128), nullptr, 56, "D3", m * 64);
     }
     R.end_group(); R.stats("D3");
     const int d2off[5] = {0, 32, 64, 96, 160};
     R.begin_group();
-    for (int m = 0; m < 3; ++m) { sk = R.src("A2", 2 * m * 64, 64); R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), &sk, 112, "D2", d2off[m]); }
+    for (int m = 0; m < 3; ++m) if (wanted(m)) { sk = R.src("A2", 2 * m * 64, 64); R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), &sk, 112, "D2", d2off[m]); }
     R.end_group();
     R.begin_group();
-    for (int m = 3; m < 5; ++m) R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), nullptr, 112, "D2", d2off[m]);
+    for (int m = 3; m < 5; ++m) if (wanted(m)) R.conv(std::string("deconv2") + heads[m], R.src("D3", m * 64, 64), nullptr, 112, "D2", d2off[m]);
     R.end_group(); R.stats("D2");
     R.plan->tail_first = (int)R.plan->ops.size();
     if (RP_ENV("RELPOSE_GEMM_HEADS") || (net->S != 15 && net->S != 21)) {   // generic implicit-GEMM path (5 members)
+        if (R.pose_only) R.rc = RELPOSE_EINVAL;                               // (pose-only plans need the fused heads kernel: S = 15 / 21)
         const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
         R.begin_group();
         for (int m = 0; m < 5; ++m) {
@@ -2674,11 +2682,12 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
 int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                            size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags) {
     if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0 || n >= (1 << 24)) return RELPOSE_EINVAL;
-    if (flags & ~RELPOSE_FWD_ZERO_WARP) return RELPOSE_EINVAL;
+    if (flags & ~(RELPOSE_FWD_ZERO_WARP | RELPOSE_FWD_POSE_OUTPUTS)) return RELPOSE_EINVAL;
     const int G = n / 2;
     // (nothing to share with one BatchNorm group; the tile kernels' patch pairing wants the 2-image members' patch count even as well)
     const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2;
-    const int plan_key = (int)n | (zero_warp ? 1 << 24 : 0);
+    const bool pose_only = (flags & RELPOSE_FWD_POSE_OUTPUTS) != 0;
+    const int plan_key = (int)n | (zero_warp ? 1 << 24 : 0) | (pose_only ? 1 << 25 : 0);
     Plan* plan = nullptr;
     {
         auto it = net->plans.find(std::make_pair(workspace, plan_key));
@@ -2689,9 +2698,9 @@ int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_
         if (workspace_bytes < o.total) return RELPOSE_ENOMEM;
         if (net->plans.size() >= 16) free_plan(net);      // callers keep a few long-lived workspaces; bound the cache
         plan = new Plan();
-        plan->n = n; plan->ws = workspace; plan->zero_warp = zero_warp;
+        plan->n = n; plan->ws = workspace; plan->zero_warp = zero_warp; plan->pose_only = pose_only;
         char* ws = (char*)workspace;
-        Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan; B.zero_warp = zero_warp;
+        Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan; B.zero_warp = zero_warp; B.pose_only = pose_only;
         B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk); B.statp = (double*)(ws + o.statp);
         build_plan(net, n, B);
         if (B.rc) { delete plan; return B.rc; }
@@ -2846,8 +2855,12 @@ int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_
             hd.w = net->d_w + net->wh_off; hd.bias = net->d_w + net->bh_off; hd.out = act + net->bufs["OUT"].off * n;
             hd.n = n; hd.S = net->S; hd.cf = net->cf; hd.use_tanh = net->use_tanh;
             mark(1);
-            if (net->S == 15) hipLaunchKernelGGL(heads_kernel<15>, dim3((unsigned)((size_t)n * RS * RS / 256)), dim3(256), 0, s, hd);
-            else hipLaunchKernelGGL(heads_kernel<21>, dim3((unsigned)((size_t)n * RS * RS / 256)), dim3(256), 0, s, hd);
+            const dim3 hg((unsigned)((size_t)n * RS * RS / 256));
+            if (plan->pose_only) {
+                if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, true>), hg, dim3(256), 0, s, hd);
+                else hipLaunchKernelGGL((heads_kernel<21, true>), hg, dim3(256), 0, s, hd);
+            } else if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, false>), hg, dim3(256), 0, s, hd);
+            else hipLaunchKernelGGL((heads_kernel<21, false>), hg, dim3(256), 0, s, hd);
             mark(-1);
         } else if (op.type == OP_REDUCE) {
             mark(4);

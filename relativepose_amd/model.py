@@ -135,13 +135,16 @@ class SCNet:
         self._ws = ws
         return ws
 
-    def forward(self, x, out=None, tail_stream=None, ws_key=None, zero_warp=False):
+    def forward(self, x, out=None, tail_stream=None, ws_key=None, zero_warp=False, outputs="all"):
         """tail_stream (a torch stream; not part of the reference interface): run the HBM-bound tail of the forward (heads + final
         resize) there, behind the convolutions on the current stream (relpose_scnet_forward2) -- `out` is then valid on tail_stream only.
         ws_key: name of the workspace to use (forwards that may overlap need different workspaces; default: one per stream).
         zero_warp: the caller guarantees x[:, 8:16] == 0 for every image (level 0 of the recurrence: util.warping returns zeros for the
         identity pose, util.py:95-96); the warped-view encoder streams then run once per batch instead of once per image
-        (RELPOSE_FWD_ZERO_WARP; bitwise the same output)."""
+        (RELPOSE_FWD_ZERO_WARP; bitwise the same output).
+        outputs: "all" (the reference's output) or "pose" (RELPOSE_FWD_POSE_OUTPUTS: only what the pose path reads -- normal 3:6, depth 6,
+        features 7+S: -- the rgb and semantic channels are zeros and their decoder branches are not run; the other channels are bitwise
+        those of the full forward)."""
         import torch
         dev = _lib.require_gpu()
         if not self._loaded:
@@ -154,7 +157,7 @@ class SCNet:
             out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
         s0 = _lib.stream_ptr()
         rc = _lib.lib().relpose_scnet_forward3(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), s0,
-                                               s0 if tail_stream is None else C.c_void_p(tail_stream.cuda_stream), 1 if zero_warp else 0)
+                                               s0 if tail_stream is None else C.c_void_p(tail_stream.cuda_stream), (1 if zero_warp else 0) | {"all": 0, "pose": 2}[outputs])
         _lib.check(rc, "relpose_scnet_forward")
         return out
 

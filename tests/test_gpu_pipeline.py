@@ -175,3 +175,51 @@ def test_pipeline_batches_in_flight_equal_sequential_runs():
     res = pipe.run_pipelined(states[:1], 2)                     # depth 1: plain sequential path
     torch.cuda.synchronize()
     assert all(torch.equal(r[0], want[0][0]) for r in res)
+
+
+def test_pipeline_rotating_states_with_reupload_equal_sequential_runs():
+    """The bench's steady state: 4 prepared batches rotate through 2 in-flight slots (a state changes slot stream from step to step) and
+    every step re-uploads its inputs from pinned host memory on the slot stream (before_batch = upload_inputs).  The uploaded buffers are
+    scrambled first, so a result can only be right if the upload really happened before the batch's first kernel: poses bitwise equal
+    to `run` batch by batch, also through the per-run stacking the bench's single gather uses."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, mm, S, tanh = "suncg", "second", 15, 1
+    net = _gpu_net(S, tanh, E2E_WEIGHT_SEED)
+    pipe = RelativePosePipeline(net, ds, mm)
+    states, want = [], []
+    for j in range(4):
+        d = synth.make_pairs(2, 1500 + 10 * j, ds)
+        pts, ptw = synth.make_keypoints(2, 60, 1500 + 10 * j, mm)
+        st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev, keep_host=True)
+        pose, status, _ = pipe.run(st)
+        states.append(st); want.append((pose.clone(), status.clone()))
+    torch.cuda.synchronize()
+    for st in states:                                    # whatever is on the device now must not matter
+        for k in st["host"]:
+            st[k].zero_()
+    res = pipe.run_pipelined(states, 7, None, depth=2, before_batch=lambda i, st: pipe.upload_inputs(st, None))
+    torch.cuda.synchronize()
+    for k, (pose, status) in enumerate(res):
+        assert torch.equal(pose, want[k % 4][0]) and torch.equal(status, want[k % 4][1]), k
+    stacked = torch.stack([r[0] for r in res], 1).reshape(2 * 7, 4, 4).reshape(2, 7, 4, 4)
+    assert torch.equal(stacked[:, -1], want[6 % 4][0])
+
+
+def test_pipeline_pose_outputs_option_gives_the_same_poses():
+    """RelativePosePipeline(outputs="pose"): SCNet without the rgb / semantic decoder branches -- poses and status bitwise those of the
+    default pipeline (which computes every output like the reference), free-running over the three levels."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, mm, S, tanh = "suncg", "second", 15, 1
+    net = _gpu_net(S, tanh, E2E_WEIGHT_SEED)
+    d = synth.make_pairs(3, 1600, ds)
+    pts, ptw = synth.make_keypoints(3, 60, 1600, mm)
+    full = RelativePosePipeline(net, ds, mm)
+    pose, status, trace = full.run(full.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev))
+    lean = RelativePosePipeline(net, ds, mm, outputs="pose")
+    pose2, status2, trace2 = lean.run(lean.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev))
+    assert torch.equal(pose, pose2) and torch.equal(status, status2)
+    assert all(torch.equal(a, b) for a, b in zip(trace, trace2))

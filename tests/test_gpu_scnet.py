@@ -181,6 +181,25 @@ def test_scnet_zero_warp_plan_is_bitwise_the_full_forward(prec):
     log("scnet_zero_warp", prec=prec, images=int(x.shape[0]), bitwise=True)
 
 
+def test_scnet_pose_outputs_are_bitwise_the_full_forward_on_the_pose_channels():
+    """RELPOSE_FWD_POSE_OUTPUTS (opt-in): the decoder branches of the rgb and semantic heads (mymodel.py:312-316,364-368) feed nothing the
+    pose loop reads (evaluation.py:246-253 takes normal 3:6, depth 6, features 7+S:); without them those channels must be BITWISE the
+    full forward's and the skipped channels zeros -- alone and combined with the level-0 plan."""
+    import torch
+    tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
+    net, _ = make_net(S, tanh, seed)
+    x = torch.cat([torch.from_numpy(oracle_scnet_input(800 + i, ds, mm)).cuda() for i in range(2)])
+    y = net.forward(x).clone()
+    yp = net.forward(x, outputs="pose").clone()
+    assert torch.equal(yp[:, 3:7], y[:, 3:7]) and torch.equal(yp[:, 7 + S:], y[:, 7 + S:])
+    assert float(yp[:, :3].abs().max()) == 0.0 and float(yp[:, 7:7 + S].abs().max()) == 0.0
+    x[:, 8:] = 0
+    y0 = net.forward(x).clone()
+    yp0 = net.forward(x, zero_warp=True, outputs="pose")
+    assert torch.equal(yp0[:, 3:7], y0[:, 3:7]) and torch.equal(yp0[:, 7 + S:], y0[:, 7 + S:])
+    log("scnet_pose_outputs", bitwise=True)
+
+
 def test_scnet_rejects_odd_batch_like_reference():
     import torch
     tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
