@@ -624,8 +624,13 @@ __device__ __forceinline__ void rp_tile_mma(floatx16 (&acc)[MI][NI], const float
 // blockIdx.z = N tile of NI * 32 output columns (Cout 64 as two tiles of 32: three workgroups per CU instead of two).
 // PAIR (TC == 8, 4 waves): the workgroup takes TWO 8 x 8 patches (consecutive in patch order, possibly in the two images of one
 // BatchNorm group) with separate 10 x 10 halo tiles -- 56-wide grids tile into 8 x 8 but not into 8 x 16 (deconv3).
+#ifndef RP_DT_SPLIT_OCC
+#define RP_DT_SPLIT_OCC 2
+#endif
+// (16-bit modes of the paired 8 x 8 variant -- deconv3 -- spill 44 registers at the 168 of 3 workgroups per CU: 2 per CU there, -9 %)
+#define RP_DT_OCC(MI_, NI_, NW_, SP_, PAIR_) ((MI_) * (NI_) == 1 ? ((NW_) == 4 ? (((SP_) && (PAIR_)) ? RP_DT_SPLIT_OCC : 3) : 2) : 2)
 template <int MI, int NI, int NW, int TC, bool PAIR = false, int SPLIT = 0>
-__global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void deconv_tile_kernel(const ConvDesc* __restrict__ descs) {
+__global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void deconv_tile_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int NT = NW * 64, TR = 32 / TC;
     constexpr int PR = PAIR ? 8 : (TC == 16 ? TR * MI * NW : TR), PW = PAIR ? 8 : (TC == 16 ? 16 : TC * NW), HW2 = PW + 2;
     constexpr int SUBPIX = (PR + 2) * HW2, NPIX = (PAIR ? 2 : 1) * SUBPIX;
@@ -760,36 +765,88 @@ __global__ __launch_bounds__(NW * 64, MI * NI == 1 ? (NW == 4 ? 3 : 2) : 2) void
             if ((it + 1) * PSTEP <= B_ROWS || b_off[it] >= 0) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = rb[it]; \
     }
 
-    RP_DT_LOAD_A(0)
-    RP_DT_LOAD_B(0, 0)
-    __syncthreads();                                                  // sstab
-    RP_DT_STORE_A(0)
-    RP_DT_STORE_B()
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int c0 = ch * BK;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            // prefetch into registers: the next phase's weights, and (during the last phase) the next chunk's halo tile
+#define RP_DT_LOAD_B2(RB, P, C0)                                                                               \
+    {                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
+            RB[it] = rp_bufld4(rs_b[P], max(b_off[it], 0), (C0) * 4);                                          \
+    }
+#define RP_DT_STORE_B2(RB)                                                                                     \
+    {                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
+            if ((it + 1) * PSTEP <= B_ROWS || b_off[it] >= 0) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = RB[it]; \
+    }
+    if constexpr (SPLIT != 0 && PAIR) {       // (deconv3's variant, which has the registers for it at 2 workgroups per CU; <1, 1> 8 x 16: no gain,
+                                              // <1, 2>: two weight sets + 128 accumulators spill, 896 -> 1415 us)
+        // 16-bit modes: a phase is 24 MFMAs of 32 cycles (fp32: 64 of 64), shorter than a trip to L2, so the register prefetch runs
+        // deeper: the weights of phase q + 2 are requested at the top of phase q (two register sets, alternating by phase parity) and
+        // the next chunk's halo tile at the top of phase 1 (fp32: one phase ahead for both)
+        float4 rb2[B_SLOTS];
+        RP_DT_LOAD_A(0)
+        RP_DT_LOAD_B2(rb, 0, 0)
+        RP_DT_LOAD_B2(rb2, 1, 0)
+        __syncthreads();                                              // sstab
+        RP_DT_STORE_A(0)
+        RP_DT_STORE_B2(rb)
+        __syncthreads();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int c0 = ch * BK;
             const bool last = (ch + 1 == nchunk);
-            if (p < 3) RP_DT_LOAD_B(p + 1, c0)
-            else if (!last) { RP_DT_LOAD_B(0, c0 + BK) RP_DT_LOAD_A(c0 + BK) }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int aoff = aoffs[p][t];
-                int ar_[MI], br_[NI];
+            for (int p = 0; p < 4; ++p) {
+                // the set that was stored to LDS for THIS phase is free: phase p + 2's weights go there
+                if (p < 2) { if (p == 0) RP_DT_LOAD_B2(rb, 2, c0) else RP_DT_LOAD_B2(rb2, 3, c0) }
+                else if (!last) { if (p == 2) RP_DT_LOAD_B2(rb, 0, c0 + BK) else RP_DT_LOAD_B2(rb2, 1, c0 + BK) }
+                if (p == 1 && !last) RP_DT_LOAD_A(c0 + BK)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
+                for (int t = 0; t < 4; ++t) {
+                    const int aoff = aoffs[p][t];
+                    int ar_[MI], br_[NI];
 #pragma unroll
-                for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LDK;
-                rp_tile_mma<SPLIT, MI, NI>(acc[p], At, ar_, Bt, br_);
+                    for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LDK;
+                    rp_tile_mma<SPLIT, MI, NI>(acc[p], At, ar_, Bt, br_);
+                }
+                __syncthreads();                                      // every wave is done with this phase's weights (and, p == 3, the halo tile)
+                if (p < 3 || !last) { if (p & 1) RP_DT_STORE_B2(rb) else RP_DT_STORE_B2(rb2) }      // phase p + 1's weights
+                if (p == 3 && !last) RP_DT_STORE_A(c0 + BK)
+                __syncthreads();
             }
-            __syncthreads();                                          // every wave is done with this phase's weights (and, p == 3, the halo tile)
-            if (p < 3 || !last) RP_DT_STORE_B()
-            if (p == 3 && !last) RP_DT_STORE_A(c0 + BK)
-            __syncthreads();
+        }
+    } else {
+        RP_DT_LOAD_A(0)
+        RP_DT_LOAD_B(0, 0)
+        __syncthreads();                                                  // sstab
+        RP_DT_STORE_A(0)
+        RP_DT_STORE_B()
+        __syncthreads();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int c0 = ch * BK;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                // prefetch into registers: the next phase's weights, and (during the last phase) the next chunk's halo tile
+                const bool last = (ch + 1 == nchunk);
+                if (p < 3) RP_DT_LOAD_B(p + 1, c0)
+                else if (!last) { RP_DT_LOAD_B(0, c0 + BK) RP_DT_LOAD_A(c0 + BK) }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int aoff = aoffs[p][t];
+                    int ar_[MI], br_[NI];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LDK;
+                    rp_tile_mma<SPLIT, MI, NI>(acc[p], At, ar_, Bt, br_);
+                }
+                __syncthreads();                                          // every wave is done with this phase's weights (and, p == 3, the halo tile)
+                if (p < 3 || !last) RP_DT_STORE_B()
+                if (p == 3 && !last) RP_DT_STORE_A(c0 + BK)
+                __syncthreads();
+            }
         }
     }
+#undef RP_DT_LOAD_B2
+#undef RP_DT_STORE_B2
 #undef RP_DT_LOAD_A
 #undef RP_DT_STORE_A
 #undef RP_DT_LOAD_B
