@@ -139,13 +139,12 @@ class RelativePosePipeline:
         import torch
         # HIP stream priority of the SCNet stream (RELPOSE_NET_PRIO overrides; -1 = high: conv workgroups are dispatched ahead of
         # the slot streams' kernels, which then fill the holes -- the drain of every conv launch, barrier stalls).  With the forwards'
-        # head / tail on the slot streams this is worth +1..2 % at 200 keypoints (489 -> 495-500 pairs/s) but costs 3 % at 400,
-        # where the slot-stream chain (tail -> matcher -> warp -> head) has no slack left and becomes critical when deprioritised.
-        # The rule is re-evaluated on every call (one stream per priority, both created up front).
+        # head / tail on the slot streams this is worth +4 % at 200 keypoints (499 -> 518 pairs/s, round 3).  Round 2 limited it to
+        # <= 256 keypoints per view (at 400 the deprioritised slot-stream chain tail -> matcher -> warp -> head became critical: -3 %);
+        # with round 3's matcher and level-0 plan that is gone (configs[2]: 482 vs 484 pairs/s), so it is on whenever the tail overlaps.
         if self._net_streams is None:
             self._net_streams = {0: torch.cuda.Stream(priority=0), -1: torch.cuda.Stream(priority=-1)}
-        nmax = max([int(st["N"]) for st in states] or [0]) if states else 0
-        prio = int(os.environ.get("RELPOSE_NET_PRIO", "-1" if (self.tail_overlap and 0 < nmax <= 256) else "0"))
+        prio = int(os.environ.get("RELPOSE_NET_PRIO", "-1" if self.tail_overlap else "0"))
         new_stream = self._net_streams[-1 if prio < 0 else 0]
         if self._net_stream is not None and new_stream is not self._net_stream:
             new_stream.wait_stream(self._net_stream)            # forwards of the previous call stay ordered before this call's
