@@ -366,7 +366,7 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     double* part2;              // partial sums of the products done with helper workgroups (only ever written write-through)
     double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
     int C, Cmax, nseg, tri_rounds, max_prod;
-    struct FitCtl* ctl;         // helper workgroups (G > 1): the pair's control block, the published vectors [2][Cmax] (u, then h)
+    struct FitCtl* ctl;         // helper workgroups (G > 1): the pair's control block; xu = the published vectors [2][Cmax] (u, then h), part2 behind them
     double* xu;
     int G;
     unsigned* epoch;            // LDS (leader): [0] products published so far, [1] h versions published, [2] claimed chunk
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     __shared__ double red[160];
     __shared__ double Rt[12];
     __shared__ int st_s;
-    __shared__ unsigned cl_s[3];        // helper-workgroup protocol: leader [0] products / [1] h versions published; helper [0] control word seen; [2] claimed chunk
+    __shared__ unsigned cl_s[3];        // helper-workgroup protocol: leader [0] products / [1] h versions published; helper [0] / [1] the control word as polled (high / low half); [2] claimed chunk
     constexpr int DEPTH = 2;            // (4 = the whole segment in flight: measured 13 % slower at 512 threads, spills at 1024)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int G = gridDim.x;            // workgroups per scan pair: 1 leader + G - 1 helpers for the matrix-vector products
