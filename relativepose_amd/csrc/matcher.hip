@@ -401,12 +401,7 @@ __device__ __forceinline__ double rp_ld_sc1(const double* p) { return __longlong
 __device__ __forceinline__ void rp_st_sc1(rp_u64* p, rp_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ rp_u64 rp_ld_sc1(const rp_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rp_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// Chunks of the distributed products: chunk 0 is the LEADER's (never claimed: it starts on it the moment the product is published,
-// some microseconds before a helper has seen the control word and loaded the vector) and twice as long as the others, which are
-// claimed in order; sizes are whole 128-byte lines of partial sums.  With everybody there, every workgroup does one chunk.
-__device__ __forceinline__ int fit_chunk_size(int nseg, int G) { return max(64, ((nseg + G) / (G + 1) + 63) & ~63); }
-__device__ __forceinline__ int fit_chunk_count(int nseg, int csz) { return 1 + max(0, (nseg - 2 * csz + csz - 1) / csz); }
-__device__ __forceinline__ int fit_chunk_begin(int ch, int csz) { return ch == 0 ? 0 : (ch + 1) * csz; }
+// (chunk geometry of the distributed products: rp_fit_chunk_size / _count / _begin in rp_math.h, CPU-tested)
 
 // One pass over the pair's edges: thread <-> segment (<= 32 edges of one row, read with stride 64 so that a wave's loads
 // are 64 consecutive entries), sequential accumulation per segment, then every row adds up its segments in order.
@@ -531,8 +526,8 @@ __device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_x
 //   helpers: LOADER() = their vector loads, issued while the first claim is in flight; they leave when nothing is left to claim.
 template <int DEPTH, bool LEADER, class LOADER>
 __device__ __forceinline__ void fit_work_loop(const Fit1& f, rp_u64 word, int* s_chunk, LOADER loader) {
-    const int csz = fit_chunk_size(f.nseg, f.G);
-    const unsigned nchunks = (unsigned)fit_chunk_count(f.nseg, csz);
+    const int csz = rp_fit_chunk_size(f.nseg, f.G);
+    const unsigned nchunks = (unsigned)rp_fit_chunk_count(f.nseg, csz);
     int prev = -1;
     for (int it = 0;; ++it) {
         if (threadIdx.x == 0) {
@@ -563,7 +558,7 @@ __device__ __forceinline__ void fit_work_loop(const Fit1& f, rp_u64 word, int* s
         __syncthreads();
         const int ch = __builtin_amdgcn_readfirstlane(*s_chunk);
         if (ch < 0) break;
-        const int s0 = fit_chunk_begin(ch, csz), s1 = min(f.nseg, fit_chunk_begin(ch + 1, csz));
+        const int s0 = rp_fit_chunk_begin(ch, csz), s1 = min(f.nseg, rp_fit_chunk_begin(ch + 1, csz));
         for (int sgm = s0 + threadIdx.x; sgm < s1; sgm += blockDim.x) seg_body<1, DEPTH, true>(f, sgm, 0.0, false);
         rp_drain_stores();
         __syncthreads();        // every wave's partial sums are out (and everyone has read *s_chunk) before thread 0 counts the chunk

@@ -37,6 +37,14 @@ struct RpPairConsts {       // derived on the host in double, exactly as numpy d
     double mu;
 };
 
+// Chunks of the fit's distributed matrix-vector products (matcher.hip, fit_work_loop) over nseg segments and G workgroups per scan
+// pair: chunk 0 is the LEADER's (never claimed: it starts on it the moment the product is published, some microseconds before a helper
+// has seen the control word and loaded the vector) and twice as long as the others, which are claimed in order; sizes are whole
+// 128-byte lines of partial sums (multiples of 64 segments).  With everybody there, every workgroup does one chunk.
+RP_HD int rp_fit_chunk_size(int nseg, int G) { const int c = ((nseg + G) / (G + 1) + 63) & ~63; return c < 64 ? 64 : c; }
+RP_HD int rp_fit_chunk_count(int nseg, int csz) { const int r = (nseg - 2 * csz + csz - 1) / csz; return 1 + (r < 0 ? 0 : r); }
+RP_HD int rp_fit_chunk_begin(int ch, int csz) { return ch == 0 ? 0 : (ch + 1) * csz; }
+
 RP_HD double rp_norm3(double x, double y, double z) { return sqrt((x * x + y * y) + z * z); }
 RP_HD double rp_dot3(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 RP_HD double rp_clip1(double v) { return v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v); }   // NaN stays NaN

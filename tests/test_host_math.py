@@ -28,6 +28,8 @@ int t_inv4(const double* A, double* o) { return rp_inv4(A, o) ? 1 : 0; }
 void t_horn_fast(const double* M, double* R) { double m[3][3], r[3][3]; for(int i=0;i<9;++i) m[i/3][i%3]=M[i];
     rp_horn_rotation_fast(m, r); for(int i=0;i<9;++i) R[i]=r[i/3][i%3]; }
 void t_div100(const float* x, float* out, int* ok, int n) { for (int i = 0; i < n; ++i) { out[i] = rp_div100_fast(x[i]); ok[i] = rp_div100_ok(x[i]) ? 1 : 0; } }
+void t_chunks(int nseg, int G, int* out) { const int c = rp_fit_chunk_size(nseg, G); out[0] = c; out[1] = rp_fit_chunk_count(nseg, c);
+    for (int k = 0; k <= out[1] && k < 62; ++k) out[2 + k] = rp_fit_chunk_begin(k, c); }
 int t_eig4_fast(const double* N, double* q) { double n[4][4]; for(int i=0;i<16;++i) n[i/4][i%4]=N[i]; return rp_sym4_max_eigvec_fast(n, q); }
 }
 '''
@@ -163,3 +165,23 @@ def test_div100_fast_equals_float32_division(shim):
     assert m.sum() > 2_000_000
     assert np.array_equal(out[m].view(np.uint32), ref[m].view(np.uint32))
     assert not ok[np.abs(x) >= 1e30].any() and not ok[(np.abs(x) <= 1e-30) & (x != 0)].any()
+
+
+def test_fit_chunk_geometry_covers_every_segment_once(shim):
+    """Chunks of the fit's distributed products (rp_fit_chunk_*): for every segment count and cluster size the chunks tile [0, nseg)
+    exactly -- consecutive, disjoint, on 64-segment (128-byte) boundaries, the leader's chunk 0 twice the size of the others, at most
+    one chunk per workgroup once there are enough segments -- so a partial sum is written by exactly one claim."""
+    out = (C.c_int * 64)()
+    rng = np.random.default_rng(3)
+    cases = [(n, g) for g in range(2, 9) for n in (1, 63, 64, 65, 127, 128, 129, 500, 1000, 4999, 5000, 5001, 32768)]
+    cases += [(int(n), int(g)) for n, g in zip(rng.integers(1, 40000, 300), rng.integers(2, 9, 300))]
+    for nseg, G in cases:
+        shim.t_chunks(nseg, G, out)
+        csz, cnt = out[0], out[1]
+        assert csz % 64 == 0 and csz >= 64 and 1 <= cnt <= 60, (nseg, G, csz, cnt)
+        begins = [out[2 + k] for k in range(cnt + 1)]
+        assert begins[0] == 0 and begins[1] == 2 * csz and all(b - a == csz for a, b in zip(begins[1:], begins[2:]))
+        assert begins[cnt - 1] < nseg or cnt == 1            # the last chunk is not empty ...
+        assert begins[cnt] >= nseg                            # ... and reaches the end (the kernel clamps it to nseg)
+        if nseg >= 64 * (G + 1):
+            assert cnt <= G, (nseg, G, csz, cnt)              # everybody there: one chunk each
