@@ -1566,15 +1566,17 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     for (int o = 0; o < 32; ++o) af[o] = 0.f;
     // One 128-byte line (32 channels) of a pixel at a time: all 8 loads are issued back to back so the line is
     // fetched once (a wave touches 64 lines per load instruction; interleaving compute between the loads of a
-    // line let other waves evict it from the 32 KB L1 first).  Then BN + LeakyReLU and
-    // acc[4j+t'] += v * w[row][4j+t'] over the row's NQ4 weight quads.
-#define RP_HEAD_LINE(PTR, SSROW, WOFF, WSTRIDE, NQ4, ACC, OBASE)                                          \
+    // line let other waves evict it from the 32 KB L1 first).  The NEXT line's loads are issued before this line's arithmetic
+    // (two register sets, alternating): at 234 VGPRs only 2 waves share a SIMD and nothing else hides the trip to HBM.
+    // Then BN + LeakyReLU and acc[4j+t'] += v * w[row][4j+t'] over the row's NQ4 weight quads.
+#define RP_HEAD_LOAD(X8, PTR)                                                                             \
+    { _Pragma("unroll") for (int q = 0; q < 8; ++q) X8[q] = reinterpret_cast<const float4*>(PTR)[q]; }
+#define RP_HEAD_LINE(X8, NEXT, SSROW, WOFF, WSTRIDE, NQ4, ACC, OBASE)                                     \
     {                                                                                                    \
-        float4 x8[8];                                                                                    \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) x8[q] = reinterpret_cast<const float4*>(PTR)[q];   \
+        NEXT                                                                                             \
         _Pragma("unroll 1") for (int q = 0; q < 8; ++q) {                                                \
-            const float4 x4 = x8[0];                                                                     \
-            _Pragma("unroll") for (int z = 0; z < 7; ++z) x8[z] = x8[z + 1];                             \
+            const float4 x4 = X8[0];                                                                     \
+            _Pragma("unroll") for (int z = 0; z < 7; ++z) X8[z] = X8[z + 1];                             \
             const float xv[4] = {x4.x, x4.y, x4.z, x4.w};                                                \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                              \
                 const float2 sc = ssl[(SSROW) + q * 4 + t];                                              \
@@ -1589,18 +1591,24 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
             }                                                                                            \
         }                                                                                                \
     }
+    // line order: [rgb: D2, A1 skip]  n: D2, A1  d: D2, A1  [s: 2 lines of D2]  f: 2 lines of D2
+    float4 xa[8], xb[8];
+    constexpr int M0 = POSE ? 1 : 0;
+    RP_HEAD_LOAD(xa, pd + M0 * 32)
 #pragma unroll
-    for (int m = POSE ? 1 : 0; m < 3; ++m) {           // rgb, n, d: 32 channels of D2 + 32 skip channels of A1
-        RP_HEAD_LINE(pd + m * 32, m * 32, (m * 32) * 4, 4, 1, a3, m * 4)
-        RP_HEAD_LINE(pa + m * 64, 224 + m * 32, (96 + m * 32) * 4, 4, 1, a3, m * 4)
+    for (int m = M0; m < 3; ++m) {                     // rgb, n, d: 32 channels of D2 + 32 skip channels of A1
+        RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pa + m * 64), m * 32, (m * 32) * 4, 4, 1, a3, m * 4)
+        if (m < 2) { RP_HEAD_LINE(xb, RP_HEAD_LOAD(xa, pd + (m + 1) * 32), 224 + m * 32, (96 + m * 32) * 4, 4, 1, a3, m * 4) }
+        else { RP_HEAD_LINE(xb, RP_HEAD_LOAD(xa, pd + (POSE ? 160 : 96)), 224 + m * 32, (96 + m * 32) * 4, 4, 1, a3, m * 4) }
     }
     if (!POSE) {
-#pragma unroll
-        for (int l = 0; l < 2; ++l) RP_HEAD_LINE(pd + 96 + l * 32, 96 + l * 32, 768 + l * 32 * 24, 24, 6, as_, 0)       // s
+        RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 128), 96, 768, 24, 6, as_, 0)                                                // s
+        RP_HEAD_LINE(xb, RP_HEAD_LOAD(xa, pd + 160), 128, 768 + 32 * 24, 24, 6, as_, 0)
     }
-#pragma unroll
-    for (int l = 0; l < 2; ++l) RP_HEAD_LINE(pd + 160 + l * 32, 160 + l * 32, 2304 + l * 32 * 32, 32, 8, af, 0)         // f
+    RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 192), 160, 2304, 32, 8, af, 0)                                                   // f
+    RP_HEAD_LINE(xb, , 192, 2304 + 32 * 32, 32, 8, af, 0)
 #undef RP_HEAD_LINE
+#undef RP_HEAD_LOAD
     // bias, tanh, store (cf is even: 8-byte stores; a lane's cf floats are contiguous in the NHWC output)
     float r[cf + 1];
 #pragma unroll
