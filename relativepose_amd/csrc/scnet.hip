@@ -1848,6 +1848,8 @@ __global__ void resize_in_kernel(const float* __restrict__ x, float* __restrict_
 // (C = 54/60 floats per pixel: 8-B aligned), then every lane blends its 4 taps from LDS and writes plane by
 // plane (256 contiguous bytes per store instruction).
 #define RO_MAXW 28
+#define RO_MAXC 60                                   // channels of the LDS path (7 + S + 32 <= 60); more: the generic path
+#define RO_PF ((RO_MAXW * RO_MAXC / 2 + 63) / 64)    // float2 per lane and source row
 __global__ __launch_bounds__(256) void resize_out_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float smem_ro[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1855,52 +1857,81 @@ __global__ __launch_bounds__(256) void resize_out_kernel(const float* __restrict
     const int segs = (W + 63) / 64;
     const size_t nseg = (size_t)n * H * segs;
     const float shh = (float)RS / H, sww = (float)RS / W;
-    for (size_t sidx = (size_t)blockIdx.x * 4 + wave; sidx < nseg; sidx += (size_t)gridDim.x * 4) {
-        const int seg = (int)(sidx % segs), oy = (int)((sidx / segs) % H), img = (int)(sidx / ((size_t)segs * H));
-        const int ox_first = seg * 64, ox_last = min(ox_first + 63, W - 1);
-        int y0, y1, xa, xb, xc, xd; float ly0, ly1, t0, t1;
-        lin_coef(oy, shh, RS, y0, y1, ly0, ly1);
-        lin_coef(ox_first, sww, RS, xa, xb, t0, t1);
+    // a wave's segment: source rows y0 / y1 and the source pixel range [sx, sx + width) of its 64 output pixels
+    struct Seg { int img, oy, ox_first, y0, y1, sx, width; float ly0, ly1; bool lds; };
+    auto seg_of = [&](size_t sidx) {
+        Seg g;
+        const int seg = (int)(sidx % segs);
+        g.oy = (int)((sidx / segs) % H); g.img = (int)(sidx / ((size_t)segs * H));
+        g.ox_first = seg * 64;
+        const int ox_last = min(g.ox_first + 63, W - 1);
+        int xa, xb, xc, xd; float t0, t1;
+        lin_coef(g.oy, shh, RS, g.y0, g.y1, g.ly0, g.ly1);
+        lin_coef(g.ox_first, sww, RS, xa, xb, t0, t1);
         lin_coef(ox_last, sww, RS, xc, xd, t0, t1);
-        const int sx = xa, width = xd - xa + 1;           // <= RO_MAXW for scale <= 0.4 (224/640 = 0.35)
-        if (width > RO_MAXW || (C & 1)) {
+        g.sx = xa; g.width = xd - xa + 1;           // <= RO_MAXW for scale <= 0.4 (224/640 = 0.35)
+        g.lds = g.width <= RO_MAXW && !(C & 1) && C <= RO_MAXC;
+        return g;
+    };
+    // The source pixels of the NEXT segment travel in registers while this segment is blended and stored (a wave did load -> blend ->
+    // store strictly in turn before: 698 us per forward at 64 images).
+    float2 pf[2][RO_PF];
+    auto prefetch = [&](const Seg& g) {
+        const int nf2 = g.width * C / 2;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float2* src = reinterpret_cast<const float2*>(x + (((size_t)g.img * RS + (r ? g.y1 : g.y0)) * RS + g.sx) * C);
+#pragma unroll
+            for (int k = 0; k < RO_PF; ++k) { const int i = lane + 64 * k; if (i < nf2) pf[r][k] = src[i]; }
+        }
+    };
+    const size_t step = (size_t)gridDim.x * 4;
+    size_t sidx = (size_t)blockIdx.x * 4 + wave;
+    Seg cur;
+    if (sidx < nseg) { cur = seg_of(sidx); if (cur.lds) prefetch(cur); }
+    for (; sidx < nseg; sidx += step) {
+        const Seg g = cur;
+        if (!g.lds) {
             // generic shapes (W < ~560: the 64-pixel segment spans more source pixels than the LDS region holds; odd C:
             // pixel rows are not 8-byte aligned): every lane gathers its 4 taps straight from global memory
-            const int ox = ox_first + lane;
+            const int ox = g.ox_first + lane;
             if (ox < W) {
                 int x0, x1; float lx0, lx1;
                 lin_coef(ox, sww, RS, x0, x1, lx0, lx1);
-                const float* r0 = x + ((size_t)img * RS + y0) * RS * C;
-                const float* r1 = x + ((size_t)img * RS + y1) * RS * C;
+                const float* r0 = x + ((size_t)g.img * RS + g.y0) * RS * C;
+                const float* r1 = x + ((size_t)g.img * RS + g.y1) * RS * C;
                 const float* a = r0 + (size_t)x0 * C; const float* b = r0 + (size_t)x1 * C;
                 const float* cc = r1 + (size_t)x0 * C; const float* dd = r1 + (size_t)x1 * C;
-                float* o = y + (size_t)img * C * H * W + (size_t)oy * W + ox;
+                float* o = y + (size_t)g.img * C * H * W + (size_t)g.oy * W + ox;
                 for (int c = 0; c < C; ++c)
-                    o[(size_t)c * H * W] = ly0 * (lx0 * a[c] + lx1 * b[c]) + ly1 * (lx0 * cc[c] + lx1 * dd[c]);
+                    o[(size_t)c * H * W] = g.ly0 * (lx0 * a[c] + lx1 * b[c]) + g.ly1 * (lx0 * cc[c] + lx1 * dd[c]);
             }
+            if (sidx + step < nseg) { cur = seg_of(sidx + step); if (cur.lds) prefetch(cur); }
             continue;
         }
-        const int nf2 = width * C / 2;
+        const int nf2 = g.width * C / 2;
+#pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const float2* src = reinterpret_cast<const float2*>(x + (((size_t)img * RS + (r ? y1 : y0)) * RS + sx) * C);
             float2* dst = reinterpret_cast<float2*>(srow + r * RO_MAXW * C);
-            for (int i = lane; i < nf2; i += 64) dst[i] = src[i];
+#pragma unroll
+            for (int k = 0; k < RO_PF; ++k) { const int i = lane + 64 * k; if (i < nf2) dst[i] = pf[r][k]; }
         }
+        if (sidx + step < nseg) { cur = seg_of(sidx + step); if (cur.lds) prefetch(cur); }
         // the wave's own LDS region: make the writes visible to all of its lanes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int ox = ox_first + lane;
+        const int ox = g.ox_first + lane;
         if (ox < W) {
             int x0, x1; float lx0, lx1;
             lin_coef(ox, sww, RS, x0, x1, lx0, lx1);
-            const float* a = srow + (x0 - sx) * C;
-            const float* b = srow + (x1 - sx) * C;
+            const float* a = srow + (x0 - g.sx) * C;
+            const float* b = srow + (x1 - g.sx) * C;
             const float* cc = a + RO_MAXW * C;
             const float* dd = b + RO_MAXW * C;
-            float* o = y + (size_t)img * C * H * W + (size_t)oy * W + ox;
+            float* o = y + (size_t)g.img * C * H * W + (size_t)g.oy * W + ox;
             for (int c = 0; c < C; ++c)
-                o[(size_t)c * H * W] = ly0 * (lx0 * a[c] + lx1 * b[c]) + ly1 * (lx0 * cc[c] + lx1 * dd[c]);
+                o[(size_t)c * H * W] = g.ly0 * (lx0 * a[c] + lx1 * b[c]) + g.ly1 * (lx0 * cc[c] + lx1 * dd[c]);
         }
         __builtin_amdgcn_wave_barrier();                 // LDS region is reused by the next segment
     }
@@ -2969,7 +3000,7 @@ int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_
         }
     }
     mark(3);
-    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), (size_t)4 * 2 * RO_MAXW * net->cf * sizeof(float), s,
+    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), net->cf <= RO_MAXC ? (size_t)4 * 2 * RO_MAXW * net->cf * sizeof(float) : 0, s,
                        act + net->bufs["OUT"].off * n, out, n, net->cf, H, W);
     mark(-3);
     RP_CHECK_LAUNCH();
