@@ -239,7 +239,9 @@ class RelativePosePipeline:
         x = self._net_input(st)
         R_hat, status = st["eye"], None
         for step in range(self.alter_steps):
-            inv = util.pose_inverse_dev(R_hat)
+            # (level 0: the estimate IS the identity, and so is its inverse -- taken literally, not through the inversion kernel, because
+            # the zero-warp plan below relies on BOTH warps of a pair being the identity's all-zero view, util.py:95-96)
+            inv = R_hat if step == 0 else util.pose_inverse_dev(R_hat)
             poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
             util.warp_pairs_dev(x, poses, self.dataset)       # x[:, 8:] = partner view warped by the pose estimate
             if self._chain_nets:
@@ -286,7 +288,7 @@ class RelativePosePipeline:
             if R_forced is not None:
                 R_hat = R_forced[step]
             # image 2b (source) gets target warped by inv(R), image 2b+1 (target) gets source warped by R
-            inv = util.pose_inverse_dev(R_hat)
+            inv = R_hat if (step == 0 and R_forced is None) else util.pose_inverse_dev(R_hat)
             poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
             util.warp_pairs_dev(x, poses, self.dataset)       # x[:, 8:] = partner view warped by the pose estimate
             # level 0 starts from the identity: util.warping returns zeros (util.py:95-96) for every image, which SCNet can exploit
