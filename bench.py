@@ -116,9 +116,10 @@ def _traffic(tag):
         return None
 
 
-def affinity_roofline(N, B, dev, sigmas):
+def affinity_roofline(N, B, dev, sigmas, want_wij=True):
     """N x N affinity build (materialised fp32 wij), the kernel the HBM target is stated on: HIP-event time of `reps`
-    back-to-back launches (no host gaps) at batch B."""
+    back-to-back launches (no host gaps) at batch B.  want_wij=False: the fused variant the matcher itself runs (top-K straight from the
+    exponents, no N x N copy: algorithmic bytes = descriptors in + K correspondences out)."""
     import torch
     from relativepose_amd import rpmodule, synth
     base = [synth.make_match_case(N, 5000 + b)[:2] for b in range(min(B, 32))]
@@ -126,17 +127,17 @@ def affinity_roofline(N, B, dev, sigmas):
     para = rpmodule.opts(*sigmas[0])
     f_s, w_s, f_t, w_t, ns_, nt_ = kp[2], kp[3], kp[6], kp[7], kp[8], kp[9]
     for _ in range(3):
-        rpmodule.affinity_topk(f_s, w_s, f_t, w_t, ns_, nt_, para, want_wij=True)
+        rpmodule.affinity_topk(f_s, w_s, f_t, w_t, ns_, nt_, para, want_wij=want_wij)
     reps = 20
-    outs = rpmodule.affinity_topk_buffers(B, N, N, para.topK, dev, want_wij=True)
+    outs = rpmodule.affinity_topk_buffers(B, N, N, para.topK, dev, want_wij=want_wij)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        rpmodule.affinity_topk(f_s, w_s, f_t, w_t, ns_, nt_, para, want_wij=True, out=outs)
+        rpmodule.affinity_topk(f_s, w_s, f_t, w_t, ns_, nt_, para, want_wij=want_wij, out=outs)
     e1.record()
     e1.synchronize()
     a_ms = e0.elapsed_time(e1) / reps
-    abytes = ((N + N) * 33 * 4 + N * N * 4) * B
+    abytes = ((N + N) * 33 * 4 + (N * N * 4 if want_wij else N * para.topK * 12)) * B
     gbs = abytes / (a_ms * 1e-3) / 1e9
     return {"batch_pairs": B, "keypoints": N, "achieved": gbs, "frac": gbs / PEAK_HBM_GBS, "ms_per_launch": a_ms,
             "algorithmic_bytes_per_launch": abytes}
@@ -325,6 +326,7 @@ def worker(args):
                                         "traffic": tra["bytes"] if tra else None, "traffic_unit": "HBM bytes per launch at batch 1024 (rocprofv3 PMC; upper bound, see profiles/traffic.json)",
                                         "traffic_profile": tra["profile"] if tra else None,
                                         "at_batch_1024": a_big, "at_bench_batch": a_small,
+                                        "fused_at_batch_1024": affinity_roofline(N, 1024, dev, sigmas, want_wij=False),
                                         "note": "headline = batch 1024 (one launch at the bench batch moves only "
                                                 f"{a_small['algorithmic_bytes_per_launch'] / 1e6:.1f} MB, i.e. less than 1 us of HBM time)"}
             res["roofline_geometry"] = geometry_roofline(cfg, 2 * nloc, N, dev, net.out_channels, pipe.feat_off)
