@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: pair sharding + the single pose gather of the multi-GPU path."""
+"""CPU, gloo, world sizes 2 and 8 (the node the driver scales to): pair sharding + the single pose gather of the multi-GPU path."""
 import os
 import socket
 
@@ -50,3 +50,26 @@ def test_gather_poses_gloo_world2(total):
         assert np.array_equal(P, want)
         assert np.array_equal(S, np.arange(total) % 5)
         assert t == 2.0
+
+
+@pytest.mark.parametrize("total", [250, 256])
+def test_gather_poses_gloo_world8_ragged_and_even(total):
+    """Eight ranks like the 8-GPU node: 250 pairs = ragged shards of 32 / 31 (configs[3] with --total-pairs 250), 256 = even; every
+    rank ends up with every pose in pair order, one all_gather per rank."""
+    import torch.multiprocessing as mp
+    world = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    want = np.arange(total)[:, None, None] + np.eye(4)[None]
+    assert sorted(r[0] for r in res) == list(range(world))
+    for rank, P, S, t in res:
+        assert np.array_equal(P, want)
+        assert np.array_equal(S, np.arange(total) % 5)
+        assert t == float(world)
