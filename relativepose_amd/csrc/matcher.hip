@@ -817,12 +817,12 @@ __device__ __attribute__((noinline)) void horn_lds(const double* m9, double* r9)
 }
 
 // fit_solve for the single-workgroup kernel: same arithmetic and summation order as fit_solve, Horn through horn_lds
+template <int EPT>
 __device__ void fit_solve1(const FitCtx& f, bool reweight, double* Rt /* LDS [12]: R row-major, t */) {
-    // the first correspondence of every thread lives in registers across the three passes (12 doubles each); beyond that
-    // (C > blockDim) the passes re-read them like fit_solve does
-    constexpr int EPT = 1;
+    // EPT = 1: the first correspondence of every thread lives in registers across the three passes (12 doubles each); beyond that
+    // (C > blockDim) -- and with EPT = 0 for all of them -- the passes re-read them from the gathered geometry table (L2-resident)
     const int nloc = min(EPT, (f.C - (int)threadIdx.x + (int)blockDim.x - 1) / (int)blockDim.x);
-    double gsp[EPT][3], gtp[EPT][3], gsn[EPT][3], gtn[EPT][3], gdeg[EPT], ggP[EPT], ggN[EPT];
+    double gsp[EPT + 1][3], gtp[EPT + 1][3], gsn[EPT + 1][3], gtn[EPT + 1][3], gdeg[EPT + 1], ggP[EPT + 1], ggN[EPT + 1];      // (+ 1: no zero-length arrays)
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const int c = threadIdx.x + k * blockDim.x;
@@ -924,6 +924,9 @@ __device__ __forceinline__ void write_pose_lds(double* out, const double* Rt) {
     }
 }
 
+#ifndef RP_FIT_EPT
+#define RP_FIT_EPT(T_) ((T_) == 512 ? 1 : 0)
+#endif
 template <int THREADS, bool GVEC>       // GVEC: the three per-correspondence vectors + row / segment pointers in global memory (else LDS)
 __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK, int method,
                                                                     double* __restrict__ lz_basis, double* __restrict__ gvec, int32_t* __restrict__ status,
@@ -1054,7 +1057,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     }
     const bool irls0 = (method == RELPOSE_FIT_IRLS_SM || method == RELPOSE_FIT_IRLS);
     long long ti_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
-    for (int it = 0; it < (irls0 ? 5 : 1); ++it) fit_solve1(fc, irls0, Rt);
+    for (int it = 0; it < (irls0 ? 5 : 1); ++it) fit_solve1<RP_FIT_EPT(THREADS)>(fc, irls0, Rt);
     if (f.prof && tid == 0 && b == 0) { f.prof[4] += (long long)__builtin_readcyclecounter() - ti_; f.prof[7] = ti_ - tstart_; }
     write_pose_lds(pose + (size_t)b * 16, Rt);
     if (trace) write_pose_lds(trace + (size_t)b * 96, Rt);
@@ -1077,7 +1080,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             for (int c = tid; c < C; c += blockDim.x) { fc.deg[c] = f.yy[c]; fc.gP[c] = 1.0; fc.gN[c] = 1.0; }
             __syncthreads();
             long long tj_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
-            for (int it = 0; it < (sm ? 5 : 1); ++it) fit_solve1(fc, sm, Rt);
+            for (int it = 0; it < (sm ? 5 : 1); ++it) fit_solve1<RP_FIT_EPT(THREADS)>(fc, sm, Rt);
             if (f.prof && tid == 0 && b == 0) f.prof[4] += (long long)__builtin_readcyclecounter() - tj_;
             write_pose_lds(pose + (size_t)b * 16, Rt);
             if (trace) write_pose_lds(trace + (size_t)b * 96 + (round + 1) * 16, Rt);
@@ -1232,15 +1235,15 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
         // helper workgroups per pair for the matrix-vector products (see FitCtl): a LATENCY tool.  Alone on the chip the matcher of 32
         // N = 400 pairs drops from 7.7 to 5.1 ms with 7 helpers per pair, but helpers sit on a CU each for the whole fit, mostly
         // polling, and inside the pipeline they take those CUs from the SCNet kernels of the other slot: configs[2] 462 -> 400 pairs/s,
-        // configs[1] 497 -> 475 with 3 helpers (measured, round 3).  So by default only small batches -- at most 64 workgroups, a
-        // quarter of the chip -- get helpers (up to 7 beyond 1024 correspondences per pair, up to 3 from 512), never the 'spectral'
+        // configs[1] 497 -> 475 with 3 helpers (measured, round 3).  So by default only small batches -- at most 32 workgroups, an
+        // eighth of the chip: even 2 workgroups per pair at 32 pairs cost configs[2] 1.7 % (505 -> 496) -- get helpers (up to 7 beyond 1024 correspondences per pair, up to 3 from 512), never the 'spectral'
         // method (its per-round edge weights are written by the leader with plain stores) or the global layout.
         // RELPOSE_TUNE_FIT_CLUSTER forces a size (1 = none).
         int G = 1;
         if (in_lds && m != RELPOSE_FIT_SPECTRAL) {
             const int want = g_rp_tune[RELPOSE_TUNE_FIT_CLUSTER];
             if (want > 0) G = want > 8 ? 8 : want;
-            else if (L.Cmax >= 512) { G = L.Cmax > 1024 ? 8 : 4; while (G > 1 && (long long)kp->B * G > 64) G >>= 1; }
+            else if (L.Cmax >= 512) { G = L.Cmax > 1024 ? 8 : 4; while (G > 1 && (long long)kp->B * G > 32) G >>= 1; }
         }
         if (G > 1) RP_HIP(hipMemsetAsync(ws + L.ctl, 0, (size_t)kp->B * sizeof(FitCtl), s));
 #define RP_FIT_LAUNCH(T_, G_)                                                                                                          \
