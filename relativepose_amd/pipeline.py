@@ -15,7 +15,7 @@ import os
 
 import numpy as np
 
-from . import rpmodule, util
+from . import _lib, rpmodule, util
 
 
 class RelativePosePipeline:
@@ -181,37 +181,41 @@ class RelativePosePipeline:
                 st["stream"].wait_stream(cur)
         results = [None] * steps
         live, nxt = {}, 0
-        while nxt < steps or live:
-            for slot in range(depth):
-                if slot not in live and nxt < steps:
-                    st = states[nxt % nst]
-                    ss = self._slot_streams[slot]
-                    if st.get("stream") is not None and st["stream"] is not ss:
-                        ss.wait_stream(st["stream"])         # the buffers' previous use (another slot / run_interleaved)
-                    st["stream"] = ss
-                    if before_batch is not None:
-                        with torch.cuda.stream(st["stream"]):
-                            before_batch(nxt, st)
-                    live[slot] = (nxt, st, self._run_gen(st))
-                    nxt += 1
-                if slot not in live:
-                    continue
-                k, st, gen = live[slot]
-                done = None
-                with torch.cuda.stream(st["stream"]):
-                    try:
-                        next(gen)
-                    except StopIteration as e:
-                        done = e.value
-                if done is not None:
-                    del live[slot]
-                    pose, status = done[0], done[1]
-                    if on_result is not None:
-                        cur.wait_stream(st["stream"])
-                        pose.record_stream(cur); status.record_stream(cur)
-                        results[k] = on_result(k, pose, status)
-                    else:
-                        results[k] = (pose, status)
+        # batches in flight = a throughput loop: the fit's helper workgroups (a latency tool for a lone small batch)
+        # would take CUs from the other slot's convolutions, so the matcher calls enqueued here use one workgroup per pair
+        import contextlib
+        with (_lib.tuning(fit_cluster=1) if depth > 1 else contextlib.nullcontext()):
+            while nxt < steps or live:
+                for slot in range(depth):
+                    if slot not in live and nxt < steps:
+                        st = states[nxt % nst]
+                        ss = self._slot_streams[slot]
+                        if st.get("stream") is not None and st["stream"] is not ss:
+                            ss.wait_stream(st["stream"])         # the buffers' previous use (another slot / run_interleaved)
+                        st["stream"] = ss
+                        if before_batch is not None:
+                            with torch.cuda.stream(st["stream"]):
+                                before_batch(nxt, st)
+                        live[slot] = (nxt, st, self._run_gen(st))
+                        nxt += 1
+                    if slot not in live:
+                        continue
+                    k, st, gen = live[slot]
+                    done = None
+                    with torch.cuda.stream(st["stream"]):
+                        try:
+                            next(gen)
+                        except StopIteration as e:
+                            done = e.value
+                    if done is not None:
+                        del live[slot]
+                        pose, status = done[0], done[1]
+                        if on_result is not None:
+                            cur.wait_stream(st["stream"])
+                            pose.record_stream(cur); status.record_stream(cur)
+                            results[k] = on_result(k, pose, status)
+                        else:
+                            results[k] = (pose, status)
         for st in states:
             if "stream" in st:
                 cur.wait_stream(st["stream"])
