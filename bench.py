@@ -76,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--pose-outputs", action="store_true",
                     help="opt-in: SCNet computes only the heads the pose loop reads (normal, depth, features; RELPOSE_FWD_POSE_OUTPUTS) -- "
                          "same poses, no completed rgb / semantic maps; NOT the BASELINE metric (the default computes every output)")
+    ap.add_argument("--no-self-cache", action="store_true",
+                    help="levels 1-2 recompute the self-view encoder streams (A/B switch; the default reuses level 0's, bitwise the same poses)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
     ap.add_argument("--batches", type=int, default=4, help="distinct prepared batches rotated through the in-flight slots")
@@ -221,7 +223,7 @@ def worker(args):
     net.set_precision(prec)
     Cc = N * 5
     pipe = RelativePosePipeline(net, ds, mm, sigmas, max_edges=min(Cc * (Cc - 1), (1 << 20) * max(1, (N // 200) ** 2)),
-                                outputs="pose" if args.pose_outputs else "all")
+                                outputs="pose" if args.pose_outputs else "all", self_stream_cache=not args.no_self_cache)
     batches, first = [], None
     for j in range(nbatch):
         seed = 1000 * (args.config + 1) + lo + 100000 * j      # seed = 1000*config + pair index; slot j>0: other pairs
@@ -286,6 +288,9 @@ def worker(args):
                           "batches_in_flight": depth, "prepared_batches_rotated": nbatch,
                           "scnet_outputs": "pose path only (normal, depth, features): opt-in, NOT the BASELINE metric" if args.pose_outputs else "all (like the reference)",
                           "level0_zero_warp_plan": True,
+                          # levels 1-2 take the self-view encoder streams (conv1-3 self members, conv4 self K slices) from level 0 of the same
+                          # pass (relpose_scnet_forward4; bitwise the same output); "roofline" below is still measured on FULL forwards
+                          "self_stream_cache": not args.no_self_cache,
                           "shard_sizes": [D.shard_range(total, r, world)[1] - D.shard_range(total, r, world)[0] for r in range(world)],
                           "pose_all_gathers_in_timed_region": ncoll,
                           "dist_backend": dist.get_backend() if world > 1 else None,

@@ -252,6 +252,18 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
 enum { RELPOSE_FWD_ZERO_WARP = 1, RELPOSE_FWD_POSE_OUTPUTS = 2 };
 int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
                            void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags);
+/* relpose_scnet_forward3 with a self-stream cache.  Inside one scan pair's recurrence (evaluation.py:217-242) the masked own views --
+ * channels 0:8 of every image -- never change between the levels, only the warped partner view (channels 8:16) does, and the reference
+ * runs the self-view encoder streams as module calls of their own with their own batch statistics (conv1/2/3{rgb,n,d} on x[:,0:8],
+ * mymodel.py:266-276; the warped-view calls are :278-288).  `self_tag` names the content of channels 0:8: when it is non-zero and
+ * equal to the tag (and n, H, W) of the PREVIOUS forward on this workspace, the self-view blocks of conv1 / conv2 / conv3, their BatchNorm
+ * scale / shift and conv4's three self K slices are taken from the workspace instead of being recomputed -- bitwise the values the
+ * full forward would produce.  Any other tag (or 0) runs the full forward and leaves the cache filled for the next call.
+ * Contract: two forwards on one workspace that carry the same non-zero tag have identical channels 0:8 (the caller draws a fresh tag
+ * whenever it rewrites them); the weights / precision may not change in between (set_param / finalize / set_precision drop the cache).
+ * RELPOSE_FWD_ZERO_WARP forwards always compute (and cache) the self streams. */
+int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
+                           void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags, uint64_t self_tag);
 
 /* Debug: copy a raw (pre-BatchNorm) layer output of the last forward, NHWC float32, to out (device).
  * Returns the number of floats written (or needed if out is NULL), <0 if unknown. */

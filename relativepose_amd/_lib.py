@@ -65,6 +65,8 @@ SIGNATURES = {
     "relpose_scnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "relpose_scnet_forward2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "relpose_scnet_forward3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
+    "relpose_scnet_forward4": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int,
+                                       C.c_uint64]),
     "relpose_scnet_read_tap": (c_int64, [c_void_p, c_char_p, c_void_p, c_void_p, c_void_p]),
     "relpose_scnet_profile": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_int,
                                       C.POINTER(c_double), C.POINTER(c_double), C.POINTER(c_int64), c_void_p]),

@@ -135,7 +135,15 @@ class SCNet:
         self._ws = ws
         return ws
 
-    def forward(self, x, out=None, tail_stream=None, ws_key=None, zero_warp=False, outputs="all"):
+    _tag_counter = 0
+
+    @classmethod
+    def new_self_tag(cls):
+        """A fresh non-zero tag for forward(self_tag=...): draw one whenever channels 0:8 of the input are (re)written."""
+        cls._tag_counter += 1
+        return cls._tag_counter
+
+    def forward(self, x, out=None, tail_stream=None, ws_key=None, zero_warp=False, outputs="all", self_tag=0):
         """tail_stream (a torch stream; not part of the reference interface): run the HBM-bound tail of the forward (heads + final
         resize) there, behind the convolutions on the current stream (relpose_scnet_forward2) -- `out` is then valid on tail_stream only.
         ws_key: name of the workspace to use (forwards that may overlap need different workspaces; default: one per stream).
@@ -144,7 +152,10 @@ class SCNet:
         (RELPOSE_FWD_ZERO_WARP; bitwise the same output).
         outputs: "all" (the reference's output) or "pose" (RELPOSE_FWD_POSE_OUTPUTS: only what the pose path reads -- normal 3:6, depth 6,
         features 7+S: -- the rgb and semantic channels are zeros and their decoder branches are not run; the other channels are bitwise
-        those of the full forward)."""
+        those of the full forward).
+        self_tag: non-zero = the caller's name for the content of x[:, 0:8] (the masked own views, constant across the levels of a scan
+        pair's recurrence, evaluation.py:217-242): a forward that finds the previous forward of its workspace carried the same tag reuses
+        that forward's self-view encoder streams (relpose_scnet_forward4; bitwise the same output).  0 = always recompute."""
         import torch
         dev = _lib.require_gpu()
         if not self._loaded:
@@ -156,8 +167,9 @@ class SCNet:
         if out is None:
             out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
         s0 = _lib.stream_ptr()
-        rc = _lib.lib().relpose_scnet_forward3(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), s0,
-                                               s0 if tail_stream is None else C.c_void_p(tail_stream.cuda_stream), (1 if zero_warp else 0) | {"all": 0, "pose": 2}[outputs])
+        rc = _lib.lib().relpose_scnet_forward4(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), s0,
+                                               s0 if tail_stream is None else C.c_void_p(tail_stream.cuda_stream),
+                                               (1 if zero_warp else 0) | {"all": 0, "pose": 2}[outputs], int(self_tag))
         _lib.check(rc, "relpose_scnet_forward")
         return out
 

@@ -23,8 +23,13 @@ class RelativePosePipeline:
     _net_stream = None
     _net_streams = None
 
-    def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0, compose=0, outputs="all"):
+    def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0, compose=0, outputs="all",
+                 self_stream_cache=True):
         self.net = net
+        # the masked own views (channels 0:8 of the net input) are written once per pass and only the warped partner view changes from
+        # level to level (evaluation.py:217-242): levels >= 1 reuse level 0's self-view encoder streams (SCNet.forward(self_tag=...),
+        # bitwise the same output).  False: every level recomputes them, like the reference.
+        self.self_stream_cache = self_stream_cache
         # "all": SCNet computes every output like the reference; "pose": only the heads this loop reads (normal, depth, features:
         # RELPOSE_FWD_POSE_OUTPUTS) -- the same poses bit for bit, the completed rgb / semantic maps are not produced (opt-in)
         self.outputs = outputs
@@ -233,6 +238,8 @@ class RelativePosePipeline:
         if x is None:
             x = st["x"] = torch.empty(2 * B, 16, h, 4 * h, dtype=torch.float32, device=view.device)
         x[:, :8].copy_(view)
+        # a fresh name for this content of channels 0:8 (whoever finds the same tag on its workspace may reuse the self-view streams)
+        st["self_tag"] = self.net.new_self_tag() if self.self_stream_cache else 0
         return x
 
     def _run_gen(self, st):
@@ -258,17 +265,18 @@ class RelativePosePipeline:
                     # forwards need separate workspaces: one per stream (= per in-flight slot).
                     f = torch.empty(x.shape[0], self.net.out_channels, x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
                     with torch.cuda.stream(ns):
-                        self.net.forward(x, out=f, tail_stream=ms, ws_key=ms.cuda_stream, zero_warp=(step == 0), outputs=self.outputs)
+                        self.net.forward(x, out=f, tail_stream=ms, ws_key=ms.cuda_stream, zero_warp=(step == 0), outputs=self.outputs,
+                                         self_tag=st["self_tag"])
                 else:
                     with torch.cuda.stream(ns):
-                        f = self.net.forward(x, zero_warp=(step == 0), outputs=self.outputs)
+                        f = self.net.forward(x, zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"])
                         done = torch.cuda.Event()
                         done.record()
                     ms.wait_event(done)
                     f.record_stream(ms)        # allocated under the net stream, consumed on the batch stream
                 yield                                            # one yield per level: the other batches enqueue theirs
             else:
-                f = self.net.forward(x, zero_warp=(step == 0), outputs=self.outputs)
+                f = self.net.forward(x, zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"])
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
                                                     self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
@@ -296,7 +304,7 @@ class RelativePosePipeline:
             poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
             util.warp_pairs_dev(x, poses, self.dataset)       # x[:, 8:] = partner view warped by the pose estimate
             # level 0 starts from the identity: util.warping returns zeros (util.py:95-96) for every image, which SCNet can exploit
-            f = self.net.forward(x, zero_warp=(step == 0 and R_forced is None), outputs=self.outputs)
+            f = self.net.forward(x, zero_warp=(step == 0 and R_forced is None), outputs=self.outputs, self_tag=st["self_tag"])
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
                                                     self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)

@@ -223,3 +223,37 @@ def test_pipeline_pose_outputs_option_gives_the_same_poses():
     pose2, status2, trace2 = lean.run(lean.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev))
     assert torch.equal(pose, pose2) and torch.equal(status, status2)
     assert all(torch.equal(a, b) for a, b in zip(trace, trace2))
+
+
+def test_pipeline_self_stream_cache_gives_the_same_poses():
+    """Levels 1-2 reuse level 0's self-view encoder streams (RelativePosePipeline(self_stream_cache=True), the default:
+    SCNet.forward(self_tag=...)); with the cache off every level recomputes them like the reference (mymodel.py:266-276 at every
+    call of evaluation.py:242).  Poses, status and the pose after every level must be bitwise equal -- in `run`, and in the serving
+    loop where four prepared batches rotate through two in-flight slots (a slot's workspace goes from batch to batch)."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, mm, S, tanh = "suncg", "second", 15, 1
+    net = _gpu_net(S, tanh, E2E_WEIGHT_SEED)
+    plain = RelativePosePipeline(net, ds, mm, self_stream_cache=False)
+    cached = RelativePosePipeline(net, ds, mm)
+    assert cached.self_stream_cache
+    states, want = [], []
+    for j in range(4):
+        d = synth.make_pairs(2, 1700 + 10 * j, ds)
+        pts, ptw = synth.make_keypoints(2, 60, 1700 + 10 * j, mm)
+        st = plain.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+        pose, status, trace = plain.run(st)
+        pose2, status2, trace2 = cached.run(st)
+        assert torch.equal(pose, pose2) and torch.equal(status, status2)
+        assert all(torch.equal(a, b) for a, b in zip(trace, trace2))
+        states.append(st); want.append((pose.clone(), status.clone()))
+    torch.cuda.synchronize()
+    res = cached.run_pipelined(states, 9, None, depth=2)
+    torch.cuda.synchronize()
+    for k, (pose, status) in enumerate(res):
+        assert torch.equal(pose, want[k % 4][0]) and torch.equal(status, want[k % 4][1]), k
+    res = cached.run_interleaved(states[:3])
+    torch.cuda.synchronize()
+    for k, (pose, status) in enumerate(res):
+        assert torch.equal(pose, want[k][0]) and torch.equal(status, want[k][1]), k

@@ -181,6 +181,63 @@ def test_scnet_zero_warp_plan_is_bitwise_the_full_forward(prec):
     log("scnet_zero_warp", prec=prec, images=int(x.shape[0]), bitwise=True)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+def test_scnet_self_stream_cache_is_bitwise_the_full_forward(prec):
+    """Levels >= 1 of the recurrence: channels 0:8 (the masked own views) are those of level 0, only the warped view changed
+    (evaluation.py:217-242), and the reference runs the self-view streams as separate module calls with their own batch statistics
+    (mymodel.py:266-276).  A forward carrying the tag of the previous forward of its workspace skips the self members of
+    conv1 / conv2 / conv3 and conv4's self K slices: output, raw A1..A4 and everything else must be BITWISE the tag-less forward's --
+    after a level-0 (zero-warp) forward, after a full forward, as the first forward of a fresh workspace (nothing cached: it must
+    compute), after the tag changed (a new batch in a rotating slot), and with the pose-outputs plan."""
+    import torch
+    tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
+    net, _ = make_net(S, tanh, seed)
+    net.set_precision(prec)
+    xa = torch.cat([torch.from_numpy(oracle_scnet_input(900 + i, ds, mm)).cuda() for i in range(3)])
+    xb = torch.cat([torch.from_numpy(oracle_scnet_input(910 + i, ds, mm)).cuda() for i in range(3)])
+    taps = ("A1", "A2", "A3", "A4", "D3", "D2")
+
+    def fwd(x, **kw):
+        y = net.forward(x, **kw).clone()
+        return y, {t: net.read_tap(t).clone() for t in taps}
+
+    def same(got, ref, what):
+        assert torch.equal(got[0], ref[0]), what
+        for t in taps:
+            assert torch.equal(got[1][t], ref[1][t]), (what, t)
+
+    # a pass over batch a: level 0 = zero warp, levels 1 and 2 = two different warped views
+    x0 = xa.clone(); x0[:, 8:] = 0
+    x1 = xa.clone()
+    x2 = xa.clone(); x2[:, 8:] = xb[:, 8:]
+    ref1, ref2 = fwd(x1), fwd(x2)                                      # tag-less: always the full forward
+    t1 = net.new_self_tag()
+    same(fwd(x1, self_tag=t1), ref1, "first forward with a new tag computes everything")
+    same(fwd(x2, self_tag=t1), ref2, "cached after a full forward")
+    same(fwd(x1, self_tag=t1), ref1, "cached again")
+    t2 = net.new_self_tag()
+    fwd(x0, zero_warp=True, self_tag=t2)                               # level 0 fills the cache (its warped streams: first pair only)
+    same(fwd(x1, self_tag=t2), ref1, "cached after the level-0 plan")
+    same(fwd(x2, self_tag=t2), ref2, "second cached level")
+    # another batch takes the workspace (new tag): its self streams must be recomputed, then cached
+    refb = fwd(xb)
+    xb2 = xb.clone(); xb2[:, 8:] = xa[:, 8:]
+    refb2 = fwd(xb2)
+    t3 = net.new_self_tag()
+    same(fwd(xb, self_tag=t3), refb, "new tag after another batch's cached forwards")
+    same(fwd(xb2, self_tag=t3), refb2, "cached for the new batch")
+    # a tag-less forward of other data in between invalidates the cache (tag 0 never matches)
+    fwd(xa)
+    same(fwd(xb2, self_tag=t3), refb2, "tag-less forward in between: recompute")
+    # pose-outputs plan combined with the cache
+    yp = net.forward(xb, outputs="pose", self_tag=t3)
+    assert torch.equal(yp[:, 3:7], refb[0][:, 3:7]) and torch.equal(yp[:, 7 + S:], refb[0][:, 7 + S:])
+    # a fresh workspace (another batch size) whose first forward already carries a known tag
+    y2 = net.forward(xb[:2].contiguous(), self_tag=t3)
+    assert torch.equal(y2, refb[0][:2])
+    log("scnet_self_stream_cache", prec=prec, images=int(xa.shape[0]), bitwise=True)
+
+
 def test_scnet_pose_outputs_are_bitwise_the_full_forward_on_the_pose_channels():
     """RELPOSE_FWD_POSE_OUTPUTS (opt-in): the decoder branches of the rgb and semantic heads (mymodel.py:312-316,364-368) feed nothing the
     pose loop reads (evaluation.py:246-253 takes normal 3:6, depth 6, features 7+S:); without them those channels must be BITWISE the
