@@ -328,7 +328,7 @@ def worker(args):
             tra = _traffic(f"affinity_b1024_n{N}")
             res["roofline_affinity"] = {"kernel": "affinity_tile_kernel + fix-up scan (batch 1024) / affinity_rows_kernel (bench batch), materialised fp32 wij", "bound": "hbm", "unit": "GB/s",
                                         "peak": PEAK_HBM_GBS, "achieved": a_big["achieved"], "frac": a_big["frac"],
-                                        "traffic": tra["bytes"] if tra else None, "traffic_unit": "HBM bytes per launch at batch 1024 (rocprofv3 PMC; upper bound, see profiles/traffic.json)",
+                                        "traffic": tra["bytes"] if tra else None, "traffic_unit": "HBM bytes per launch at batch 1024 (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                                         "traffic_profile": tra["profile"] if tra else None,
                                         "at_batch_1024": a_big, "at_bench_batch": a_small,
                                         "fused_at_batch_1024": affinity_roofline(N, 1024, dev, sigmas, want_wij=False),

@@ -305,32 +305,19 @@ __global__ __launch_bounds__(256) void affinity_rows_kernel(RelposeKeypoints kp,
 // ---- tile (MFMA) variant: exact work only where it can matter ----------------------------------------------------------------
 // The numpy-order float32 distance costs 95 separately rounded operations per entry, but only a handful of entries per row
 // matter: the K winners, whatever lies within RP_AFF_NORM_WINDOW of the row maximum (the float64 row norm) and, when wij is
-// materialised, within RP_AFF_WINDOW of it (everything else is an exact 0 in the float32 wij).  A wave owns 32 source rows
-// and finds those entries from APPROXIMATE exponents:
-//   e~ = -rd (|s|^2 + |t|^2 - 2 s.t), s.t from v_mfma_f32_32x32x16_f16 with the TARGETS as M and the 32 source rows as N: in
-//   the C layout lane (n, h) holds entries of ITS OWN row n (16 targets per 32-target tile, lanes n and n + 32 share a row),
-//   so row-wise selection is in-lane work (no cross-lane traffic) and the approximate values never leave registers.
-// With err bounding |e~ - e| (fp16 operand rounding, derived below) every true winner has e~ >= kth~ - 2 err, where kth~ is the
-// K-th largest of the row's group-of-8 maxima (a lower bound of the K-th largest e~), and every entry inside a window W of
-// the true maximum has e~ >= max~ - W - 2 err.  Three sweeps over the targets (the MFMAs are recomputed, 4 per 64 targets):
-//   P1   max~ and kth~ of every row (one v_max3 chain per 8 entries + one sorted-list insertion per group);
-//   P2a  the IMPORTANT entries (possible winners + norm window) onto a per-lane stack, then per lane the exact treatment of
-//        affinity_rows_kernel -- numpy-order distance, Markstein division, float64 exp, (e, smaller j) ordering, norm --
-//        and the K outputs of the row;
-//   P2b  (materialised wij only) the window entries go through a wave-wide ring (ballot compaction) and are evaluated 64 at a
-//        time, one per lane whatever row they belong to (source row gathered from its owner lane with ds_bpermute): exact
-//        distance, exp(e - max~) on the float32 exp2 unit, scaled by the row's exp(max~)/norm, stored over the zero.
-//   The zeros themselves -- the 164 MB of a 1024-pair batch -- are one contiguous span per wave (its 32 rows), written with
-//   coalesced 16-byte stores between the P1 tiles, so that they drain while the matrix and vector pipes work (issued in the
-//   P2b sweep, when every wave of the chip is in its store phase at once, they cost 47 us instead of 15).
-// A row whose stack overflows, or whose data the bound does not cover (weights outside [0, 1], |descriptor| >= 1e4, NaN), is
-// marked RP_AFF_REDO and redone by affinity_rows_kernel<FIXUP> (launched right behind, normally a no-op).
-// Results: indices and float64 weights identical to affinity_rows_kernel's (same exact arithmetic on a superset of the
-// entries that matter; the norm leaves out terms below e^-48 of the largest); float32 wij within 3e-7 relative.
+// materialised, within RP_AFF_WINDOW of it (everything else is an exact 0 in the float32 wij).  A wave owns up to 32 source rows
+// and finds those entries from APPROXIMATE distances on the matrix pipe: v_mfma_f32_32x32x16_f16 with the TARGETS as M and the
+// source rows as N -- in the C layout lane (n, h) holds entries of ITS OWN row n (16 targets per 32-target tile, lanes n and
+// n + 32 share a row), so row-wise selection is in-lane work and the approximate values never leave registers.
+// With err bounding |e~ - e| (fp16 operand rounding, derived in the kernel) every true winner has e~ >= kth~ - 2 err, where kth~ is
+// the K-th largest of the row's group-of-8 maxima (a lower bound of the K-th largest e~), and every entry inside a window W of
+// the true maximum has e~ >= max~ - W - 2 err.
+// A row whose candidates do not fit the wave's queue / the lane's stack, or whose data the bound does not cover (weights outside
+// [0, 1], |descriptor| >= 1e4, NaN), is marked RP_AFF_REDO and redone by affinity_rows_kernel<FIXUP> (launched right behind,
+// normally a no-op).  The kernel itself (round 4: second generation) is described at affinity_tile_kernel.
 #define AT_WAVES 8             // waves per workgroup = tiles of 32 source rows (small batches launch 2 or 4)
 #define AT_LDT 36              // LDS row stride of the target descriptors (floats): conflict-free b128 reads
 #define AT_ISTK 16             // important-entry stack per lane (half a row), uint16 target indices; 24 beyond 256 targets
-#define AT_QCAP 128            // window-entry ring per wave (flushed 64 at a time)
 #define RP_AFF_NORM_WINDOW 24.0      // squares below e^-48 (1.4e-21) of the largest are left out of the float64 row norm: 512 of them stay under half an ulp
 #define RP_AFF_TILE_MIN_TILES 1024   // 32-row tiles in the batch from which rp_launch_affinity picks the tile kernel
 
@@ -342,10 +329,13 @@ __device__ __forceinline__ float rp_div100(float x) {
 __device__ __forceinline__ float4 rp_div100(float4 v) { return make_float4(rp_div100(v.x), rp_div100(v.y), rp_div100(v.z), rp_div100(v.w)); }
 __device__ __forceinline__ unsigned rp_pkrtz(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 __device__ __forceinline__ float rp_bperm_f(int byte_idx, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_idx, __float_as_int(v))); }
-__device__ __forceinline__ void rp_wave_lds_sync() {       // LDS traffic between the lanes of ONE wave (in order in hardware; keeps the compiler from reordering)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+// LDS traffic between the lanes of ONE wave: LDS operations of a wave execute in issue order, so the lanes only need the compiler to
+// keep the order -- wavefront-scope fences.  (A workgroup-scope release fence also waits for the wave's global STORES, s_waitcnt
+// vmcnt(0): with those in the write phase every staging chunk waited for the previous chunk's stores to be acknowledged.)
+__device__ __forceinline__ void rp_wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 template <int KL>
 __device__ __forceinline__ void rp_list_push(float (&te)[KL], float x) {       // sorted (descending) list of the KL largest values
@@ -353,23 +343,6 @@ __device__ __forceinline__ void rp_list_push(float (&te)[KL], float x) {       /
     te[0] = fmaxf(prev, x);
 #pragma unroll
     for (int k = 1; k < KL; ++k) { const float cur = te[k]; te[k] = __builtin_amdgcn_fmed3f(prev, cur, x); prev = cur; }
-}
-// numpy-order float32 squared distance of two 32-vectors: 8 strided partial sums + fixed tree (s in registers, t in LDS)
-__device__ __forceinline__ float rp_exact_dist(const float (&s)[RP_FEAT], const float* t) {
-    float r8[8];
-#pragma unroll
-    for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
-        const float4 tv = *reinterpret_cast<const float4*>(t + 4 * c4);
-        const float tt[4] = {tv.x, tv.y, tv.z, tv.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * c4 + k;
-            const float df = s[c] - tt[k];
-            const float sq = df * df;
-            if (c < 8) r8[c] = sq; else r8[c & 7] = r8[c & 7] + sq;
-        }
-    }
-    return ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
 }
 // RN(d / den) by Markstein's correction of d * RN(1/den), negated: the exponent of one entry
 __device__ __forceinline__ double rp_exponent(float d, double den, double rd) {
@@ -380,46 +353,108 @@ __device__ __forceinline__ double rp_exponent(float d, double den, double rd) {
     return -q;
 }
 
-template <bool WRITE_WIJ, int KL>       // KL = length of the per-lane winner lists (>= topK): 5 or RP_MAXK
-__global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(RelposeKeypoints kp, AffConsts ac, int topK, int ntp,
-                                                                          float* __restrict__ wij, int32_t* __restrict__ corres_j,
-                                                                          double* __restrict__ corres_w, int32_t* __restrict__ keff_out, int istk_cap) {
+// ---- the tile kernel (round 4: second generation) ---------------------------------------------------------------------------
+// Reorganised around what the counters of round 3's version showed (profiles/r03_affinity_pmc.txt: 2.1x the algorithmic HBM
+// traffic, VALU-issue / latency bound at 1.8 waves per SIMD):
+//  1. wij rows are written ONCE.  The first version zero-filled a wave's rows with streaming stores and then overwrote the window
+//     entries with 4-byte scatter stores: partial-line read-modify-writes (FETCH 3.4x, WRITE 1.7x the algorithmic bytes).  Here the
+//     window values of a wave are gathered first (5 items per lane, in registers), then the wave's rows go through a small LDS
+//     staging buffer, a few rows at a time -- zeros, the rows' items scattered over them, coalesced 16-byte stores of finished lines.
+//  2. The sweeps work in DISTANCE space.  The targets are staged sorted by their weight class (weight == 1 first), so that the
+//     denominator of the exponent -- which takes two values, rpmodule.py:357-359 -- is uniform per 32-target MFMA tile except for the
+//     one tile holding the class boundary; -|t|^2/2 enters the product as two extra K slots (fp16 hi + lo) of a third MFMA, so the
+//     accumulator IS g = s.t - |t|^2/2 = (|s|^2 - D)/2 and the selection is one v_cmp per entry against a per-class threshold (the first
+//     version spent two FMAs per entry and sweep on e~ = B_j (|s|^2 - 2 s.t) + A_j, three sweeps).
+//  3. ONE selection sweep and a POOLED exact evaluation.  Winners, norm-window and wij-window entries are nested sets ("e~ >= some
+//     threshold"), so one mask per lane covers them all; the candidates of the wave's rows go through a ballot-compacted queue and are
+//     evaluated 64 at a time, one per lane whatever row they belong to (exact distance only: 4 bytes per item back to LDS).  The
+//     owner lanes then rank their rows' candidates (exponent from the stored distance: 8 instructions) and evaluate exp() for the K
+//     winners only; the norm is the winners' share plus -- rarely -- the other candidates inside the norm window.
+//     (The first version ran distance + float64 exp + insertion for max-over-lanes candidates per lane: ~60 % of its instructions.)
+// A wave owns rpw <= 32 consecutive source rows, rpw chosen so that the waves of a workgroup are equally loaded (200 rows = 8 x 25;
+// the first version ran 6 full waves, one quarter-full and one idle).
+// Results: corres_j / corres_w identical in meaning to affinity_rows_kernel's (same exact arithmetic on a superset of the entries
+// that matter; the float64 norm is added up winners first), wij zeros below e^-75 of the row maximum exactly like the row kernel.
+// max(a, b) as med3(a, b, +inf): clang puts a canonicalising v_max x, x in front of every fmaxf operand that it cannot prove quiet
+// (MFMA results); v_med3 takes them as they are.  (Inline-asm v_max3 on accumulator registers is not safe: the hazard recognizer
+// does not put the MFMA-result wait states in front of inline asm.)
+__device__ __forceinline__ float rp_max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+#define AT2_CAPW 448           // candidate items per wave (25 rows x (5 winners + ~6 window entries + slack))
+#define AT2_IPL (AT2_CAPW / 64)
+#define AT2_PADG (-60000.0f)   // -|t|^2/2 of a padding target: below every threshold, finite in fp16
+
+template <bool WRITE_WIJ, int KL>
+__global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(RelposeKeypoints kp, AffConsts ac, int topK, int ntp, int rows_per_block, int rpw,
+                                                                           float* __restrict__ wij, int32_t* __restrict__ corres_j,
+                                                                           double* __restrict__ corres_w, int32_t* __restrict__ keff_out, int istk_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int NT = blockDim.x, rows_per_block = (NT >> 6) * 32;      // 2, 4 or 8 waves: small batches use smaller workgroups
+    const int NT = blockDim.x;
     const int b = blockIdx.y;
     const int ns = kp.ns[b], nt = kp.nt[b];
     const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
     if (keff == 0) return;
     if (blockIdx.x * rows_per_block >= ns) return;
-    float* ftT = (float*)smem;                                   // [ntp][AT_LDT] scaled target descriptors (float32, exact)
-    float* tab = ftT + (size_t)ntp * AT_LDT;                     // {A_j, B_j} per target: e~ = B_j (|s|^2 - 2 g) + A_j, for rows with weight 1 ...
-    const int tab_other = 2 * ntp + 16;                          // ... and for the other rows (16 floats further: other banks)
-    int* misc = (int*)(tab + 4 * ntp + 16);                      // [0] max |t|^2 (float bits), [1] pair not covered by the bound
+    float* ftT = (float*)smem;                                   // [ntp][AT_LDT] scaled target descriptors (float32, exact), class-sorted
+    unsigned* tpack = (unsigned*)(ftT + (size_t)ntp * AT_LDT);   // [ntp] fp16 {hi, lo * 1024} of -|t|^2 / 2
+    unsigned short* perm = (unsigned short*)(tpack + ntp);       // [ntp] sorted position -> target index
+    unsigned short* posof = perm + ntp;                          // [ntp] target index -> sorted position (staging only)
+    int* misc = (int*)(posof + ntp);                             // [0] max |t|^2 (float bits), [1] pair not covered by the bound, [2] class-1 targets
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, n = lane & 31;
-    unsigned short* queue = (unsigned short*)(misc + 4) + (size_t)wave * (AT_QCAP + istk_cap * 64);
-    unsigned short* istk = queue + AT_QCAP;                      // [istk_cap][64]
-    const float nrd0 = -(float)ac.rden[0], nrd1 = -(float)ac.rden[1];
-    // this lane's source row (both halves of a wave share it): its loads are issued before the staging so that their latency
-    // overlaps the target loads'
-    const int i0w = blockIdx.x * rows_per_block + wave * 32;          // first source row of this wave
+    const int wbytes = AT2_CAPW * 6 + istk_cap * 128;            // per-wave area: queue u16[CAPW] | dist f32[CAPW] | istk u16[cap][64]
+    char* warea = (char*)(misc + 4) + (size_t)wave * wbytes;
+    float* resd = (float*)warea;                                 // exact distance of item `slot`
+    unsigned short* queue = (unsigned short*)(resd + AT2_CAPW);  // item `slot` = (row slot << 9) | sorted target position
+    unsigned short* istk = queue + AT2_CAPW;                     // [istk_cap][64] slots of the lane's own candidates
+    // this lane's source row: loads issued before the staging
+    const int i0w = blockIdx.x * rows_per_block + wave * rpw;
+    const int nrows = max(0, min(min(rpw, rows_per_block - wave * rpw), ns - i0w));       // rows of this wave
     const int i = i0w + n;
-    const bool rowok = i < ns;
+    const bool rowok = n < nrows;
     const size_t si = (size_t)b * kp.ns_max + (rowok ? i : 0);
     float4 fsraw[RP_FEAT / 4];
 #pragma unroll
     for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) fsraw[c4] = rowok ? rp_ldg4(kp.feat_s + si * RP_FEAT + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const double wsi = rowok ? rp_ldg(kp.weight_s + si) : 0.0;
-    {   // ---- stage the pair's targets: descriptors / 100 (float32 division like numpy), |t|^2, the exponent tables
+    {   // ---- stage the pair's targets, sorted by weight class
+        if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+        if (wave == 0) {
+            // one wave ranks the targets: class 1 (weight == 1: the "both observed" denominator for rows of weight 1) first, in index order
+            double wt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int j = lane + 64 * k; wt[k] = (j < nt) ? rp_ldg(kp.weight_t + (size_t)b * kp.nt_max + j) : 0.0; }
+            int n1 = 0;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = lane + 64 * k;
+                n1 += __popcll(__ballot(j < nt && wt[k] == 1.0));
+                if (j < nt && !(wt[k] >= 0.0 && wt[k] <= 1.0)) bad = true;
+            }
+            int r1 = 0, r0 = n1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = lane + 64 * k;
+                const bool v = j < nt, c1 = v && wt[k] == 1.0, c0 = v && !c1;
+                const unsigned long long b1 = __ballot(c1), b0 = __ballot(c0);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int p = c1 ? r1 + __popcll(b1 & below) : r0 + __popcll(b0 & below);
+                if (v) { posof[j] = (unsigned short)p; perm[p] = (unsigned short)j; }
+                r1 += __popcll(b1); r0 += __popcll(b0);
+            }
+            for (int j = nt + lane; j < ntp; j += 64) perm[j] = (unsigned short)j;       // padding positions
+            if (lane == 0) misc[2] = n1;
+            if (bad) misc[1] = 1;
+        }
+        __syncthreads();
         const float* ftg = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
         for (int idx = tid; idx < ntp * (RP_FEAT / 4); idx += NT) {
             const int j = idx >> 3, c4 = idx & 7;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < nt) v = rp_ldg4(ftg + (size_t)j * RP_FEAT + 4 * c4);
-            *reinterpret_cast<float4*>(&ftT[j * AT_LDT + 4 * c4]) = rp_div100(v);
+            int row = j;
+            if (j < nt) { v = rp_ldg4(ftg + (size_t)j * RP_FEAT + 4 * c4); row = posof[j]; }
+            *reinterpret_cast<float4*>(&ftT[row * AT_LDT + 4 * c4]) = rp_div100(v);
         }
-        if (tid == 0) { misc[0] = 0; misc[1] = 0; }
-        const double wt_first = (tid < nt) ? rp_ldg(kp.weight_t + (size_t)b * kp.nt_max + tid) : 0.0;       // (ntp <= NT: one target per thread)
         __syncthreads();
         float mx = 0.f;
         bool bad = false;
@@ -427,112 +462,106 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
             float a = 0.f;
             for (int c = 0; c < RP_FEAT; ++c) a += ftT[j * AT_LDT + c] * ftT[j * AT_LDT + c];
             const bool ok = j < nt;
-            const double wtj = ok ? (j == tid ? wt_first : rp_ldg(kp.weight_t + (size_t)b * kp.nt_max + j)) : 0.0;
-            if (ok && (!(wtj >= 0.0 && wtj <= 1.0) || !(a < 1e8f))) bad = true;
-            const float b1 = (wtj == 1.0) ? nrd1 : nrd0;
-            tab[2 * j] = ok ? b1 * a : -INFINITY;
-            tab[2 * j + 1] = ok ? b1 : 0.f;
-            tab[tab_other + 2 * j] = ok ? nrd0 * a : -INFINITY;
-            tab[tab_other + 2 * j + 1] = ok ? nrd0 : 0.f;
+            if (ok && !(a < 1e8f)) bad = true;
+            const float g0 = ok ? -0.5f * a : AT2_PADG;
+            const _Float16 hi = (_Float16)g0;
+            const _Float16 lo = ok ? (_Float16)((g0 - (float)hi) * 1024.0f) : (_Float16)0.0f;
+            tpack[j] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
             if (ok) mx = fmaxf(mx, a);
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-        if (lane == 0) atomicMax(&misc[0], __float_as_int(mx));          // non-negative floats order like ints
+        if (lane == 0) atomicMax(&misc[0], __float_as_int(mx));
         if (bad) misc[1] = 1;
         __syncthreads();
     }
     const float ntmax = __int_as_float(misc[0]);
     const bool pair_bad = misc[1] != 0;
-    if (i0w >= ns) return;
-    // ---- the source row: all 32 scaled features (exact distances, ds_bpermute source of the flush) + the fp16 half this lane feeds to the MFMA
-    float fs[RP_FEAT];
-#pragma unroll
-    for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
-        const float4 v = rp_div100(fsraw[c4]);
-        fs[4 * c4] = v.x; fs[4 * c4 + 1] = v.y; fs[4 * c4 + 2] = v.z; fs[4 * c4 + 3] = v.w;
-    }
+    const int n1 = misc[2];                                                     // sorted positions [0, n1) are the weight-1 targets
+    if (nrows <= 0) return;
+    // ---- the source row: |s|^2 and the fp16 halves this lane feeds to the MFMAs.  The 32 exact features are NOT kept across the sweeps
+    // (with them the sweeps spill into scratch memory inside their loops): the pooled evaluation re-reads the row (L2-resident).
     float nsq = 0.f;
-#pragma unroll
-    for (int c = 0; c < RP_FEAT; ++c) nsq += fs[c] * fs[c];
-    f16x8 bf0, bf1;                                                   // B operand: features 8h .. 8h+7 and 16+8h .. 16+8h+7 of row n
+    f16x8 bf0, bf1, bfx;
     {
-        unsigned p[8];
+        float fs[RP_FEAT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            p[q] = rp_pkrtz(h ? fs[8 + 2 * q] : fs[2 * q], h ? fs[9 + 2 * q] : fs[1 + 2 * q]);
-            p[4 + q] = rp_pkrtz(h ? fs[24 + 2 * q] : fs[16 + 2 * q], h ? fs[25 + 2 * q] : fs[17 + 2 * q]);
+        for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
+            const float4 v = rp_div100(fsraw[c4]);
+            fs[4 * c4] = v.x; fs[4 * c4 + 1] = v.y; fs[4 * c4 + 2] = v.z; fs[4 * c4 + 3] = v.w;
         }
+#pragma unroll
+        for (int c = 0; c < RP_FEAT; ++c) nsq += fs[c] * fs[c];
+        // (all 16 packed pairs, then selects between VALUES: a select between fs[] elements becomes a dynamically indexed load and
+        // sends the whole array to scratch memory)
+        unsigned P[16], p[8];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) P[q] = rp_pkrtz(fs[2 * q], fs[2 * q + 1]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { p[q] = h ? P[4 + q] : P[q]; p[4 + q] = h ? P[12 + q] : P[8 + q]; }
         const u32x4 lo = {p[0], p[1], p[2], p[3]}, hi = {p[4], p[5], p[6], p[7]};
         bf0 = __builtin_bit_cast(f16x8, lo);
         bf1 = __builtin_bit_cast(f16x8, hi);
+        const u32x4 one = {h ? 0u : rp_pkrtz(1.0f, 0.0009765625f), 0u, 0u, 0u};     // K slots 0, 1 of the third MFMA: 1 and 2^-10
+        bfx = __builtin_bit_cast(f16x8, one);
     }
     const bool rowone = wsi == 1.0;
     const bool row_bad = pair_bad || !(wsi >= 0.0 && wsi <= 1.0) || !(nsq < 1e8f);
-    const float* tsel = tab + (rowone ? 0 : tab_other);
-    const int ntiles = ntp / 32;                                                // even: ntp is a multiple of 64
+    const float nrd0 = -(float)ac.rden[0], nrd1 = -(float)ac.rden[1];
+    // e~ = B D~ with D~ = |s|^2 - 2 g, B = -1/den of the entry's class: e~ = alpha g + beta
+    const float B1 = rowone ? nrd1 : nrd0, B0 = nrd0;
+    const float al1 = -2.0f * B1, be1 = B1 * nsq, al0 = -2.0f * B0, be0 = B0 * nsq;
+    const int ntiles = ntp / 32;                                                // even
+    const int tmix = (n1 & 31) ? (n1 >> 5) : -1;                                // the tile that holds the class boundary
 
-    // approximate exponents of TWO 32-target tiles for this lane's row: et[u][r] belongs to target j0 + 32 u + 8 (r >> 2) + 4 h + (r & 3)
-    auto tile_exponents = [&](int j0, float (&et)[2][16]) {
-        floatx16 acc[2];
+    // g of one 32-target tile for this lane's row: acc[r] belongs to sorted position 32 T + 8 (r >> 2) + 4 h + (r & 3)
+    auto tile_g = [&](int T) {
+        floatx16 acc;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
-            const float* row = &ftT[(j0 + 32 * u + n) * AT_LDT + 8 * h];
-            const float4 a0 = *reinterpret_cast<const float4*>(row), a1 = *reinterpret_cast<const float4*>(row + 4);
-            const float4 a2 = *reinterpret_cast<const float4*>(row + 16), a3 = *reinterpret_cast<const float4*>(row + 20);
-            const u32x4 k0 = {rp_pkrtz(a0.x, a0.y), rp_pkrtz(a0.z, a0.w), rp_pkrtz(a1.x, a1.y), rp_pkrtz(a1.z, a1.w)};
-            const u32x4 k1 = {rp_pkrtz(a2.x, a2.y), rp_pkrtz(a2.z, a2.w), rp_pkrtz(a3.x, a3.y), rp_pkrtz(a3.z, a3.w)};
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, k0), bf0, acc[u], 0, 0, 0);
-            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, k1), bf1, acc[u], 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float* tp = tsel + 2 * (j0 + 32 * u + 8 * q + 4 * h);
-                const float4 t0 = *reinterpret_cast<const float4*>(tp), t1 = *reinterpret_cast<const float4*>(tp + 4);
-                const float A[4] = {t0.x, t0.z, t1.x, t1.z}, B[4] = {t0.y, t0.w, t1.y, t1.w};
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-                    et[u][4 * q + rr] = __builtin_fmaf(B[rr], __builtin_fmaf(-2.0f, acc[u][4 * q + rr], nsq), A[rr]);
-            }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* row = &ftT[(32 * T + n) * AT_LDT + 8 * h];
+        const float4 a0 = *reinterpret_cast<const float4*>(row), a1 = *reinterpret_cast<const float4*>(row + 4);
+        const float4 a2 = *reinterpret_cast<const float4*>(row + 16), a3 = *reinterpret_cast<const float4*>(row + 20);
+        const u32x4 k0 = {rp_pkrtz(a0.x, a0.y), rp_pkrtz(a0.z, a0.w), rp_pkrtz(a1.x, a1.y), rp_pkrtz(a1.z, a1.w)};
+        const u32x4 k1 = {rp_pkrtz(a2.x, a2.y), rp_pkrtz(a2.z, a2.w), rp_pkrtz(a3.x, a3.y), rp_pkrtz(a3.z, a3.w)};
+        const u32x4 k2 = {h ? 0u : tpack[32 * T + n], 0u, 0u, 0u};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, k0), bf0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, k1), bf1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, k2), bfx, acc, 0, 0, 0);
+        return acc;
     };
-    // target index of bit `bit` of a candidate mask built by m = (m << 1) | pred over (u, r) in order
-    auto mask_target = [&](int t, int bit) { const int idx = 31 - bit, u = idx >> 4, r = idx & 15; return (t + u) * 32 + 8 * (r >> 2) + 4 * h + (r & 3); };
+    auto pos_of = [&](int T, int r) { return 32 * T + 8 * (r >> 2) + 4 * h + (r & 3); };
 
-    // zero-fill of the wave's rows of wij (ONE contiguous span: rows i0w .. i0w + 31), part `part` of `nparts`: coalesced 16-byte
-    // stores issued early (between the P1 tiles) so that the 164 MB of zeros drain while the matrix / vector pipes work
-    float* wbase = WRITE_WIJ ? wij + ((size_t)b * kp.ns_max + i0w) * kp.nt_max : nullptr;
-    const int span = min(32, ns - i0w) * kp.nt_max;                           // floats
-    const bool vec4 = (kp.nt_max & 3) == 0;                                   // span start 16-byte aligned (the buffer itself is)
-    auto zero_span = [&](int part, int nparts) {
-        if (vec4) {
-            const int n4 = span >> 2, per = (n4 + nparts - 1) / nparts, lo = part * per, hi = min(n4, lo + per);
-            for (int q = lo + lane; q < hi; q += 64) rp_stg4(wbase + 4 * q, make_float4(0.f, 0.f, 0.f, 0.f));
-        } else {
-            const int per = (span + nparts - 1) / nparts, lo = part * per, hi = min(span, lo + per);
-            for (int q = lo + lane; q < hi; q += 64) rp_stg(wbase + q, 0.f);
-        }
-    };
-
-    // ---- P1: the row maximum and the KL largest group-of-8 maxima of the half row (sorted, te[0] = max)
+    // ---- P1: the row maximum and the KL largest group-of-8 maxima of the half row, as exponents (sorted, te[0] = max)
     float te[KL];
 #pragma unroll
     for (int k = 0; k < KL; ++k) te[k] = -INFINITY;
-    for (int t = 0; t < ntiles; t += 2) {
-        float et[2][16];
-        if (WRITE_WIJ) zero_span(t >> 1, ntiles >> 1);
-        tile_exponents(t * 32, et);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
+    for (int T = 0; T < ntiles; ++T) {
+        const floatx16 g = tile_g(T);
+        float gm[2];
+        if (T != tmix) {
+            const bool c1 = 32 * T < n1;
+            const float al = c1 ? al1 : al0, be = c1 ? be1 : be0;
 #pragma unroll
             for (int g8 = 0; g8 < 2; ++g8) {
-                const float* e8 = &et[u][8 * g8];
-                const float gm = fmaxf(fmaxf(fmaxf(e8[0], e8[1]), fmaxf(e8[2], e8[3])), fmaxf(fmaxf(e8[4], e8[5]), fmaxf(e8[6], e8[7])));
-                rp_list_push<KL>(te, gm);
+                const float q0 = rp_max_nc(rp_max_nc(g[8 * g8], g[8 * g8 + 1]), rp_max_nc(g[8 * g8 + 2], g[8 * g8 + 3]));
+                const float q1 = rp_max_nc(rp_max_nc(g[8 * g8 + 4], g[8 * g8 + 5]), rp_max_nc(g[8 * g8 + 6], g[8 * g8 + 7]));
+                gm[g8] = __builtin_fmaf(al, rp_max_nc(q0, q1), be);
             }
+        } else {
+#pragma unroll
+            for (int g8 = 0; g8 < 2; ++g8) {
+                float m8 = -INFINITY;
+#pragma unroll
+                for (int r = 8 * g8; r < 8 * g8 + 8; ++r) {
+                    const bool c1 = pos_of(T, r) < n1;
+                    m8 = fmaxf(m8, __builtin_fmaf(c1 ? al1 : al0, g[r], c1 ? be1 : be0));
+                }
+                gm[g8] = m8;
+            }
+        }
+        rp_list_push<KL>(te, gm[0]);
+        rp_list_push<KL>(te, gm[1]);
     }
     {   // merge with the other half of the row (lane ^ 32)
         float ot[KL];
@@ -545,76 +574,141 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
 #pragma unroll
     for (int k = 1; k < KL; ++k) if (k == keff - 1) kth = te[k];
     const float emax_a = te[0];
-    // |e~ - e|: operands rounded toward zero to fp16 (|dx| <= 2^-10 |x| + 2^-24), products and sums in float32 on the matrix pipe:
-    // |g~ - g| <= 2^-9 (1 + 2^-10) |s||t| + 2^-24 sqrt(32) (|s| + |t|) (1 + 2^-10) + 32 2^-24 |s||t|, the distance doubles that and adds the
-    // float32 roundings of |s|^2, |t|^2 and of the two FMAs (< 6e-6 (|s|^2 + |t|^2)); 2 |s||t| <= |s|^2 + |t|^2.
+    // |e~ - e|: as in affinity_tile_kernel (fp16 operands rounded toward zero, float32 accumulation), plus the two extra K slots
+    // (|t|^2/2 to 2^-21 relative) and the float32 roundings of alpha g + beta and of the thresholds below
     const float rdmax = fmaxf(-nrd0, -nrd1);
-    const float errd = 2.1e-3f * (nsq + ntmax) + 3.5e-7f * (sqrtf(nsq) + sqrtf(ntmax));
-    const float err = errd * rdmax + 1e-6f * fmaxf(fabsf(kth), fabsf(emax_a)) + 1e-30f;
+    const float errd = 2.2e-3f * (nsq + ntmax) + 3.5e-7f * (sqrtf(nsq) + sqrtf(ntmax));
+    const float err = errd * rdmax + 4e-6f * (fmaxf(fabsf(kth), fabsf(emax_a)) + rdmax * nsq) + 1e-30f;
+    // important entries (possible winners + norm window: ranked by the row's owner lanes) and, for a materialised wij, the window
+    // entries (a value each, nothing else): nested sets, so the sweep tests the wider threshold and a candidate the narrower one
     const float thr_imp = fminf(kth, emax_a - (float)RP_AFF_NORM_WINDOW) - 2.0f * err;
-    const float thr_win = emax_a - (float)RP_AFF_WINDOW - 2.0f * err;
+    const float thr = WRITE_WIJ ? fminf(thr_imp, emax_a - (float)RP_AFF_WINDOW - 2.0f * err) : thr_imp;
     const double need_norm = (double)emax_a - RP_AFF_NORM_WINDOW - 3.0 * (double)err;
+    // the same thresholds in g: e~ >= thr  <=>  g >= (thr - beta) / alpha (alpha > 0); rows that are not rowok select nothing
+    const float tg1 = rowok ? (thr - be1) / al1 - 1e-6f * fabsf((thr - be1) / al1) : INFINITY;
+    const float tg0 = rowok ? (thr - be0) / al0 - 1e-6f * fabsf((thr - be0) / al0) : INFINITY;
+    const float ti1 = (thr_imp - be1) / al1 - 1e-6f * fabsf((thr_imp - be1) / al1);
+    const float ti0 = (thr_imp - be0) / al0 - 1e-6f * fabsf((thr_imp - be0) / al0);
 
-    // ---- P2a: important entries onto the lane's stack
-    int cnt = 0;
-    for (int t = 0; t < ntiles; t += 2) {
-        float et[2][16];
-        tile_exponents(t * 32, et);
-        unsigned m = 0;
+    // ---- pooled exact distances: items [from, from + count) of the wave's queue, one per lane
+    auto evaluate = [&](const float (&fs)[RP_FEAT], int from, int count) {
+        const bool act = lane < count;
+        const int item = act ? queue[from + lane] : 0;
+        const int pidx = (item >> 9) << 2;
+        const float* tj = &ftT[(item & 511) * AT_LDT];
+        float r8[8];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int c8 = 0; c8 < RP_FEAT / 8; ++c8) {
+            const float4 ta = *reinterpret_cast<const float4*>(tj + 8 * c8), tb = *reinterpret_cast<const float4*>(tj + 8 * c8 + 4);
+            const float tt[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = (m << 1) | (et[u][r] >= thr_imp ? 1u : 0u);
-        while (m) {
-            const int bit = __builtin_ctz(m);
-            m &= m - 1;
-            const int jc = mask_target(t, bit);
-            if (jc < nt) {
-                if (cnt < istk_cap) istk[cnt * 64 + lane] = (unsigned short)jc;
-                ++cnt;
+            for (int k = 0; k < 8; ++k) {
+                const float df = rp_bperm_f(pidx, fs[8 * c8 + k]) - tt[k];
+                const float sq = df * df;
+                if (c8 == 0) r8[k] = sq; else r8[k] = r8[k] + sq;
+            }
+            __builtin_amdgcn_sched_barrier(0);                                  // (8 gathers in flight, not 32: registers)
+        }
+        const float d = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+        if (act) resd[from + lane] = d;
+    };
+
+    // ---- P2: ONE selection sweep; candidates through the wave's queue, evaluated 64 at a time
+    int cnt = 0, qtot = 0;                                                      // qtot: wave-uniform
+    bool over = false;
+    for (int T = 0; T < ntiles; T += 2) {
+        unsigned m = 0, mi = 0;                                                 // candidates / the important ones among them
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const floatx16 g = tile_g(T + u);
+            if (T + u != tmix) {
+                // g >= t  <=>  the sign bit of g - t is clear (g, t finite; -0 cannot come out of x - y with x != y ... and x == y gives +0):
+                // one packed subtraction per two entries and one v_alignbit per entry ({m, d} >> 31 = (m << 1) | sign(d)) -- a v_cmp +
+                // v_cndmask + shift / or chain through VCC is 3 instructions and a hazard nop per entry.  m collects the "below" bits.
+                const bool c1 = 32 * (T + u) < n1;
+                const float tg = c1 ? tg1 : tg0, ti = c1 ? ti1 : ti0;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const rp_v2f d = (rp_v2f){g[r], g[r + 1]} - (rp_v2f){tg, tg};
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(d.x), 31);
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(d.y), 31);
+                }
+                if (WRITE_WIJ) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const rp_v2f d = (rp_v2f){g[r], g[r + 1]} - (rp_v2f){ti, ti};
+                        mi = __builtin_amdgcn_alignbit(mi, __float_as_uint(d.x), 31);
+                        mi = __builtin_amdgcn_alignbit(mi, __float_as_uint(d.y), 31);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool c1 = pos_of(T + u, r) < n1;
+                    m = (m << 1) | (g[r] >= (c1 ? tg1 : tg0) ? 0u : 1u);
+                    if (WRITE_WIJ) mi = (mi << 1) | (g[r] >= (c1 ? ti1 : ti0) ? 0u : 1u);
+                }
             }
         }
+        m = ~m;                                                                 // candidates = not below
+        mi = WRITE_WIJ ? ~mi : m;
+        while (__ballot(m != 0)) {
+            int jc = INT_MAX;
+            bool imp = false;
+            if (m) { const int bit = __builtin_ctz(m); m &= m - 1; imp = (mi >> bit) & 1u; const int idx = 31 - bit; jc = pos_of(T + (idx >> 4), idx & 15); }
+            const bool push = jc < nt;
+            const unsigned long long bm = __ballot(push);
+            const int slot = qtot + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+            if (push) {
+                if (slot < AT2_CAPW) queue[slot] = (unsigned short)((n << 9) | jc);
+                else over = true;
+                if (imp) {
+                    if (slot < AT2_CAPW && cnt < istk_cap) istk[cnt * 64 + lane] = (unsigned short)slot; else over = true;
+                    ++cnt;
+                }
+            }
+            qtot = min(qtot + __popcll(bm), AT2_CAPW);
+        }
     }
-    const bool over = cnt > istk_cap;
-    const int ncand = min(cnt, istk_cap);
+    rp_wave_lds_order();
+    {   // the exact distances of the queued candidates, 64 at a time, one per lane whatever row they belong to
+        float fs[RP_FEAT];
+        long long soff = (long long)(si * RP_FEAT);
+        asm volatile("" : "+v"(soff));                                          // (a second load the compiler cannot merge with the first)
+#pragma unroll
+        for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
+            const float4 v = rp_div100(rowok ? rp_ldg4(kp.feat_s + soff + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f));
+            fs[4 * c4] = v.x; fs[4 * c4 + 1] = v.y; fs[4 * c4 + 2] = v.z; fs[4 * c4 + 3] = v.w;
+        }
+        for (int from = 0; from < qtot; from += 64) evaluate(fs, from, min(64, qtot - from));
+    }
+    rp_wave_lds_order();
+    const int ncand = over ? 0 : cnt;
 
-    // ---- exact treatment of the important entries: sorted list of the KL best by (e descending, j ascending), norm
+    // ---- the owner lanes rank their candidates: sorted list of the KL best by (e descending, target index ascending)
     double le[KL];
     int lj[KL];
 #pragma unroll
     for (int k = 0; k < KL; ++k) { le[k] = -INFINITY; lj[k] = INT_MAX; }
-    double sumsq = 0.0;
-    {
-        constexpr int IL = 1;                                 // entries per trip (2 gives the scheduler independent chains but spills at 128 VGPRs)
-        for (int c = 0; __ballot(c < ncand); c += IL) {
-            double ev[IL];
-            int jv[IL];
+    int nnorm = 0;                                                              // own candidates inside the norm window
+    for (int c = 0; __ballot(c < ncand); ++c) {
+        const bool v = c < ncand;
+        const int slot = v ? istk[c * 64 + lane] : 0;
+        const int jp = queue[slot] & 511;
+        const bool cls = rowone && jp < n1;
+        double e = rp_exponent(resd[slot], cls ? ac.den[1] : ac.den[0], cls ? ac.rden[1] : ac.rden[0]);
+        int jj = v ? (int)perm[jp] : INT_MAX;
+        if (!v) e = -INFINITY;
+        nnorm += (e >= need_norm) ? 1 : 0;
 #pragma unroll
-            for (int q = 0; q < IL; ++q) {
-                const bool v = c + q < ncand;
-                const int j = v ? istk[(c + q) * 64 + lane] : 0;
-                const float d = rp_exact_dist(fs, &ftT[j * AT_LDT]);
-                const bool cls = rowone && (tab[2 * j + 1] == nrd1);
-                const double e = rp_exponent(d, cls ? ac.den[1] : ac.den[0], cls ? ac.rden[1] : ac.rden[0]);
-                ev[q] = v ? e : -INFINITY;
-                jv[q] = v ? j : INT_MAX;
-            }
-#pragma unroll
-            for (int q = 0; q < IL; ++q) {
-                double e = ev[q];
-                int jj = jv[q];
-                if (__ballot(e >= need_norm)) { const double w = exp(e); if (e >= need_norm) sumsq += w * w; }
-#pragma unroll
-                for (int k = 0; k < KL; ++k) {    // insert (e, jj) into the sorted list (an empty entry, (-inf, INT_MAX), never displaces anything)
-                    const bool better = (e > le[k]) || (e == le[k] && jj < lj[k]);
-                    const double te_ = le[k]; const int tj_ = lj[k];
-                    le[k] = better ? e : te_; lj[k] = better ? jj : tj_;
-                    e = better ? te_ : e; jj = better ? tj_ : jj;
-                }
-            }
+        for (int k = 0; k < KL; ++k) {
+            const bool better = (e > le[k]) || (e == le[k] && jj < lj[k]);
+            const double te_ = le[k]; const int tj_ = lj[k];
+            le[k] = better ? e : te_; lj[k] = better ? jj : tj_;
+            e = better ? te_ : e; jj = better ? tj_ : jj;
         }
     }
-    {   // merge the two halves of the row: the partner's list, the partner's share of the norm, the partner's overflow flag
+    {   // merge the two halves of the row
         double oe[KL]; int oj[KL];
 #pragma unroll
         for (int k = 0; k < KL; ++k) { oe[k] = rp_shfl_xor_d(le[k], 32); oj[k] = __shfl_xor(lj[k], 32, 64); }
@@ -630,87 +724,115 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
             }
         }
     }
-    // fixed order: (half 0) + (half 1)
-    const double s_other = rp_shfl_xor_d(sumsq, 32);
-    const double nm = sqrt(h == 0 ? sumsq + s_other : s_other + sumsq);
-    const int partner_over = __shfl_xor((int)over, 32, 64);       // unconditionally: a short-circuited shuffle would read inactive lanes
+    // exp() of the winners; the norm = the winners inside the norm window, in rank order ...
+    // (both lanes of a row hold the same list: half 0 evaluates the even ranks, half 1 the odd ones, then they swap)
+    double lw[KL];
+    double sumsq = 0.0;
+    int inlist = 0;
+    {
+        constexpr int KH = (KL + 1) / 2;
+        double wh[KH];
+#pragma unroll
+        for (int q = 0; q < KH; ++q) {
+            const int k0 = 2 * q, k1 = (2 * q + 1 < KL) ? 2 * q + 1 : 2 * q;
+            wh[q] = exp(h ? le[k1] : le[k0]);                                   // (exp(-inf) = 0 for an empty entry)
+        }
+#pragma unroll
+        for (int q = 0; q < KH; ++q) {
+            const double wo = rp_shfl_xor_d(wh[q], 32);
+            lw[2 * q] = h ? wo : wh[q];
+            if (2 * q + 1 < KL) lw[2 * q + 1] = h ? wh[q] : wo;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KL; ++k)
+        if (le[k] >= need_norm) { sumsq += lw[k] * lw[k]; ++inlist; }
+    // ... plus, rarely, candidates inside the norm window that are not among the KL best: half 0's first, then half 1's, in queue order
+    const int nrow_norm = nnorm + __shfl_xor(nnorm, 32, 64);
+    if (__ballot(nrow_norm > inlist)) {
+        double extra = 0.0;
+        const double elast = le[KL - 1]; const int jlast = lj[KL - 1];
+        for (int c = 0; __ballot(c < ncand && nrow_norm > inlist); ++c) {
+            const bool v = c < ncand && nrow_norm > inlist;
+            const int slot = v ? istk[c * 64 + lane] : 0;
+            const int jp = queue[slot] & 511;
+            const bool cls = rowone && jp < n1;
+            const double e = rp_exponent(resd[slot], cls ? ac.den[1] : ac.den[0], cls ? ac.rden[1] : ac.rden[0]);
+            const int jj = (int)perm[jp];
+            const bool want = v && e >= need_norm && ((e < elast) || (e == elast && jj > jlast));
+            if (__ballot(want)) { const double w = exp(e); if (want) extra += w * w; }
+        }
+        const double xo = rp_shfl_xor_d(extra, 32);
+        sumsq += (h == 0) ? extra + xo : xo + extra;
+    }
+    const double nm = sqrt(sumsq);
+    const int partner_over = __shfl_xor((int)over, 32, 64);
     const bool redo = over || partner_over != 0 || row_bad;
-    if (rowok && h == 0) {
-        if (redo) corres_j[si * topK] = RP_AFF_REDO;
+    if (rowok) {       // half h writes the ranks k with k & 1 == h (the float64 divisions are the cost here)
+        if (redo) { if (h == 0) corres_j[si * topK] = RP_AFF_REDO; }
         else {
 #pragma unroll
-            for (int k = 0; k < KL; ++k) {
-                if (k < keff) {
-                    const bool ok = lj[k] >= 0 && lj[k] < nt;
-                    corres_j[si * topK + k] = ok ? lj[k] : 0;
-                    corres_w[si * topK + k] = (ok && nm != 0.0) ? exp(le[k]) / nm : 0.0;
+            for (int q = 0; q < (KL + 1) / 2; ++q) {
+                const int k = 2 * q + h;
+                const int jk = (2 * q + 1 < KL) ? (h ? lj[2 * q + 1] : lj[2 * q]) : lj[2 * q];
+                const double wk = (2 * q + 1 < KL) ? (h ? lw[2 * q + 1] : lw[2 * q]) : lw[2 * q];
+                if (k < keff && k < KL) {
+                    const bool ok = jk >= 0 && jk < nt;
+                    corres_j[si * topK + k] = ok ? jk : 0;
+                    corres_w[si * topK + k] = (ok && nm != 0.0) ? wk / nm : 0.0;
                 }
             }
         }
     }
     if (!WRITE_WIJ) return;
 
-    // ---- the window entries of the wave's 32 rows, evaluated 64 at a time, one per lane whatever row they belong to
-    const double rsd = (nm > 0.0) ? exp((double)emax_a) / nm : 0.0;          // wij = exp(e - max~) * exp(max~) / norm
-    const float rsf = redo ? 0.f : (float)rsd;                                 // (rows to be redone get zeros here, the fix-up kernel rewrites them)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the zero-fill stores of this wave have landed: same-address order
-    auto flush = [&](int base, int nitems, int mask) {
-        rp_wave_lds_sync();
-        const bool act = lane < nitems;
-        const int item = act ? queue[(base + lane) & mask] : 0;
-        const int rown = item >> 9, j = item & 511, pidx = rown << 2;
-        const float em_i = rp_bperm_f(pidx, emax_a), rs_i = rp_bperm_f(pidx, rsf);
+    // ---- window values: item slot = lane + 64 q -> (row, target, wij) in registers; wij = exp(e - e_max) * (exp(e_max) / norm)
+    const float rsf = (redo || !(nm > 0.0)) ? 0.f : (float)(lw[0] / nm);
+    const double emx = le[0];
+    int it_rj[AT2_IPL];
+    float it_v[AT2_IPL];
+#pragma unroll
+    for (int q = 0; q < AT2_IPL; ++q) {
+        const int slot = lane + 64 * q;
+        const bool act = slot < qtot;
+        const int item = act ? queue[slot] : 0;
+        const int rown = item >> 9, jp = item & 511, pidx = rown << 2;
+        const float rs_i = rp_bperm_f(pidx, rsf);
         const int one_i = __builtin_amdgcn_ds_bpermute(pidx, rowone ? 1 : 0);
-        float d;
-        {   // numpy-order distance, the source row gathered from its owner lane 8 features at a time
-            const float* tj = &ftT[j * AT_LDT];
-            float r8[8];
-#pragma unroll
-            for (int c8 = 0; c8 < RP_FEAT / 8; ++c8) {
-                const float4 ta = *reinterpret_cast<const float4*>(tj + 8 * c8), tb = *reinterpret_cast<const float4*>(tj + 8 * c8 + 4);
-                const float tt[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float df = rp_bperm_f(pidx, fs[8 * c8 + k]) - tt[k];
-                    const float sq = df * df;
-                    if (c8 == 0) r8[k] = sq; else r8[k] = r8[k] + sq;
-                }
-            }
-            d = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-        }
-        const bool cls = one_i && (tab[2 * j + 1] == nrd1);
-        const double x = rp_exponent(d, cls ? ac.den[1] : ac.den[0], cls ? ac.rden[1] : ac.rden[0]) - (double)em_i;
-        // exp(x) * rs in float32: 2^(x log2 e) = 2^nr * 2^fr with |fr| <= 1/2 on the float32 exp2 unit (x <= 2 err, >= -(window + 4 err))
+        const double em_i = __hiloint2double(__builtin_amdgcn_ds_bpermute(pidx, __double2hiint(emx)), __builtin_amdgcn_ds_bpermute(pidx, __double2loint(emx)));
+        const bool cls = one_i && jp < n1;
+        const double x = rp_exponent(act ? resd[slot] : 0.f, cls ? ac.den[1] : ac.den[0], cls ? ac.rden[1] : ac.rden[0]) - em_i;
         const double tl = x * 1.4426950408889634;
         const double nr = __builtin_rint(tl);
         const float p2 = __builtin_amdgcn_exp2f((float)(tl - nr));
         float val = ldexpf(p2 * rs_i, (int)fmax(nr, -300.0));
-        if (!(x >= -200.0)) val = 0.f;
-        if (act) rp_stg(wbase + (size_t)rown * kp.nt_max + j, val);
-    };
-    // ---- P2b: third sweep: window entries through the wave's ring (ballot compaction), flushed 64 at a time
-    int qhead = 0, qn = 0;                                                     // wave-uniform ring state
-    for (int t = 0; t < ntiles; t += 2) {
-        float et[2][16];
-        tile_exponents(t * 32, et);
-        unsigned mw = 0;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mw = (mw << 1) | (et[u][r] >= thr_win ? 1u : 0u);
-        if (!rowok || redo) mw = 0;
-        while (__ballot(mw != 0)) {
-            int jc = INT_MAX;
-            if (mw) { const int bit = __builtin_ctz(mw); mw &= mw - 1; jc = mask_target(t, bit); }
-            const bool push = jc < nt;
-            const unsigned long long bm = __ballot(push);
-            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
-            if (push) queue[(qhead + qn + pos) & 127] = (unsigned short)((n << 9) | jc);
-            qn += __popcll(bm);
-            if (qn >= 64) { flush(qhead, 64, 127); qhead = (qhead + 64) & 127; qn -= 64; }
-        }
+        if (!(x >= -RP_AFF_WINDOW && x <= 0.0)) val = 0.f;                      // exact zeros below the window, like affinity_rows_kernel (and for rows without a list)
+        it_rj[q] = act ? ((rown << 9) | (int)perm[jp]) : -1;
+        it_v[q] = val;
     }
-    if (qn) flush(qhead, qn, 127);
+    rp_wave_lds_order();                                                         // every lane has its items: the wave's LDS area becomes the staging buffer
+    // ---- the wave's rows, a few at a time: zeros, the rows' items over them, coalesced stores of the finished lines
+    float* stage = (float*)warea;
+    float* wbase = wij + ((size_t)b * kp.ns_max + i0w) * kp.nt_max;
+    const int ntm = kp.nt_max;
+    const int crow = max(1, min(nrows, (wbytes / 4) / ntm));                    // rows per chunk
+    const bool vec4 = (ntm & 3) == 0;
+    for (int r0 = 0; r0 < nrows; r0 += crow) {
+        const int rows = min(crow, nrows - r0), nfl = rows * ntm;
+        if (vec4) for (int q4 = lane; q4 < (nfl >> 2); q4 += 64) *reinterpret_cast<float4*>(stage + 4 * q4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (int q1 = lane; q1 < nfl; q1 += 64) stage[q1] = 0.f;
+        rp_wave_lds_order();
+#pragma unroll
+        for (int q = 0; q < AT2_IPL; ++q) {
+            const int rr = (it_rj[q] >> 9) - r0;
+            if (it_rj[q] >= 0 && rr >= 0 && rr < rows) stage[rr * ntm + (it_rj[q] & 511)] = it_v[q];
+        }
+        rp_wave_lds_order();
+        float* dst = wbase + (size_t)r0 * ntm;
+        if (vec4) for (int q4 = lane; q4 < (nfl >> 2); q4 += 64) rp_stg4(dst + 4 * q4, *reinterpret_cast<const float4*>(stage + 4 * q4));
+        else for (int q1 = lane; q1 < nfl; q1 += 64) rp_stg(dst + q1, stage[q1]);
+        rp_wave_lds_order();
+    }
 }
 
 template <int TP>
@@ -746,28 +868,29 @@ int rp_launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float
         const long long tiles32 = (long long)kp.B * ((kp.ns_max + 31) / 32);
         const bool use_tile = sel == 2 || (sel == 0 && tiles32 >= RP_AFF_TILE_MIN_TILES);
         if (use_tile) {
-            // tile kernel + (normally idle) exact redo of the rows it marked
+            // second-generation tile kernel + (normally idle) exact redo of the rows it marked
             const int ntp = (kp.nt_max + 63) & ~63;
-            // waves (32-row tiles) per workgroup: 8 when the batch fills the chip anyway, fewer for small batches (the per-workgroup
-            // target staging is then paid more often, but more CUs work)
             const int atw = tiles32 >= 4096 ? AT_WAVES : (tiles32 >= 1024 ? 4 : 2);
-            const int istk_cap = ntp <= 256 ? AT_ISTK : 24;          // (more than 256 targets: one workgroup per CU anyway)
-            const size_t lds = (size_t)ntp * AT_LDT * 4 + ((size_t)4 * ntp + 16) * 4 + 16 + (size_t)atw * (AT_QCAP + istk_cap * 64) * 2;
-            dim3 grid((kp.ns_max + atw * 32 - 1) / (atw * 32), kp.B);
-#define RP_TILE_LAUNCH(W_, KL_)                                                                                                       \
+            const int istk_cap = ntp <= 256 ? AT_ISTK : 24;
+            // rows: blocks of <= 32 atw rows, equally loaded; inside a block every wave takes rpw consecutive rows
+            const int nblk = (kp.ns_max + atw * 32 - 1) / (atw * 32);
+            const int rb = (kp.ns_max + nblk - 1) / nblk, rpw = (rb + atw - 1) / atw;
+            const size_t lds = (size_t)ntp * (AT_LDT * 4 + 8) + 16 + (size_t)atw * (AT2_CAPW * 6 + istk_cap * 128);
+            dim3 grid(nblk, kp.B);
+#define RP_TILE2_LAUNCH(W_, KL_)                                                                                                      \
             {                                                                                                                          \
                 RP_HIP(hipFuncSetAttribute((const void*)affinity_tile_kernel<W_, KL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                hipLaunchKernelGGL((affinity_tile_kernel<W_, KL_>), grid, dim3(atw * 64), lds, s, kp, ac, p.topK, ntp, wij, cj, cw, keff, istk_cap); \
+                hipLaunchKernelGGL((affinity_tile_kernel<W_, KL_>), grid, dim3(atw * 64), lds, s, kp, ac, p.topK, ntp, rb, rpw, wij, cj, cw, keff, istk_cap); \
             }
-            if (wij) { if (p.topK <= 5) RP_TILE_LAUNCH(true, 5) else RP_TILE_LAUNCH(true, RP_MAXK) }
-            else { if (p.topK <= 5) RP_TILE_LAUNCH(false, 5) else RP_TILE_LAUNCH(false, RP_MAXK) }
-#undef RP_TILE_LAUNCH
+            if (wij) { if (p.topK <= 5) RP_TILE2_LAUNCH(true, 5) else RP_TILE2_LAUNCH(true, RP_MAXK) }
+            else { if (p.topK <= 5) RP_TILE2_LAUNCH(false, 5) else RP_TILE2_LAUNCH(false, RP_MAXK) }
+#undef RP_TILE2_LAUNCH
             RP_CHECK_LAUNCH();
-            const int rpw = 32;
-            dim3 grid2((kp.ns_max + 4 * rpw - 1) / (4 * rpw), kp.B);
+            const int rpw2 = 32;
+            dim3 grid2((kp.ns_max + 4 * rpw2 - 1) / (4 * rpw2), kp.B);
 #define RP_FIXUP_LAUNCH(TP_)                                                                                                             \
-            if (wij) hipLaunchKernelGGL((affinity_rows_kernel<TP_, true, true>), grid2, dim3(256), 0, s, kp, ac, p.topK, rpw, wij, cj, cw, keff);   \
-            else hipLaunchKernelGGL((affinity_rows_kernel<TP_, false, true>), grid2, dim3(256), 0, s, kp, ac, p.topK, rpw, wij, cj, cw, keff);
+            if (wij) hipLaunchKernelGGL((affinity_rows_kernel<TP_, true, true>), grid2, dim3(256), 0, s, kp, ac, p.topK, rpw2, wij, cj, cw, keff);   \
+            else hipLaunchKernelGGL((affinity_rows_kernel<TP_, false, true>), grid2, dim3(256), 0, s, kp, ac, p.topK, rpw2, wij, cj, cw, keff);
             switch (tp) {
                 case 1: RP_FIXUP_LAUNCH(1) break;
                 case 2: RP_FIXUP_LAUNCH(2) break;

@@ -26,8 +26,9 @@ def device_asm(tmp_path_factory):
     out = {}
     for src, extra in B.SOURCES:
         s = d / (src[:-4] + ".s")
-        subprocess.check_call([HIPCC, f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", *extra, "--cuda-device-only", "-S", "-o", str(s),
-                               os.path.join(B.CSRC, src)], stderr=subprocess.DEVNULL)
+        # -fno-discard-value-names: release clang drops IR value names, and FixIrreducible's blocks would print as %bb.N instead of irr.guard
+        subprocess.check_call([HIPCC, f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", *extra, "--cuda-device-only", "-fno-discard-value-names", "-S",
+                               "-o", str(s), os.path.join(B.CSRC, src)], stderr=subprocess.DEVNULL)
         out[src] = s.read_text()
     shutil.rmtree(d, ignore_errors=True)
     return out
@@ -36,9 +37,38 @@ def device_asm(tmp_path_factory):
 def _kernels(txt):
     """kernel name -> {vgpr_count, vgpr_spill_count, ...} from the amdhsa metadata of an assembly listing"""
     res = {}
-    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", txt, re.S):
+    # (the kernel-level .name is directly followed by .private_segment_fixed_size; with value names kept, arguments have .name entries too)
+    for m in re.finditer(r"\.name:\s+(\S+)\n(\s+\.private_segment_fixed_size:.*?)\.wavefront_size", txt, re.S):
         res[m.group(1)] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", m.group(2))}
     return res
+
+
+IRREDUCIBLE_KERNEL = r"""
+#include <hip/hip_runtime.h>
+// two entries into the cycle {L1, L2}: an irreducible loop (positive control of the check below)
+extern "C" __global__ void irreducible_control(int* p, int n) {
+    int i = threadIdx.x;
+    if (p[i & 3] > 0) goto L2;
+L1:
+    i += p[i & 7];
+    __syncthreads();
+L2:
+    i += 3;
+    p[i & 15] = i;
+    if (i < n) goto L1;
+}
+"""
+
+
+def test_irreducible_control_flow_check_can_fail(tmp_path):
+    """Positive control: a kernel with a known irreducible loop must trip the marker the next test greps for (without
+    -fno-discard-value-names the marker never appears and that test could not fail: ADVICE r3)."""
+    src = tmp_path / "irr.hip"
+    src.write_text(IRREDUCIBLE_KERNEL)
+    out = tmp_path / "irr.s"
+    subprocess.check_call([HIPCC, f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "--cuda-device-only", "-fno-discard-value-names", "-S",
+                           "-o", str(out), str(src)], stderr=subprocess.DEVNULL)
+    assert "irr.guard" in out.read_text()
 
 
 def test_no_kernel_has_irreducible_control_flow(device_asm):
@@ -68,6 +98,10 @@ def test_headline_kernels_keep_their_register_budget(device_asm):
             assert k[n]["vgpr_spill_count"] == 0, (n, k[n])
     for n in find("fit_pair_kernelILi1024E") + find("affinity_tile_kernel"):
         assert k[n]["vgpr_count"] <= 128, (n, k[n])
+    # the affinity tile kernel neither spills nor keeps an array in scratch memory (round 4: a select between elements of the source-row
+    # array had turned into a dynamically indexed load and sent the whole array to scratch, re-read in every pooled evaluation)
+    for n in find("affinity_tile_kernel"):
+        assert k[n]["vgpr_spill_count"] == 0 and k[n]["private_segment_fixed_size"] == 0, (n, k[n])
     # three workgroups of the fp32 tile kernels per CU: <= 168 VGPRs
     for parts in spill_free[:6]:
         for n in find(*parts):

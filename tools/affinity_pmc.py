@@ -13,6 +13,9 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 Ns = [int(a) for a in sys.argv[3:]] or [200, 400]
 dev = torch.device("cuda", 0)
 para = rpmodule.opts(*FINAL_PARAMS["suncg"][0])
+if os.environ.get("RELPOSE_AFF_SEL"):          # A/B: force a kernel variant (relpose_set_tuning) for the whole run
+    from relativepose_amd import _lib
+    _lib.lib().relpose_set_tuning(_lib.TUNE_KEYS["affinity_kernel"], _lib.AFFINITY_KERNELS[os.environ["RELPOSE_AFF_SEL"]])
 for N in Ns:
     base = [synth.make_match_case(N, 5000 + b)[:2] for b in range(32)]
     kp = rpmodule.pack_keypoints([base[i % 32] for i in range(B)], dev)
