@@ -113,7 +113,13 @@ typedef struct RelposeMatchDebug {
 } RelposeMatchDebug;
 
 /* max_edges = capacity, per pair, of the symmetric pair-compatibility graph
- * (2 x surviving pairs); 0 = worst case ns_max*topK*(ns_max*topK-1). */
+ * (2 x surviving pairs); 0 = worst case ns_max*topK*(ns_max*topK-1).
+ * LIMITS (the reference has none; its largest shipped configuration uses 400 keypoints per view): ns_max * topK <=
+ * RELPOSE_MAX_CORRESPONDENCES (the pair-consistency kernels keep a row's correspondence list in LDS) and nt_max <= RELPOSE_MAX_TARGETS
+ * (beyond 512 targets the affinity kernel keeps all target descriptors of a pair in LDS).  Outside them
+ * relpose_match_workspace_bytes returns 0 and relpose_match_pairs / relpose_affinity_topk RELPOSE_EINVAL. */
+#define RELPOSE_MAX_CORRESPONDENCES 8192
+#define RELPOSE_MAX_TARGETS 1152
 size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, int32_t topK, int64_t max_edges);
 
 /* Replaces RelativePoseEstimation_helper (RPModule/rpmodule.py:317-508) for a

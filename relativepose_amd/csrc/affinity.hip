@@ -910,7 +910,7 @@ int rp_launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float
     }
     const int ntp = (kp.nt_max + 63) & ~63;
     const size_t lds = (size_t)ntp * 8 + (size_t)RP_FEAT * (ntp + 1) * 4;
-    if (lds > 160 * 1024) return RELPOSE_EINVAL;
+    if (lds > 160 * 1024 || kp.nt_max > RELPOSE_MAX_TARGETS) return RELPOSE_EINVAL;      // (RELPOSE_MAX_TARGETS = what fits: 1152 x 136 B + 128 B < 160 KB)
     const int rows = 8;
     dim3 grid((kp.ns_max + rows - 1) / rows, kp.B);
     if (wij) {

@@ -549,7 +549,9 @@ __device__ __forceinline__ void fit_work_loop(const Fit1& f, rp_u64 word, int* s
                     // leader: every chunk is claimed; wait until the nchunks - 1 claimed ones are counted done
                     if (rp_ld_sc1(&f.ctl->done) == ((word >> 40 << 40) | (rp_u64)(nchunks - 1))) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if ((long long)__builtin_readcyclecounter() - t0 > (1ll << 32)) break;      // (~2 s: a claimed chunk always completes; never a hang)
+                    // ~2 s without the claimed chunks being counted: never a hang -- and never a silently wrong product either: -2 makes the
+                    // leader redo every chunk itself (below) and finish the fit without helpers
+                    if ((long long)__builtin_readcyclecounter() - t0 > (1ll << 32)) { got = -2; break; }
                 }
             }
             *s_chunk = got;
@@ -557,6 +559,16 @@ __device__ __forceinline__ void fit_work_loop(const Fit1& f, rp_u64 word, int* s
         if (it == 0) loader();
         __syncthreads();
         const int ch = __builtin_amdgcn_readfirstlane(*s_chunk);
+        if (LEADER && ch == -2) {
+            // A claimed chunk was not counted in time (its workgroup descheduled, or lost): entries of part2 may be stale.  A partial sum
+            // belongs to its segment, not to whoever computed it, so the leader recomputes every chunk but its own chunk 0 -- a late helper
+            // storing the same values over them is harmless -- tells the helpers to leave and runs the remaining products alone (they
+            // use `part`, which no helper ever writes; a late bump of ctl->done is never read again).
+            for (int sgm = rp_fit_chunk_begin(1, csz) + threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<1, DEPTH, true>(f, sgm, 0.0, false);
+            rp_drain_stores();
+            if (threadIdx.x == 0) { f.epoch[3] = 1; rp_st_sc1(&f.ctl->claim, (rp_u64)RP_FIT_DONE << 40); }
+            break;
+        }
         if (ch < 0) break;
         const int s0 = rp_fit_chunk_begin(ch, csz), s1 = min(f.nseg, rp_fit_chunk_begin(ch + 1, csz));
         for (int sgm = s0 + threadIdx.x; sgm < s1; sgm += blockDim.x) seg_body<1, DEPTH, true>(f, sgm, 0.0, false);
@@ -695,7 +707,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
         bool done = false;
         for (int j = 0; j < RP_LZ_M && !done; ++j) {
             long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
-            if (f.G > 1) fit_dist_product<DEPTH>(f, f.yy, (int*)(f.epoch + 2));               // yy = A v_j with the helper workgroups
+            if (f.G > 1 && f.epoch[3] == 0) fit_dist_product<DEPTH>(f, f.yy, (int*)(f.epoch + 2));     // yy = A v_j with the helper workgroups
             else seg_pass<1, DEPTH>(f, f.yy, mu_xe, false);                                // yy = A v_j   (barriers inside)
             ++nprod;
             long long t1_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -938,7 +950,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     __shared__ double red[160];
     __shared__ double Rt[12];
     __shared__ int st_s;
-    __shared__ unsigned cl_s[3];        // helper-workgroup protocol: leader [0] products / [1] h versions published; helper [0] / [1] the control word as polled (high / low half); [2] claimed chunk
+    __shared__ unsigned cl_s[4];        // helper-workgroup protocol: leader [0] products / [1] h versions published; helper [0] / [1] the control word as polled (high / low half); [2] claimed chunk; leader [3] helpers given up on (a claimed chunk did not arrive in time)
     constexpr int DEPTH = 2;            // (4 = the whole segment in flight: measured 13 % slower at 512 threads, spills at 1024)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int G = gridDim.x;            // workgroups per scan pair: 1 leader + G - 1 helpers for the matrix-vector products
@@ -983,7 +995,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
         }
         return;
     }
-    if (tid == 0) { cl_s[0] = 0; cl_s[1] = 0; }
+    if (tid == 0) { cl_s[0] = 0; cl_s[1] = 0; cl_s[3] = 0; }
     if (tid == 0) {
         int st = status[b];
         if (st == RELPOSE_OK && g.counters[b * 4 + 2] < 1) st = RELPOSE_ZERO_WEIGHT;
@@ -1093,7 +1105,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
 }
 
 bool kp_ok(const RelposeKeypoints* kp, const RelposeParams* p) {
-    return kp && p && kp->B > 0 && kp->ns_max > 0 && kp->nt_max > 0 && kp->nt_max <= 4096 && p->topK >= 1 && p->topK <= RP_MAXK &&
+    return kp && p && kp->B > 0 && kp->ns_max > 0 && kp->nt_max > 0 && kp->nt_max <= RELPOSE_MAX_TARGETS && p->topK >= 1 && p->topK <= RP_MAXK &&
            kp->ns && kp->nt && kp->pc_s && kp->pc_t && kp->normal_s && kp->normal_t && kp->feat_s && kp->feat_t &&
            kp->weight_s && kp->weight_t;
 }
@@ -1104,7 +1116,7 @@ static bool fit_in_lds(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && g_rp_tune[
 static size_t fit_lds_bytes(int32_t Cmax, bool in_lds) {
     return (size_t)(5 * (RP_LZ_M + 1)) * 8 + 16 + (in_lds ? (size_t)Cmax * 24 + (size_t)(Cmax + 1) * 8 : 0);
 }
-#define RP_MAX_CORRES 8192      // correspondences per pair (ns_max * topK): the fill kernel's row lists are uint16 in 8 * Cmax bytes of LDS
+#define RP_MAX_CORRES RELPOSE_MAX_CORRESPONDENCES      // correspondences per pair (ns_max * topK): the fill kernel's row lists are uint16 in 8 * Cmax bytes of LDS
 
 struct WsLayout {
     size_t corres_j, corres_w, keff, bitmap, upcnt, counters, rowptr, col, wv, xe, state, geo, lz, gvec, segptr, segrow, part, ctl, xu, total;
@@ -1170,7 +1182,7 @@ void relpose_default_params(RelposeParams* p) {
 const char* relpose_version(void) { return "relpose-hip 0.1 (gfx950)"; }
 
 size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, int32_t topK, int64_t max_edges) {
-    (void)nt_max;
+    if (nt_max > RELPOSE_MAX_TARGETS) return 0;
     if (B <= 0 || ns_max <= 0 || topK < 1 || topK > RP_MAXK || (int64_t)ns_max * topK > RP_MAX_CORRES) return 0;
     return ws_layout(B, ns_max, topK, max_edges).total;
 }
@@ -1211,6 +1223,9 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     RP_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_scan_kernel, dim3(kp->B), dim3(1024), 0, s, *kp, g, status);
     RP_CHECK_LAUNCH();
+    // (at the capacity limit the row lists are exactly 64 KB of dynamic LDS, the default cap: raise it explicitly)
+    if ((size_t)4 * L.Cmax * sizeof(unsigned short) > 48 * 1024)
+        RP_HIP(hipFuncSetAttribute((const void*)pair_fill_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * L.Cmax * sizeof(unsigned short))));
     hipLaunchKernelGGL(pair_fill_rows_kernel, grid_rows, dim3(256), (size_t)4 * L.Cmax * sizeof(unsigned short), s, *kp, g, kc, p->topK, status);
     RP_CHECK_LAUNCH();
     // ---- fit: ONE launch, one workgroup per pair (fit_pair_kernel)

@@ -59,6 +59,10 @@ class MatchResult:
 _ws_cache = {}
 
 
+MAX_CORRESPONDENCES = 8192       # include/relpose.h RELPOSE_MAX_CORRESPONDENCES, RELPOSE_MAX_TARGETS (tests/test_cabi_cpu.py checks that they agree)
+MAX_TARGETS = 1152
+
+
 def _workspace(nbytes, dev):
     import torch
     key = (dev.index, torch.cuda.current_stream().cuda_stream)      # streams must not share scratch
@@ -87,6 +91,12 @@ def match_pairs(pc_s, n_s, f_s, w_s, pc_t, n_t, f_t, w_t, ns, nt, para, debug=Fa
                         _lib.ptr(pc_t), _lib.ptr(n_t), _lib.ptr(f_t), _lib.ptr(w_t))
     nbytes = L.relpose_match_workspace_bytes(B, ns_max, nt_max, p.topK, int(max_edges))
     if nbytes == 0:
+        if ns_max * p.topK > MAX_CORRESPONDENCES:
+            raise RuntimeError(f"relpose_match_pairs: {ns_max} keypoints x topK {p.topK} = {ns_max * p.topK} correspondences per pair exceed the "
+                               f"library's limit of {MAX_CORRESPONDENCES} (include/relpose.h: RELPOSE_MAX_CORRESPONDENCES)")
+        if nt_max > MAX_TARGETS:
+            raise RuntimeError(f"relpose_match_pairs: {nt_max} target keypoints exceed the library's limit of {MAX_TARGETS} "
+                               "(include/relpose.h: RELPOSE_MAX_TARGETS)")
         raise RuntimeError("relpose_match_workspace_bytes: invalid shape")
     ws = _workspace(nbytes, dev)
     res = MatchResult()

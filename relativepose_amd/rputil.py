@@ -104,13 +104,17 @@ def set_sift_detector(fn):
 
 def _detect(gray):
     if _sift_detector is not None:
-        return np.asarray(_sift_detector(gray), dtype=np.float64).reshape(-1, 2)
+        # a COPY: getKeypoint / getKeypoint_kinect shift and rescale the detections in place, and the hook may hand out an array it keeps
+        return np.array(_sift_detector(gray), dtype=np.float64, copy=True).reshape(-1, 2)
     try:
         import cv2
-        sift = cv2.xfeatures2d.SIFT_create(contrastThreshold=0.02)
+        try:
+            sift = cv2.xfeatures2d.SIFT_create(contrastThreshold=0.02)          # (the reference's call, rputil.py:152)
+        except AttributeError:
+            sift = cv2.SIFT_create(contrastThreshold=0.02)                      # OpenCV >= 4.4: SIFT moved into the main module
     except Exception as e:
-        raise RuntimeError("relativepose_amd.rputil: no SIFT detector (cv2.xfeatures2d is not importable); install one with "
-                           "rputil.set_sift_detector(fn)") from e
+        raise RuntimeError("relativepose_amd.rputil: no SIFT detector (neither cv2.xfeatures2d.SIFT_create nor cv2.SIFT_create is "
+                           "available); install one with rputil.set_sift_detector(fn)") from e
     kps, _ = sift.detectAndCompute(gray, None)
     return np.array([k.pt for k in kps], dtype=np.float64).reshape(-1, 2)
 

@@ -180,6 +180,17 @@ def make_match_case(N, seed, inlier=0.6, noise=0.005, Nt=None):
     return S, Tt, T
 
 
+def make_tune_primitives(n, N, seed0):
+    """A list of cached matching primitives in the reference's format (trainRelativePoseModuleRecFD.py:207-208: pc/normal/feat/weight of
+    source and target + R_gt) from seeded synthetic matcher cases of growing size and inlier ratio."""
+    out = []
+    for i in range(n):
+        S, T, G = make_match_case(N + 7 * i, seed0 + i, inlier=0.5 + 0.05 * i, noise=0.01)
+        out.append({'pc_src': S['pc'], 'normal_src': S['normal'], 'feat_src': S['feat'], 'weight_src': S['weight'],
+                    'pc_tgt': T['pc'], 'normal_tgt': T['normal'], 'feat_tgt': T['feat'], 'weight_tgt': T['weight'], 'R_gt': G})
+    return out
+
+
 # ---- well-conditioned scan pair (tests/golden "wc" fixtures) ---------------------------------------------------
 def _ray_box(half, T, dataset, slot, px, py, h):
     """World points hit by the rays of sub-pixel panorama coords (px, py) of face ``slot`` (camera pose T)."""

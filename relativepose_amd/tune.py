@@ -42,11 +42,11 @@ def make_para(sig):
     return p
 
 
-def tune_step(prims, sigmas, rng, n_probe=10, objective_fn=objective):
+def tune_step(prims, sigmas, rng, n_probe=10, objective_fn=objective, info=None):
     """One outer iteration of trainRelativePoseModuleRecFD.py:245-298: finite-difference gradient from
     `n_probe` random relative perturbations (least squares), normalised step, halving line search.
-    `rng.uniform(size=4)` replaces the reference's global np.random.uniform.  Returns
-    (new sigmas [4], loss, ad, found_descent)."""
+    `rng.uniform(size=4)` replaces the reference's global np.random.uniform (the same stream for the same seed).  Returns
+    (new sigmas [4], loss, ad, found_descent); `info` (a dict) receives the probes: eps [n_probe,4], losses, ads, grad."""
     if not isinstance(prims, PrimitiveSet) and objective_fn is objective:
         prims = PrimitiveSet(prims)
     sig = np.asarray(sigmas, dtype=np.float64)
@@ -58,6 +58,8 @@ def tune_step(prims, sigmas, rng, n_probe=10, objective_fn=objective):
         losses[j], ads[j] = objective_fn(prims, make_para(sig * (1 + eps[j])))
     grad = np.linalg.lstsq(eps[1:], losses[1:] - losses[0], rcond=None)[0]
     grad = grad / max(np.abs(grad / sig))
+    if info is not None:
+        info.update(eps=eps, losses=losses, ads=ads, grad=grad)
     alpha = 1.0
     for _ in range(10):
         cand = sig * (1 + -1 * grad * alpha)

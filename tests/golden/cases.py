@@ -43,3 +43,6 @@ WC2_CASES = (
 
 # rputil.getKeypoint / getKeypoint_kinect minus the SIFT detector (getkeypoint.npz): (kind, seed) for synth.make_keypoint_case
 GK_CASES = (("second", 31), ("second", 32), ("kinect", 33), ("kinect", 34))
+
+# sigma tuning (tune.npz, make_golden.gen_tune): synth.make_tune_primitives(n_prims, N, seed0), np.random.seed(np_seed), outer iterations
+TUNE_CASE = dict(n_prims=3, N=40, seed0=300, np_seed=12345, iters=2)

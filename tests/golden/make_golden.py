@@ -6,7 +6,7 @@ regenerated from seeds, expected outputs are stored) travel with the repo.
     python tests/golden/make_golden.py            # all groups
     python tests/golden/make_golden.py matcher    # one group
 
-Groups: matcher, matcher_big, geometry, scnet, e2e, e2e_env, e2e_wc, e2e_wc2, stats, keypoints, getkeypoint, metrics.  See SURVEY.md §8c for the plan.
+Groups: matcher, matcher_stages, tune, matcher_big, geometry, scnet, e2e, e2e_env, e2e_wc, e2e_wc2, stats, keypoints, getkeypoint, metrics.  See SURVEY.md §8c for the plan.
 """
 import hashlib
 import os
@@ -43,7 +43,7 @@ def sample_idx(n, k, seed):
 
 
 from cases import (MATCH_CASES, MATCH_METHODS, GEOM_CASES, WARP_ANGLES, SCNET_CASES, E2E_CASES, E2E_N, E2E_WEIGHT_SEED,  # noqa: E402
-                   ENV_AMP, ENV_SEEDS, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED, WC2_CASES)
+                   ENV_AMP, ENV_SEEDS, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED, WC2_CASES, TUNE_CASE)
 
 
 def gen_matcher():
@@ -64,6 +64,155 @@ def gen_matcher():
             out[f"pose_{ci}_{method}"] = pose
     out["params_suncg"], out["params_matterport"], out["params_scannet"] = (params[k] for k in ("suncg", "matterport", "scannet"))
     np.savez_compressed(os.path.join(HERE, "matcher.npz"), **out)
+
+
+class _HelperSpy:
+    """Captures the intermediates of ONE reference run of RelativePoseEstimation_helper (rpmodule.py:317-508) from the reference run
+    itself: the helper's locals when it returns (sys.settrace 'return' event: wij, corres, the surviving pairs and their weights), the
+    filter counts from the reference's own log lines (:404, :436), and the pose (R_cur, t_cur) of fit_irls_sm every time the fit
+    rebinds it (:270-271 after the initial IRLS, :306-307 after each of the 5 alternations)."""
+
+    def __init__(self, rp):
+        self.rp, self.locals, self.trace, self.log = rp, None, [], []
+        self._t_id = None
+
+    def info(self, msg, *a, **k):
+        self.log.append(str(msg))
+
+    def __getattr__(self, name):            # any other logger method
+        return lambda *a, **k: None
+
+    def _tracer(self, frame, event, arg):
+        name = frame.f_code.co_name
+        if event != "call" or name not in ("RelativePoseEstimation_helper", "fit_irls_sm"):
+            return None
+        if frame.f_code.co_filename != self.rp.__file__:
+            return None
+
+        def local(fr, ev, ar):
+            if name == "fit_irls_sm" and ev in ("line", "return"):
+                t = fr.f_locals.get("t_cur")
+                if t is not None and id(t) != self._t_id:          # a new t_cur: R_cur was assigned on the line before
+                    self._t_id = id(t)
+                    T = np.eye(4)
+                    T[:3, :3], T[:3, 3] = np.asarray(fr.f_locals["R_cur"]).reshape(3, 3), np.asarray(t).reshape(3)
+                    self.trace.append(T)
+            if name == "RelativePoseEstimation_helper" and ev == "return":
+                self.locals = dict(fr.f_locals)
+            return local
+        return local
+
+    def run(self, S, T, para):
+        old_logger = self.rp.logger
+        self.rp.logger = self
+        sys.settrace(self._tracer)
+        try:
+            pose = self.rp.RelativePoseEstimation_helper(S, T, para)
+        finally:
+            sys.settrace(None)
+            self.rp.logger = old_logger
+        return pose
+
+
+def stage_record(spy, pose, N, Nt):
+    """The stage-level quantities SURVEY 8(c) lists, from a _HelperSpy run: SHA-256 + 64 samples of wij (float64), the per-row
+    correspondence sets over wij > 0 (sorted, -1 padded), the filter counts, M, sum(w) and the pose after each alternation."""
+    L = spy.locals
+    rec = {"pose": pose}
+    if L is None or "wij" not in L:
+        return rec
+    wij = np.asarray(L["wij"])
+    rec["wij_sha"] = np.array(digest(wij))
+    idx = sample_idx(wij.size, 64, 7)
+    rec["wij_idx"], rec["wij_val"] = idx, wij.reshape(-1)[idx]
+    rec["wij_rowsum"] = wij.sum(1)
+    if "corres" in L:
+        corres = np.asarray(L["corres"])
+        K = corres.shape[1] // N
+        cj = corres[1].reshape(N, K)
+        sets = np.full((N, K), -1, dtype=np.int64)
+        for i in range(N):
+            keep = sorted(int(j) for j in cj[i] if wij[i, j] > 0)
+            sets[i, :len(keep)] = keep
+        rec["corres_sets"] = sets
+        rec["wij_kth"] = np.sort(wij, 1)[:, ::-1][:, K - 1:K + 1]          # K-th and (K+1)-th largest per row: exact ties are visible
+    C = N * min(5, Nt - 1)
+    n_pairs = C * (C - 1) // 2
+    for msg in spy.log:
+        if msg.startswith("dist delete:"):
+            rec["n_dist"] = np.array(n_pairs - int(msg.split(":")[1]))
+        if msg.startswith("angle delete:"):
+            rec["n_angle"] = np.array(int(rec["n_dist"]) - int(msg.split(":")[1]))
+    if "w_i1i2j1j2" in L:
+        w = np.asarray(L["w_i1i2j1j2"])
+        rec["M"], rec["w_sum"], rec["w_nonzero"] = np.array(len(w)), np.array(w.sum()), np.array(int((w != 0).sum()))
+    if spy.trace:
+        rec["trace"] = np.stack(spy.trace)
+    return rec
+
+
+def gen_matcher_stages():
+    """matcher_stages.npz: the intermediates of the reference helper for every MATCH_CASES entry and MATCH_BIG, captured from the
+    reference run itself (no restatement involved): see _HelperSpy / stage_record."""
+    from cases import MATCH_BIG
+    R = ref_loader.load()
+    rp, ru = R["rpmodule"], R["rputil"]
+    params = load_params()
+    out = {}
+    cases = [(f"{ci}", c + (0.005,)) for ci, c in enumerate(MATCH_CASES)] + [("big", MATCH_BIG)]
+    for tag, (N, Nt, seed, ds, row, inl, noise) in cases:
+        S, T, _ = synth.make_match_case(N, seed, inlier=inl, noise=noise, Nt=Nt)
+        para = ru.opts(*params[ds][row])
+        spy = _HelperSpy(rp)
+        t = time.time()
+        pose = spy.run(S, T, para)
+        rec = stage_record(spy, pose, N, Nt)
+        print(f"matcher_stages {tag}: N={N}/{Nt} {time.time()-t:.1f}s keys={sorted(rec)} trace={len(spy.trace)}")
+        for k, v in rec.items():
+            out[f"{tag}_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "matcher_stages.npz"), **out)
+
+
+def gen_tune():
+    """tune.npz: the finite-difference sigma tuning of the reference (trainRelativePoseModuleRecFD.py:215-298: objective(), probe
+    perturbations, least-squares gradient, normalised step, halving line search) run BY THE REFERENCE'S OWN LINES: the text of
+    lines 215-298 is read from /root/reference at generation time and exec'd (nothing of it is stored) in a namespace that provides
+    what the script's earlier lines would have: the primitives (seeded synthetic ones instead of the cached .npy), the reference's
+    helper / opts / angular_distance_np, a seeded np.random and args.max_iter.  Stored: per outer iteration the probe perturbations
+    and loss differences (as handed to np.linalg.lstsq), and the line the script appends to its log: loss, angular distance, sigmas."""
+    import contextlib
+    import io
+    import tempfile
+    import types
+    R = ref_loader.load()
+    src = open(os.path.join(ref_loader.REF, "trainRelativePoseModuleRecFD.py")).read().split("\n")
+    body = "\n".join(src[214:298])                      # lines 215-298
+    assert body.lstrip().startswith("def objective(para):") and "f.write(" in src[297]
+    records = []
+    real_lstsq = np.linalg.lstsq
+
+    def spy_lstsq(a, b, *args, **kw):
+        records.append((np.array(a, copy=True), np.array(b, copy=True)))
+        return real_lstsq(a, b, *args, **kw)
+
+    tmp = tempfile.mkdtemp()
+    ns = {"np": np, "primitives": synth.make_tune_primitives(TUNE_CASE["n_prims"], TUNE_CASE["N"], TUNE_CASE["seed0"]), "RelativePoseEstimation_helper": R["rpmodule"].RelativePoseEstimation_helper,
+          "opts": R["rputil"].opts, "angular_distance_np": R["util"].angular_distance_np,
+          "args": types.SimpleNamespace(max_iter=TUNE_CASE["iters"], exp=os.path.join(tmp, "tune"))}
+    np.random.seed(TUNE_CASE["np_seed"])
+    np.linalg.lstsq = spy_lstsq
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            exec(compile(body, "trainRelativePoseModuleRecFD.py[215:298]", "exec"), ns)
+    finally:
+        np.linalg.lstsq = real_lstsq
+    lines = np.loadtxt(os.path.join(tmp, "tune.txt")).reshape(-1, 6)      # loss_best ad_best sigmaAngle1 sigmaAngle2 sigmaDist sigmaFeat
+    assert len(records) == len(lines) == TUNE_CASE["iters"]
+    out = {"log": lines, "eps": np.stack([r[0] for r in records]), "dloss": np.stack([r[1] for r in records]),
+           "sigma_init": np.array([ns["sigmaAngle1_init"], ns["sigmaAngle2_init"], ns["sigmaDist_init"], ns["sigmaFeat_init"]]),
+           "found_last": np.array(bool(ns["foundDescentDirection"]))}
+    print("tune log:\n", lines)
+    np.savez_compressed(os.path.join(HERE, "tune.npz"), **out)
 
 
 def gen_matcher_big():
@@ -459,7 +608,7 @@ def gen_metrics():
 
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
-    groups = sys.argv[1:] or ["matcher", "matcher_big", "geometry", "scnet", "e2e", "e2e_env", "e2e_wc", "e2e_wc2", "stats", "keypoints", "getkeypoint", "metrics"]
+    groups = sys.argv[1:] or ["matcher", "matcher_stages", "tune", "matcher_big", "geometry", "scnet", "e2e", "e2e_env", "e2e_wc", "e2e_wc2", "stats", "keypoints", "getkeypoint", "metrics"]
     for g in groups:
         t = time.time()
         globals()["gen_" + g]()

@@ -83,3 +83,11 @@ def test_precision_codes_match_the_header():
     assert set(model.PRECISION_CODES) == set(want)
     for name, sym in want.items():
         assert enum[sym] == model.PRECISION_CODES[name], (name, sym)
+
+
+def test_capacity_limit_matches_the_header():
+    import re
+    from relativepose_amd import rpmodule
+    hdr = open(os.path.join(ROOT, "include", "relpose.h")).read()
+    assert int(re.search(r"#define RELPOSE_MAX_CORRESPONDENCES\s+(\d+)", hdr).group(1)) == rpmodule.MAX_CORRESPONDENCES
+    assert int(re.search(r"#define RELPOSE_MAX_TARGETS\s+(\d+)", hdr).group(1)) == rpmodule.MAX_TARGETS

@@ -92,6 +92,30 @@ def test_thousand_keypoints_fit_converges_and_matches_reference(golden_dir):
     assert e_ref < 1e-6 and t_ref < 1e-6, (e_ref, t_ref)
 
 
+def test_capacity_limits_largest_pair_runs_and_beyond_is_refused():
+    """include/relpose.h: RELPOSE_MAX_TARGETS = 1152 keypoints per view (the affinity kernel's LDS beyond 512 targets) and
+    RELPOSE_MAX_CORRESPONDENCES = 8192 = ns_max x topK (pair_fill_rows_kernel then asks for the full 64 KB of dynamic LDS).  A pair AT
+    both limits -- 1152 keypoints, topK 7: 8064 correspondences -- must run to a converged pose equal to the planted motion; one keypoint
+    more, or topK 8, is refused with a message that names the limit (the reference has no limit)."""
+    from relativepose_amd import rpmodule
+    N = rpmodule.MAX_TARGETS
+    S, T, G = synth.make_match_case(N, 4100, inlier=0.5, noise=0.002)
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.009)
+    para.topK = rpmodule.MAX_CORRESPONDENCES // N
+    assert para.topK == 7
+    res = _run([(S, T)], para, debug=True, max_edges=1 << 23)
+    pose = res.pose[0].cpu().numpy()
+    e_gt = float(np.linalg.norm(pose[:3, :3] - G[:3, :3]))
+    log("fit_capacity_limit", N=N, topK=para.topK, status=int(res.status[0]), surviving_pairs=int(res.counts[0, 1]), rot_err_vs_ground_truth=e_gt)
+    assert int(res.counts[0, 3]) == 7 and int(res.status[0]) == 0 and e_gt < 5e-3, (int(res.status[0]), e_gt)
+    para.topK = 8
+    with pytest.raises(RuntimeError, match="8192"):
+        _run([(S, T)], para)
+    S2, T2, _ = synth.make_match_case(N + 1, 4101)
+    with pytest.raises(RuntimeError, match="1152"):
+        _run([(S2, T2)], rpmodule.opts(0.3, 0.3, 0.04, 0.009))
+
+
 def test_fit_is_batch_invariant_and_deterministic():
     import torch
     from relativepose_amd import rpmodule
