@@ -270,6 +270,10 @@ def worker(args):
         run_steps(1, True)
         dt_h2d, _ = timed(args.steps, True)
 
+    if world > 1:
+        # per-rank rate on stderr (the JSON line carries the whole-job value only): a slow GPU / a bad link shows up here
+        print(f"[bench rank {rank}/{world} cuda:{local}] {nloc * args.steps / dt:.1f} pairs/s on this rank's {nloc} pairs per step "
+              f"({dt / args.steps * 1e3:.2f} ms/step, max over ranks)", file=sys.stderr, flush=True)
     if rank == 0:
         import torch.distributed as dist
         ms = dt / args.steps * 1e3
@@ -295,6 +299,7 @@ def worker(args):
                           "pose_all_gathers_in_timed_region": ncoll,
                           "dist_backend": dist.get_backend() if world > 1 else None,
                           "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                          "peer_access": D.peer_access_summary() if world > 1 else None,      # hipDeviceCanAccessPeer (xGMI inside one node)
                           "collective": ("one all_gather of [steps*pairs,17] f64 (pose + status) per run" if (args.gather == "run" and total % world == 0)
                                          else "one all_gather of [pairs,17] f64 (pose + status) per step") if world > 1 else None},
                "status_ok_fraction": float((status == 0).double().mean().item())}
@@ -359,11 +364,18 @@ def main():
             print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) visible; refusing to fall back", file=sys.stderr)
             raise SystemExit(2)
         import torch.multiprocessing as mp
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        mp.spawn(_spawned, args=(args, port), nprocs=args.gpus, join=True)
+        for attempt in range(3):             # a free port can be taken between the probe and the rendezvous: retry with another one
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            try:
+                mp.spawn(_spawned, args=(args, port), nprocs=args.gpus, join=True)
+                return
+            except Exception as e:
+                if attempt == 2 or not any(t in str(e) for t in ("Address already in use", "EADDRINUSE", "address already in use")):
+                    raise
+                print(f"bench.py: port {port} was taken ({e.__class__.__name__}); retrying with another one", file=sys.stderr)
         return
     worker(args)
 

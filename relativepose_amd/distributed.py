@@ -21,8 +21,25 @@ def init_from_env(backend=None):
             backend = os.environ.get("RELPOSE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # a rank that never arrives (a GPU that is not visible, a wrong MASTER_PORT) must not hang the others for the default 10-30 min
+        timeout = datetime.timedelta(seconds=float(os.environ.get("RELPOSE_DIST_TIMEOUT", "300")))
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        except Exception as e:
+            raise RuntimeError(f"relativepose_amd.distributed: rank {rank}/{world} could not join the process group (backend {backend} -- "
+                               f"'nccl' is RCCL on ROCm --, MASTER_ADDR={os.environ.get('MASTER_ADDR')}, MASTER_PORT={os.environ.get('MASTER_PORT')}, "
+                               f"timeout {timeout.total_seconds():.0f} s: RELPOSE_DIST_TIMEOUT): {e}") from e
     return rank, world, local
+
+
+def peer_access_summary():
+    """hipDeviceCanAccessPeer over the visible GPUs (one node: xGMI links make every pair peer-accessible): {"gpus", "peer_pairs",
+    "peer_accessible"} -- the pose all_gather runs over those links; reported in the bench line, not relied upon."""
+    import torch
+    n = torch.cuda.device_count()
+    ok = sum(1 for i in range(n) for j in range(n) if i != j and torch.cuda.can_device_access_peer(i, j))
+    return {"gpus": n, "peer_pairs": n * (n - 1), "peer_accessible": ok}
 
 
 def shard_range(total, rank, world):

@@ -8,6 +8,10 @@ unchanged" is realised by the build's own eval_pairs-style harness).
   result_record           evaluation.py:299-305
   save_results / load_results   evaluation.py:319-320 (np.save of the list of dicts)
   evaluate_pairs          evaluation.py:203-320 (loop over the loader, keypoints injected)
+  evaluate_pairs_sharded  the same over the GPUs of a node: the reference shards by hand (--entrySplit, evaluation.py:59,
+                          datasets/SUNCG.py:68-69: one process and one result file per split, merged afterwards); here every global
+                          batch is cut into contiguous per-rank blocks, ONE all_gather of the poses per round, rank 0 writes ONE
+                          <exp>.result.npy and resumes from an existing one in units of 100 pairs (:129-133, :319-320)
 
 The metrics are host numpy like the reference's (a handful of 3x3 products per pair); the overlap statistics use the
 GPU nearest-neighbour kernel (util.point_cloud_overlap)."""
@@ -103,3 +107,228 @@ def evaluate_pairs(pipe, batches, device, result_path=None, names=None):
     if result_path is not None:
         save_results(result_path, stats)
     return stats
+
+
+class SyntheticBatch:
+    """A global batch of `size` seeded synthetic scan pairs (synth.make_pairs / make_keypoints conventions: pair b of the batch comes from
+    seed + b) that materialises only the pairs a rank asks for -- evaluate_pairs_sharded hands every rank the same batch list, and a rank
+    should not render the other ranks' panoramas."""
+
+    def __init__(self, size, seed, dataset, mask_method, keypoints, h=160):
+        self.size, self.seed, self.dataset, self.mask_method, self.keypoints, self.h = size, seed, dataset, mask_method, keypoints, h
+
+    def take(self, idx):
+        from . import synth
+        parts = [synth.make_pairs(1, self.seed + int(b), self.dataset, h=self.h) for b in idx]
+        kps = [synth.make_keypoints(1, self.keypoints, self.seed + 7919 * int(b), self.mask_method, h=self.h) for b in idx]
+        out = {k: np.concatenate([p[k] for p in parts]) for k in ("rgb", "norm", "depth", "R")}
+        out["pts"], out["ptw"] = np.concatenate([k[0] for k in kps]), np.concatenate([k[1] for k in kps])
+        return out
+
+
+def _batch_size(batch):
+    return batch.size if hasattr(batch, "take") else batch["rgb"].shape[0]
+
+
+def _batch_take(batch, idx):
+    """The pairs `idx` of a global batch as a dict of arrays (a dict batch is sliced, a lazy one renders them)."""
+    if hasattr(batch, "take"):
+        return batch.take(idx)
+    return {k: v[idx] for k, v in batch.items() if isinstance(v, np.ndarray)}
+
+
+def _default_record(pipe, sub, poses, device, names, ks):
+    """Result records (the reference's keys, evaluation.py:286-305) of the pairs of `sub` (a _batch_take dict), given their poses
+    [n,4,4] (host) and their global pair indices `ks`: overlap statistics from the observed clouds, then the error metrics."""
+    from . import util
+    import torch
+    n = len(ks)
+    depth = torch.from_numpy(np.ascontiguousarray(sub["depth"].reshape(2 * n, *sub["depth"].shape[2:]))).to(device)
+    pcs, valid = util.depth2pc_dev(depth, pipe.dataset)
+    pcs, valid = pcs.cpu().numpy(), valid.cpu().numpy().astype(bool)
+    out = []
+    for q in range(n):
+        R_gt_44 = np.matmul(sub["R"][q, 1], np.linalg.inv(sub["R"][q, 0]))
+        pc_src, pc_tgt = pcs[2 * q][valid[2 * q]], pcs[2 * q + 1][valid[2 * q + 1]]
+        ov, cam_dist, pc_dist, pc_nn = util.point_cloud_overlap(pc_src, pc_tgt, R_gt_44)
+        nm = names[ks[q]] if names is not None else (f"pair{ks[q]}/src", f"pair{ks[q]}/tgt")
+        out.append(result_record(nm[0], nm[1], poses[q], R_gt_44, pc_src, ov, pc_dist, cam_dist, pc_nn))
+    return out
+
+
+def evaluate_pairs_sharded(pipe, batches, device, result_path=None, names=None, rank=0, world=1, resume=True, round_batches=None,
+                           record_fn=None, depth=2):
+    """`evaluate_pairs` over `world` ranks (one process per GPU, torch.distributed initialised by the caller:
+    distributed.init_from_env).  Every rank receives the same `batches` (a sequence of the DataLoader-layout dicts, B pairs each);
+    of every global batch rank r takes the contiguous block distributed.shard_range(B_todo, r, world) -- BatchNorm groups are scan
+    pairs, so a shard is independent of the others -- runs its blocks through pipe.run_pipelined (`depth` in flight), and computes
+    the records of its own pairs.  Per ROUND (`round_batches` global batches; default: the whole list) there is ONE all_gather of
+    the stacked poses (distributed.gather_poses: the north-star's single RCCL gather) and one gather of the record lists to rank 0,
+    which keeps the records in global pair order and writes `result_path` (np.save of the list of dicts, evaluation.py:319-320).
+    resume: an existing result file is loaded and its first (len // 100) * 100 pairs are kept and skipped, like the reference's
+    repeat bookkeeping (evaluation.py:129-133).  Returns the full record list on rank 0, None elsewhere.
+    A batch may be a dict of arrays or a lazy provider with `.size` and `.take(indices)` (SyntheticBatch): a rank then only
+    materialises its own pairs.
+    record_fn(sub_batch, local_indices, poses_host, k0) -> list of records (sub_batch = the rank's pairs of the global batch, in the
+    order of local_indices): override for callers with their own statistics (tests)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from . import distributed as D
+    batches = list(batches)
+    sizes = [_batch_size(b) for b in batches]
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    stats = []
+    if rank == 0 and resume and result_path is not None and os.path.exists(result_path if result_path.endswith(".npy") else result_path + ".npy"):
+        old = load_results(result_path if result_path.endswith(".npy") else result_path + ".npy")
+        stats = old[:(len(old) // 100) * 100]
+    done = len(stats)
+    if world > 1:
+        t = torch.tensor([done], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.broadcast(t, 0)
+        done = int(t.item())
+    todo = [(i, max(0, done - int(starts[i]))) for i in range(len(batches)) if int(starts[i + 1]) > done]     # (batch, first pair still to do)
+    nround = len(todo) if round_batches is None else max(1, int(round_batches))
+    for r0 in range(0, len(todo), max(1, nround)):
+        chunk = todo[r0:r0 + nround]
+        states, local, subs = [], [], []
+        for i, first in chunk:
+            lo, hi = D.shard_range(sizes[i] - first, rank, world)
+            idx = np.arange(first + lo, first + hi)
+            local.append(idx)
+            if len(idx):
+                b = _batch_take(batches[i], idx)
+                subs.append(b)
+                states.append(pipe.prepare(b["rgb"], b["norm"], b["depth"], b["pts"], b["ptw"], device))
+        res = pipe.run_pipelined(states, len(states), depth=min(depth, max(1, len(states)))) if states else []
+        # records of this rank's pairs, poses stacked in (batch, pair) order
+        recs, poses, status, si = [], [], [], 0
+        for (i, first), idx in zip(chunk, local):
+            if not len(idx):
+                continue
+            pose, st = res[si][0], res[si][1]
+            si += 1
+            poses.append(pose.reshape(-1, 4, 4)); status.append(st.reshape(-1))
+            ph = pose.detach().cpu().numpy().reshape(-1, 4, 4)
+            k0 = int(starts[i])
+            sub = subs[si - 1]
+            rr = record_fn(sub, idx, ph, k0) if record_fn is not None else _default_record(pipe, sub, ph, device, names, [k0 + int(b) for b in idx])
+            for b, rec in zip(idx, rr):
+                recs.append((k0 + int(b), rec))
+        n_local = sum(len(ix) for ix in local)
+        n_round = sum(sizes[i] - first for i, first in chunk)
+        if world > 1:
+            # ONE all_gather of this round's poses (+ status); blocks are per-rank concatenations, ragged by at most one pair per batch
+            pl = torch.cat(poses) if poses else torch.zeros(0, 4, 4, dtype=torch.float64, device=device)
+            sl = torch.cat(status) if status else torch.zeros(0, dtype=torch.int32, device=device)
+            counts = [sum(D.shard_range(sizes[i] - first, r, world)[1] - D.shard_range(sizes[i] - first, r, world)[0] for i, first in chunk)
+                      for r in range(world)]
+            bmax = max(counts)
+            buf = torch.zeros(bmax, 17, dtype=torch.float64, device=pl.device)
+            buf[:n_local, :16] = pl.reshape(-1, 16); buf[:n_local, 16] = sl.to(torch.float64)
+            out = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(out, buf)
+            D.COLLECTIVES["all_gather"] += 1
+            gathered = [None] * world if rank == 0 else None
+            dist.gather_object(recs, gathered, dst=0)
+            if rank == 0:
+                allrecs = [kr for part in gathered for kr in part]
+                # cross-check: the gathered poses are the ones the records were built from
+                by_k = {}
+                for r in range(world):
+                    ks = [int(starts[i]) + first + q for i, first in chunk for q in range(*D.shard_range(sizes[i] - first, r, world))]
+                    for row, k in zip(out[r][:counts[r]].cpu().numpy(), ks):
+                        by_k[k] = row[:16].reshape(4, 4)
+                for k, rec in allrecs:
+                    if 'R_pred_44' in rec:
+                        assert np.array_equal(by_k[k][:3, :4], np.asarray(rec['R_pred_44'])[:3, :4]), k
+        else:
+            allrecs = recs
+        if rank == 0:
+            assert len(allrecs) == n_round
+            stats += [rec for _, rec in sorted(allrecs, key=lambda kr: kr[0])]
+            if result_path is not None:
+                save_results(result_path, stats)
+    return stats if rank == 0 else None
+
+
+def main(argv=None):
+    """python -m relativepose_amd.evaluation --gpus N ...: the sharded evaluation over seeded synthetic scan pairs (no dataset ships with
+    the reference) -- BASELINE configs[3]: a "val split" of --pairs pairs in global batches of --batch, sharded over N GPUs, one pose
+    all_gather, one <exp>.result.npy.  Launched plainly it spawns its N ranks (one per GPU, RCCL); under torchrun it uses the launcher's
+    environment.  Rank 0 prints one JSON line: pairs, seconds, per-overlap-bucket statistics (evaluation.py:321-327)."""
+    import argparse
+    import json
+    import os
+    import socket
+    import sys
+    import time
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dataset", default="scannet", choices=["suncg", "matterport", "scannet"])
+    ap.add_argument("--pairs", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per global batch (sharded over the ranks)")
+    ap.add_argument("--keypoints", type=int, default=200)
+    ap.add_argument("--exp", default=None, help="result file prefix: <exp>.result.npy (resumed in units of 100 pairs unless --rm)")
+    ap.add_argument("--rm", action="store_true", help="ignore an existing result file (the reference's --rm)")
+    ap.add_argument("--round-batches", type=int, default=None, help="global batches per gather + save round (default: all)")
+    ap.add_argument("--seed", type=int, default=4000)
+    args = ap.parse_args(argv)
+
+    def worker():
+        import torch
+        from types import SimpleNamespace
+        from . import distributed as D, params, weights
+        from .model import SCNet
+        from .pipeline import RelativePosePipeline
+        rank, world, local = D.init_from_env()
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        ds = args.dataset
+        mm, S, tanh = ("kinect", 21, 0) if ds == "scannet" else ("second", 21 if ds == "matterport" else 15, 1)
+        net = SCNet(SimpleNamespace(batchnorm=1, useTanh=tanh, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+        net.load_state_dict(weights.make_state_dict(7, S))
+        pipe = RelativePosePipeline(net, ds, mm, params.final_params(ds))
+        batches = [SyntheticBatch(min(args.batch, args.pairs - k), args.seed + k, ds, mm, args.keypoints) for k in range(0, args.pairs, args.batch)]
+        path = None if args.exp is None else args.exp + ".result.npy"
+        D.barrier(world)
+        t0 = time.perf_counter()
+        n0 = D.COLLECTIVES["all_gather"]
+        stats = evaluate_pairs_sharded(pipe, batches, dev, result_path=path, rank=rank, world=world, resume=not args.rm,
+                                       round_batches=args.round_batches)
+        torch.cuda.synchronize()
+        D.barrier(world)
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"pairs": len(stats), "seconds": dt, "pairs_per_s_incl_host_rendering": len(stats) / dt, "n_gpus": world,
+                              "pose_all_gathers": D.COLLECTIVES["all_gather"] - n0, "result_file": path, "dataset": ds,
+                              "stats": summarize(stats)}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch
+        import torch.multiprocessing as mp
+        if torch.cuda.device_count() < args.gpus and not os.environ.get("RELPOSE_FORCE_DEVICE"):
+            print(f"--gpus {args.gpus} requested but only {torch.cuda.device_count()} GPU(s) visible; refusing", file=sys.stderr)
+            raise SystemExit(2)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_spawned_eval, args=(argv if argv is not None else sys.argv[1:], args.gpus, port), nprocs=args.gpus, join=True)
+        return
+    worker()
+
+
+def _spawned_eval(rank, argv, world, port):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    main(argv)
+
+
+if __name__ == "__main__":
+    main()

@@ -73,3 +73,103 @@ def test_gather_poses_gloo_world8_ragged_and_even(total):
         assert np.array_equal(P, want)
         assert np.array_equal(S, np.arange(total) % 5)
         assert t == float(world)
+
+
+# ---- evaluation.evaluate_pairs_sharded: the sharded evaluation harness with a stub pipeline (no GPU) ----------------------------------
+class _StubPipe:
+    """prepare / run_pipelined of RelativePosePipeline for CPU tests: the 'pose' of a pair is the identity with the pair's tag (carried in
+    rgb[b, 0, 0, 0, 0]) as translation x, status = tag % 3."""
+    dataset = "suncg"
+
+    def prepare(self, rgb, norm, depth, pts, ptw, device):
+        return {"tags": rgb[:, 0, 0, 0, 0].copy()}
+
+    def run_pipelined(self, states, steps, depth=None, **kw):
+        import torch
+        out = []
+        for st in states[:steps]:
+            t = torch.from_numpy(st["tags"]).to(torch.float64)
+            pose = torch.eye(4, dtype=torch.float64).repeat(len(t), 1, 1)
+            pose[:, 0, 3] = t
+            out.append((pose, (t.to(torch.int32) % 3)))
+        return out
+
+
+def _stub_batches(sizes):
+    out, k = [], 0
+    for B in sizes:
+        rgb = np.zeros((B, 2, 3, 2, 8), np.float32)
+        rgb[:, 0, 0, 0, 0] = np.arange(k, k + B)
+        out.append({"rgb": rgb, "norm": rgb.copy(), "depth": np.zeros((B, 2, 2, 8), np.float32), "pts": np.zeros((B, 2, 4, 2)),
+                    "ptw": np.ones((B, 2, 4)), "R": np.tile(np.eye(4), (B, 2, 1, 1))})
+        k += B
+    return out
+
+
+def _stub_record(sub, idx, poses, k0):
+    R = []
+    for q, b in enumerate(idx):
+        Rp = np.eye(4); Rp[:3, :4] = poses[q][:3, :4]
+        R.append({"k": k0 + int(b), "tag": float(sub["rgb"][q, 0, 0, 0, 0]), "R_pred_44": Rp})
+    return R
+
+
+def _eval_worker(rank, world, port, sizes, path, q):
+    import torch
+    from relativepose_amd import evaluation as E
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = D.init_from_env("gloo")
+    n0 = D.COLLECTIVES["all_gather"]
+    stats = E.evaluate_pairs_sharded(_StubPipe(), _stub_batches(sizes), torch.device("cpu"), result_path=path, rank=r, world=w,
+                                     record_fn=_stub_record)
+    q.put((rank, None if stats is None else [(s["k"], s["tag"], float(s["R_pred_44"][0, 3])) for s in stats], D.COLLECTIVES["all_gather"] - n0))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_gloo_world2_ragged_batches(tmp_path):
+    """Two ranks, global batches of 5, 4 and 7 pairs (ragged shards 3+2, 2+2, 4+3): rank 0 ends up with one record per pair in GLOBAL
+    pair order, each built from the pose its owner rank computed, written to ONE result file; one pose all_gather for the run."""
+    import torch.multiprocessing as mp
+    from relativepose_amd import evaluation as E
+    sizes = [5, 4, 7]
+    path = str(tmp_path / "exp.result.npy")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, sizes, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=180) for _ in range(2)))
+    for p in procs:
+        p.join(60)
+    assert res[1][0] is None and res[0][1] == 1 and res[1][1] == 1
+    assert res[0][0] == [(k, float(k), float(k)) for k in range(sum(sizes))]
+    saved = E.load_results(path)
+    assert [s["k"] for s in saved] == list(range(sum(sizes)))
+
+
+def test_sharded_evaluation_resumes_in_units_of_100_pairs(tmp_path):
+    """evaluation.py:129-133: an existing result file keeps its first (len // 100) * 100 records; the run continues behind them
+    (single process; the skipped pairs are never prepared)."""
+    import torch
+    from relativepose_amd import evaluation as E
+    sizes = [64, 64, 64, 30]
+    path = str(tmp_path / "exp.result.npy")
+    full = E.evaluate_pairs_sharded(_StubPipe(), _stub_batches(sizes), torch.device("cpu"), result_path=path, record_fn=_stub_record)
+    assert [s["k"] for s in full] == list(range(222))
+    E.save_results(path, full[:150] + [{"k": -1}] * 0)            # an interrupted run: 150 records on disk -> 100 are kept
+
+    class Counting(_StubPipe):
+        prepared = 0
+
+        def prepare(self, rgb, *a):
+            Counting.prepared += rgb.shape[0]
+            return super().prepare(rgb, *a)
+
+    again = E.evaluate_pairs_sharded(Counting(), _stub_batches(sizes), torch.device("cpu"), result_path=path, record_fn=_stub_record,
+                                     round_batches=1)
+    assert [s["k"] for s in again] == list(range(222)) and Counting.prepared == 122
+    assert len(E.load_results(path)) == 222
+    fresh = E.evaluate_pairs_sharded(Counting(), _stub_batches(sizes), torch.device("cpu"), result_path=path, record_fn=_stub_record, resume=False)
+    assert len(fresh) == 222

@@ -129,3 +129,28 @@ def test_bench_other_baseline_configs_run(config):
     want = {2: ("matterport", "second", "160x640", 400, "f32"), 3: ("scannet", "kinect", "160x640", 200, "f32"), 4: ("suncg", "second", "320x1280", 200, "f16x3")}[config]
     assert (c["dataset"], c["mask"], c["pano"], c["keypoints"], c["conv_precision"]) == want
     assert (r["dtype"] == "f32") == (config != 4)
+
+
+def test_sharded_evaluation_eight_ranks_equal_one_rank(tmp_path):
+    """python -m relativepose_amd.evaluation (evaluate_pairs_sharded: BASELINE configs[3]'s sharded evaluation): a synthetic ScanNet
+    "split" of 48 pairs in global batches of 24, once on one rank and once on eight ranks (3 pairs of every batch each; the one-device
+    gloo hook -- no 8-GPU node is available to the build).  Scan pairs are BatchNorm groups and the kernels are batch-invariant, so
+    the two result files must hold the same records in the same order with BITWISE the same poses; one pose all_gather per run."""
+    import numpy as np
+    from relativepose_amd import evaluation as E
+    outs = {}
+    for gpus in (1, 8):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        if gpus > 1:
+            env.update(RELPOSE_DIST_BACKEND="gloo", RELPOSE_FORCE_DEVICE="0")
+        exp = str(tmp_path / f"split{gpus}")
+        out = subprocess.run([sys.executable, "-m", "relativepose_amd.evaluation", "--gpus", str(gpus), "--dataset", "scannet", "--pairs", "48",
+                              "--batch", "24", "--keypoints", "60", "--exp", exp, "--rm"], capture_output=True, text=True, timeout=2400, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert r["pairs"] == 48 and r["n_gpus"] == gpus and r["pose_all_gathers"] == (0 if gpus == 1 else 1)
+        assert sum(v["nobs"] for v in r["stats"].values()) == 48
+        outs[gpus] = E.load_results(exp + ".result.npy")
+    assert [e["img_src"] for e in outs[1]] == [e["img_src"] for e in outs[8]] == [f"pair{k}/src" for k in range(48)]
+    for a, b in zip(outs[1], outs[8]):
+        assert np.array_equal(a["R_pred_44"], b["R_pred_44"]) and a["err_ad"] == b["err_ad"] and a["overlap"] == b["overlap"]
