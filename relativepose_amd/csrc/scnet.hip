@@ -102,6 +102,11 @@ struct ConvDesc {
                            // images 0, 1 only, and the split-K reduce reads row (img & 1, pixel) of it for every image
     int skip_slices;       // self-stream cache (relpose_scnet_forward4), conv_s2_strip_kernel: bit ks = K slice ks is NOT computed -- its partial
                            // sums are still in `partial` from the forward that filled the cache (conv4's partials have a region of their own)
+    // self-stream cache, deconv_tile_kernel (fp32 products): the skip source (src[1]: the self-view block of A3 / A2, level-invariant) is
+    // accumulated FIRST in every plan; snap_mode 1 stores the accumulators after those chunks to `snap` (thread-private layout, coalesced),
+    // snap_mode 2 starts from that snapshot and runs only the chunks of src[0] -- bitwise the accumulator chain of the full forward
+    int snap_mode;
+    float* snap;
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return fmaxf(v, slope * v); }   // slope in (0,1]
@@ -725,6 +730,11 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
         for (int t = 0; t < 4; ++t) aoffs[p][t] = ((int)dh[p].offy[t] * HW2 + (int)dh[p].offx[t]) * LDK;
     float4 ra[A_SLOTS], rb[B_SLOTS];
     const int nchunk = d.Cin / BK;
+    // chunk order: the skip source's channels (src[1]) first, then src[0]'s -- the k-th chunk processed starts at channel c0_of(k)
+    const int nch0 = d.src[0].C / BK, nch1 = nchunk - nch0;
+    auto c0_of = [&](int k) { return (k < nch1 ? nch0 + k : k - nch1) * BK; };
+    const int k_first = (SPLIT == 0 && d.snap_mode == 2) ? nch1 : 0;
+    const size_t snap_blk = ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * (size_t)(4 * MI * NI * 4) * NT;   // float4 units (d.snap: per head)
 
 #define RP_DT_LOAD_A(C0)                                                                                       \
     {                                                                                                         \
@@ -816,20 +826,36 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
             }
         }
     } else {
-        RP_DT_LOAD_A(0)
-        RP_DT_LOAD_B(0, 0)
+        if constexpr (SPLIT == 0) {
+            if (d.snap_mode == 2) {           // the accumulators as the full forward left them after the skip source's chunks
+                const float4* sp = reinterpret_cast<const float4*>(d.snap) + snap_blk + tid;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 v = rp_ldg4(reinterpret_cast<const float*>(sp + (size_t)(((p * MI + i) * NI + j) * 4 + q) * NT));
+                                acc[p][i][j][4 * q] = v.x; acc[p][i][j][4 * q + 1] = v.y; acc[p][i][j][4 * q + 2] = v.z; acc[p][i][j][4 * q + 3] = v.w;
+                            }
+            }
+        }
+        RP_DT_LOAD_A(c0_of(k_first))
+        RP_DT_LOAD_B(0, c0_of(k_first))
         __syncthreads();                                                  // sstab
-        RP_DT_STORE_A(0)
+        RP_DT_STORE_A(c0_of(k_first))
         RP_DT_STORE_B()
         __syncthreads();
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int c0 = ch * BK;
+        for (int ch = k_first; ch < nchunk; ++ch) {
+            const int c0 = c0_of(ch), c0n = c0_of(ch + 1 < nchunk ? ch + 1 : ch);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 // prefetch into registers: the next phase's weights, and (during the last phase) the next chunk's halo tile
                 const bool last = (ch + 1 == nchunk);
                 if (p < 3) RP_DT_LOAD_B(p + 1, c0)
-                else if (!last) { RP_DT_LOAD_B(0, c0 + BK) RP_DT_LOAD_A(c0 + BK) }
+                else if (!last) { RP_DT_LOAD_B(0, c0n) RP_DT_LOAD_A(c0n) }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int aoff = aoffs[p][t];
@@ -842,8 +868,23 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
                 }
                 __syncthreads();                                          // every wave is done with this phase's weights (and, p == 3, the halo tile)
                 if (p < 3 || !last) RP_DT_STORE_B()
-                if (p == 3 && !last) RP_DT_STORE_A(c0 + BK)
+                if (p == 3 && !last) RP_DT_STORE_A(c0n)
                 __syncthreads();
+            }
+            if constexpr (SPLIT == 0) {
+                if (d.snap_mode == 1 && ch + 1 == nch1) {   // the skip source is done: leave the accumulators for the self-cached forwards
+                    float4* sp = reinterpret_cast<float4*>(d.snap) + snap_blk + tid;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    rp_stg4(reinterpret_cast<float*>(sp + (size_t)(((p * MI + i) * NI + j) * 4 + q) * NT),
+                                            make_float4(acc[p][i][j][4 * q], acc[p][i][j][4 * q + 1], acc[p][i][j][4 * q + 2], acc[p][i][j][4 * q + 3]));
+                }
             }
         }
     }
@@ -1984,7 +2025,7 @@ struct RelposeSCNet {
     size_t w1_off = 0;           // conv1 direct-kernel weights inside d_w
     size_t wh_off = 0, bh_off = 0;   // fused-heads weight image and bias vector inside d_w
     std::map<std::pair<void*, int>, void*> plans;   // (workspace, n) -> Plan* (each with its own device descriptor table)
-    struct SelfState { uint64_t tag = 0; int n = 0, H = 0, W = 0; };
+    struct SelfState { uint64_t tag = 0; int n = 0, H = 0, W = 0; bool pose_only = false; };
     std::map<void*, SelfState> self_state;          // workspace -> whose self-view streams it holds (relpose_scnet_forward4)
     std::map<std::string, Layer> layers;
     std::map<std::string, Buf> bufs;
@@ -2226,6 +2267,8 @@ struct Plan {
     bool pose_only = false;      // RELPOSE_FWD_POSE_OUTPUTS plan
     bool self_cached = false;    // self-stream cache plan (relpose_scnet_forward4): the self-view encoder streams are not recomputed
     size_t persist_floats = 0;   // conv4's split-K partial sums (a region of their own: the self slices outlive the forward)
+    size_t snap_floats = 0;      // accumulator snapshots of the skip-connection halves of deconv3 / deconv2 (ConvDesc::snap)
+    int snap_mode = 0;           // 0 = plain forward, 1 = fills the snapshots (a tagged forward), 2 = self-cached forward
     std::vector<ConvDesc> descs;
     std::vector<Op> ops;
     size_t splitk_floats = 0;
@@ -2248,7 +2291,9 @@ struct Builder {
     bool pose_only = false;     // RELPOSE_FWD_POSE_OUTPUTS plan: no rgb / semantic decoder branches
     bool self_cached = false;   // self-stream cache plan: only the warped-view members of conv1 / conv2 / conv3 and K slices of conv4
     float* persist = nullptr;   // conv4's split-K partial sums
+    float* snapbuf = nullptr;   // accumulator snapshots (ConvDesc::snap), `snap_mode` as in Plan
     int skip_slices = 0;        // (conv4, strip kernel) K slices left from the forward that filled the cache
+    int snap_mode = 0;
     int force_ksplit = 0, shared_slices = 0;   // conv4: 6 K slices = the six 128-channel stream blocks of A3 (in EVERY plan: same numerics);
                                                 // zero-warp plans mark the warped streams' slices shared (ConvDesc::shared_slices)
     int nimg = 0;               // images of the members added by conv() (0 = n): RELPOSE_FWD_ZERO_WARP plans run the warped streams on 2
@@ -2475,6 +2520,19 @@ void Builder::end_group() {
     if (dtile) {
         Op o; o.type = OP_DECONV_TILE; o.first = first; o.count = count; o.cfg = dt_cfg; o.split = net->prec;
         o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count / 4, dt_cfg >= 2 ? cp / 32 : 1);
+        if (net->prec == 0 && dt_cfg != 3) {
+            // heads with a skip source (the self-view block of A3 / A2): accumulator snapshots for the self-stream cache -- the region
+            // is laid out (and its offsets are the same) in every plan; only tagged forwards write it, only self-cached ones read it
+            const int mini = (dt_cfg == 0 || dt_cfg == 1) ? 2 : 1;                     // MI * NI of the variant
+            for (int i = first; i < first + count; i += 4) {
+                ConvDesc& d = plan->descs[i];
+                if (d.nsrc != 2) continue;
+                const size_t nfl = (size_t)o.grid.x * o.grid.z * 256 * 64 * mini;
+                d.snap = snapbuf ? snapbuf + plan->snap_floats : nullptr;
+                d.snap_mode = snapbuf ? snap_mode : 0;
+                plan->snap_floats += nfl;
+            }
+        }
         plan->ops.push_back(o);
         return;
     }
@@ -2652,7 +2710,7 @@ void free_plan(RelposeSCNet* net) {
     net->self_state.clear();       // (new weights / precision: nothing cached is valid)
 }
 
-struct WsOffsets { size_t act, ss, partial, splitk, statp, persist, total; };
+struct WsOffsets { size_t act, ss, partial, splitk, statp, persist, snap, total; };
 
 WsOffsets ws_offsets(RelposeSCNet* net, int n) {
     Plan dry;
@@ -2666,6 +2724,7 @@ WsOffsets ws_offsets(RelposeSCNet* net, int n) {
     o.splitk = off; off += rp_align(dry.splitk_floats * sizeof(float));
     o.statp = off; off += rp_align(dry.stat_doubles * sizeof(double));
     o.persist = off; off += rp_align(dry.persist_floats * sizeof(float));
+    o.snap = off; off += rp_align(dry.snap_floats * sizeof(float));
     o.total = off;
     return o;
 }
@@ -2836,10 +2895,13 @@ int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_
     bool self_cached = false;
     {
         RelposeSCNet::SelfState& st = net->self_state[workspace];
-        self_cached = self_tag != 0 && st.tag == self_tag && st.n == n && st.H == H && st.W == W && !zero_warp;
-        st.tag = self_tag; st.n = n; st.H = H; st.W = W;
+        // (the accumulator snapshots are laid out per plan family: a pose-outputs forward has fewer decoder heads)
+        self_cached = self_tag != 0 && st.tag == self_tag && st.n == n && st.H == H && st.W == W && st.pose_only == pose_only && !zero_warp;
+        st.tag = self_tag; st.n = n; st.H = H; st.W = W; st.pose_only = pose_only;
     }
-    const int plan_key = (int)n | (zero_warp ? 1 << 24 : 0) | (pose_only ? 1 << 25 : 0) | (self_cached ? 1 << 26 : 0);
+    // a tagged forward that computes the self streams also leaves the accumulator snapshots of the skip-connection halves
+    const int snap_mode = self_cached ? 2 : (self_tag != 0 ? 1 : 0);
+    const int plan_key = (int)n | (zero_warp ? 1 << 24 : 0) | (pose_only ? 1 << 25 : 0) | (self_cached ? 1 << 26 : 0) | (snap_mode == 1 ? 1 << 27 : 0);
     Plan* plan = nullptr;
     {
         auto it = net->plans.find(std::make_pair(workspace, plan_key));
@@ -2855,6 +2917,7 @@ int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_
         Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan; B.zero_warp = zero_warp; B.pose_only = pose_only; B.self_cached = self_cached;
         B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk); B.statp = (double*)(ws + o.statp);
         B.persist = (float*)(ws + o.persist);
+        B.snapbuf = (float*)(ws + o.snap); B.snap_mode = snap_mode; plan->snap_mode = snap_mode;
         build_plan(net, n, B);
         if (B.rc) { delete plan; return B.rc; }
         RP_HIP(hipMalloc((void**)&plan->d_descs, MAX_DESCS * sizeof(ConvDesc)));
