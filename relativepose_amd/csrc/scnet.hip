@@ -733,8 +733,43 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
     // chunk order: the skip source's channels (src[1]) first, then src[0]'s -- the k-th chunk processed starts at channel c0_of(k)
     const int nch0 = d.src[0].C / BK, nch1 = nchunk - nch0;
     auto c0_of = [&](int k) { return (k < nch1 ? nch0 + k : k - nch1) * BK; };
-    const int k_first = (SPLIT == 0 && d.snap_mode == 2) ? nch1 : 0;
-    const size_t snap_blk = ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * (size_t)(4 * MI * NI * 4) * NT;   // float4 units (d.snap: per head)
+    // (the <1, 2> variant serves the heads without a skip source -- deconv2 s / f --: no snapshot code there, it cost 2 spilled registers)
+    constexpr bool SNAP = !(MI == 1 && NI == 2);
+    const int snap_mode = SNAP ? d.snap_mode : 0;
+    const int k_first = (snap_mode == 2) ? nch1 : 0;
+    // accumulator snapshot (ConvDesc::snap, one region per head): float4 q of accumulator (p, i, j) of thread tid of this workgroup at
+    // float4 index ((((p MI + i) NI + j) 4 + q) NT + tid: buffer accesses with ONE lane offset register and the rest as the scalar offset
+    // (64-bit addresses per access cost the tile kernels up to 54 spilled registers)
+    const __amdgpu_buffer_rsrc_t rs_snap = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(snap_mode ? d.snap + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * (size_t)(4 * MI * NI * 16) * NT : nullptr), 0,
+        snap_mode ? 4 * MI * NI * 16 * NT * 4 : 0, 0x00020000);
+    auto snap_load = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = rp_bufld4(rs_snap, tid * 16, ((((p * MI + i) * NI + j) * 4 + q) * NT) * 16);
+                        acc[p][i][j][4 * q] = v.x; acc[p][i][j][4 * q + 1] = v.y; acc[p][i][j][4 * q + 2] = v.z; acc[p][i][j][4 * q + 3] = v.w;
+                    }
+    };
+    auto snap_store = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const rp_f32x4g v = {acc[p][i][j][4 * q], acc[p][i][j][4 * q + 1], acc[p][i][j][4 * q + 2], acc[p][i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128((__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned)v, rs_snap, tid * 16,
+                                                               ((((p * MI + i) * NI + j) * 4 + q) * NT) * 16, 0);
+                    }
+    };
 
 #define RP_DT_LOAD_A(C0)                                                                                       \
     {                                                                                                         \
@@ -793,22 +828,23 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
         // deeper: the weights of phase q + 2 are requested at the top of phase q (two register sets, alternating by phase parity) and
         // the next chunk's halo tile at the top of phase 1 (fp32: one phase ahead for both)
         float4 rb2[B_SLOTS];
-        RP_DT_LOAD_A(0)
-        RP_DT_LOAD_B2(rb, 0, 0)
-        RP_DT_LOAD_B2(rb2, 1, 0)
+        if (snap_mode == 2) snap_load();
+        RP_DT_LOAD_A(c0_of(k_first))
+        RP_DT_LOAD_B2(rb, 0, c0_of(k_first))
+        RP_DT_LOAD_B2(rb2, 1, c0_of(k_first))
         __syncthreads();                                              // sstab
-        RP_DT_STORE_A(0)
+        RP_DT_STORE_A(c0_of(k_first))
         RP_DT_STORE_B2(rb)
         __syncthreads();
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int c0 = ch * BK;
+        for (int ch = k_first; ch < nchunk; ++ch) {
+            const int c0 = c0_of(ch), c0n = c0_of(ch + 1 < nchunk ? ch + 1 : ch);
             const bool last = (ch + 1 == nchunk);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 // the set that was stored to LDS for THIS phase is free: phase p + 2's weights go there
                 if (p < 2) { if (p == 0) RP_DT_LOAD_B2(rb, 2, c0) else RP_DT_LOAD_B2(rb2, 3, c0) }
-                else if (!last) { if (p == 2) RP_DT_LOAD_B2(rb, 0, c0 + BK) else RP_DT_LOAD_B2(rb2, 1, c0 + BK) }
-                if (p == 1 && !last) RP_DT_LOAD_A(c0 + BK)
+                else if (!last) { if (p == 2) RP_DT_LOAD_B2(rb, 0, c0n) else RP_DT_LOAD_B2(rb2, 1, c0n) }
+                if (p == 1 && !last) RP_DT_LOAD_A(c0n)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int aoff = aoffs[p][t];
@@ -821,27 +857,13 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
                 }
                 __syncthreads();                                      // every wave is done with this phase's weights (and, p == 3, the halo tile)
                 if (p < 3 || !last) { if (p & 1) RP_DT_STORE_B2(rb) else RP_DT_STORE_B2(rb2) }      // phase p + 1's weights
-                if (p == 3 && !last) RP_DT_STORE_A(c0 + BK)
+                if (p == 3 && !last) RP_DT_STORE_A(c0n)
                 __syncthreads();
             }
+            if (snap_mode == 1 && ch + 1 == nch1) snap_store();     // the skip source is done: the accumulators for the self-cached forwards
         }
     } else {
-        if constexpr (SPLIT == 0) {
-            if (d.snap_mode == 2) {           // the accumulators as the full forward left them after the skip source's chunks
-                const float4* sp = reinterpret_cast<const float4*>(d.snap) + snap_blk + tid;
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NI; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float4 v = rp_ldg4(reinterpret_cast<const float*>(sp + (size_t)(((p * MI + i) * NI + j) * 4 + q) * NT));
-                                acc[p][i][j][4 * q] = v.x; acc[p][i][j][4 * q + 1] = v.y; acc[p][i][j][4 * q + 2] = v.z; acc[p][i][j][4 * q + 3] = v.w;
-                            }
-            }
-        }
+        if (snap_mode == 2) snap_load();        // the accumulators as the full forward left them after the skip source's chunks
         RP_DT_LOAD_A(c0_of(k_first))
         RP_DT_LOAD_B(0, c0_of(k_first))
         __syncthreads();                                                  // sstab
@@ -871,21 +893,7 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
                 if (p == 3 && !last) RP_DT_STORE_A(c0n)
                 __syncthreads();
             }
-            if constexpr (SPLIT == 0) {
-                if (d.snap_mode == 1 && ch + 1 == nch1) {   // the skip source is done: leave the accumulators for the self-cached forwards
-                    float4* sp = reinterpret_cast<float4*>(d.snap) + snap_blk + tid;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-#pragma unroll
-                        for (int i = 0; i < MI; ++i)
-#pragma unroll
-                            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    rp_stg4(reinterpret_cast<float*>(sp + (size_t)(((p * MI + i) * NI + j) * 4 + q) * NT),
-                                            make_float4(acc[p][i][j][4 * q], acc[p][i][j][4 * q + 1], acc[p][i][j][4 * q + 2], acc[p][i][j][4 * q + 3]));
-                }
-            }
+            if (snap_mode == 1 && ch + 1 == nch1) snap_store();         // the skip source is done: the accumulators for the self-cached forwards
         }
     }
 #undef RP_DT_LOAD_B2
@@ -2520,7 +2528,7 @@ void Builder::end_group() {
     if (dtile) {
         Op o; o.type = OP_DECONV_TILE; o.first = first; o.count = count; o.cfg = dt_cfg; o.split = net->prec;
         o.grid = dim3((unsigned)(plan->descs[first].M / BMt), count / 4, dt_cfg >= 2 ? cp / 32 : 1);
-        if (net->prec == 0 && dt_cfg != 3) {
+        if (dt_cfg != 3 && dt_cfg != 1) {
             // heads with a skip source (the self-view block of A3 / A2): accumulator snapshots for the self-stream cache -- the region
             // is laid out (and its offsets are the same) in every plan; only tagged forwards write it, only self-cached ones read it
             const int mini = (dt_cfg == 0 || dt_cfg == 1) ? 2 : 1;                     // MI * NI of the variant
