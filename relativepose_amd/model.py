@@ -13,6 +13,7 @@ n = 2B the call processes B scan pairs at once.
 import ctypes as C
 
 import numpy as np
+import torch
 
 from . import _lib
 from .weights import state_dict_spec
@@ -28,8 +29,12 @@ BUFFER_SHAPES = {"X0": (224, 16), "A1": (224, 192), "A2": (112, 384), "A3": (56,
 _REGISTRY = {}          # C handle -> weakref(SCNet): lets torch.ops.relpose.scnet_forward(x, net.handle) find the workspace cache
 
 
-class SCNet:
+class SCNet(torch.nn.Module):
+    """A torch.nn.Module like the reference's (isinstance checks, .to() / .cuda() / .eval() / .state_dict() call sites keep working) whose
+    parameters live in the HIP library, not in torch: `state_dict()` returns the loaded tensors (host copies), `parameters()` is empty."""
+
     def __init__(self, args):
+        super().__init__()
         if not getattr(args, "batchnorm", 1) or not getattr(args, "skipLayer", 1):
             raise NotImplementedError("only batchnorm=1, skipLayer=1 (the evaluation.py configuration) is built")
         if getattr(args, "outputType", "rgbdnsf") != "rgbdnsf":
@@ -40,6 +45,7 @@ class SCNet:
         self._h = _lib.lib().relpose_scnet_create(self.snumclass, self.useTanh)
         if not self._h:
             raise RuntimeError("relpose_scnet_create failed")
+        self._state = {}
         self._wss = {}          # one workspace (and launch plan) per (stream, n): streams must not share scratch
         self._ws = None
         self._loaded = False
@@ -68,12 +74,11 @@ class SCNet:
         except Exception:
             pass
 
-    # torch.nn.Module look-alikes used by the reference call sites
-    def cuda(self, *a, **k):
-        return self
-
-    def eval(self):
-        return self
+    # (nn.Module's own cuda() / to() / eval() / train() apply: there are no torch parameters to move; the weights were uploaded by
+    # load_state_dict and the kernels always use batch statistics, like the reference's track_running_stats=False BatchNorm)
+    def state_dict(self, *args, **kwargs):
+        """The loaded parameters under the reference's key names (host tensors)."""
+        return dict(self._state)
 
     def load_state_dict(self, state_dict, strict=True):
         """Takes the reference's key names (model/mymodel.py:142-257); a ``module.`` prefix (checkpoints saved from a
@@ -92,6 +97,7 @@ class SCNet:
             if tuple(a.shape) != tuple(shape):
                 raise RuntimeError(f"size mismatch for {k}: {a.shape} vs {shape}")
             _lib.check(L.relpose_scnet_set_param(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), f"set_param {k}")
+            self._state[k] = torch.from_numpy(a)
         _lib.require_gpu()
         _lib.check(L.relpose_scnet_finalize(self._h), "relpose_scnet_finalize")
         self._loaded = True
@@ -172,8 +178,6 @@ class SCNet:
                                                (1 if zero_warp else 0) | {"all": 0, "pose": 2}[outputs], int(self_tag))
         _lib.check(rc, "relpose_scnet_forward")
         return out
-
-    __call__ = forward
 
     def read_tap(self, name):
         """Raw (pre-BatchNorm) NHWC activations of buffer ``name`` from the last forward: [n,H,H,C]."""

@@ -11,8 +11,6 @@ B scan pairs and kept on the device from the input panoramas to the 4x4 poses:
 Keypoints are an input of this batched pipeline (the reference detects them per level with cv2 SIFT + feature-guided + random
 sampling, rputil.getKeypoint: built in relativepose_amd.rputil around a SIFT-detector hook).
 """
-import os
-
 import numpy as np
 
 from . import _lib, rpmodule, util
@@ -24,7 +22,7 @@ class RelativePosePipeline:
     _net_streams = None
 
     def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0, compose=0, outputs="all",
-                 self_stream_cache=True):
+                 self_stream_cache=True, tail_overlap=True, net_priority=None):
         self.net = net
         # the masked own views (channels 0:8 of the net input) are written once per pass and only the warped partner view changes from
         # level to level (evaluation.py:217-242): levels >= 1 reuse level 0's self-view encoder streams (SCNet.forward(self_tag=...),
@@ -45,8 +43,10 @@ class RelativePosePipeline:
         self.sigmas = np.asarray(sigmas, dtype=np.float64).reshape(-1, 4)
         self.feat_off = 7 + net.snumclass
         self._slot_streams = []
-        # RELPOSE_TAIL_OVERLAP=0: the whole forward on the SCNet stream (pipelined modes)
-        self.tail_overlap = os.environ.get("RELPOSE_TAIL_OVERLAP", "1") != "0"
+        # tail_overlap=False: the whole forward on the SCNet stream in the pipelined modes (A/B switch; the product reads no environment
+        # variable).  net_priority: HIP stream priority of the SCNet stream, None = -1 (high) when the tail overlaps, else 0.
+        self.tail_overlap = bool(tail_overlap)
+        self.net_priority = net_priority
 
     def prepare(self, rgb, norm, depth, pts, ptw, device, keep_host=False):
         """Host arrays (dataset dict layout: rgb/norm [B,2,3,h,4h], depth [B,2,h,4h] f32; pts [B,2,N,2],
@@ -142,14 +142,14 @@ class RelativePosePipeline:
         # 365-377 pairs/s; see below for today's rule) and two SCNet streams whose forwards may overlap (394 -> 358-360: the two
         # working sets fight over L2)
         import torch
-        # HIP stream priority of the SCNet stream (RELPOSE_NET_PRIO overrides; -1 = high: conv workgroups are dispatched ahead of
+        # HIP stream priority of the SCNet stream (the `net_priority` argument overrides; -1 = high: conv workgroups are dispatched ahead of
         # the slot streams' kernels, which then fill the holes -- the drain of every conv launch, barrier stalls).  With the forwards'
         # head / tail on the slot streams this is worth +4 % at 200 keypoints (499 -> 518 pairs/s, round 3).  Round 2 limited it to
         # <= 256 keypoints per view (at 400 the deprioritised slot-stream chain tail -> matcher -> warp -> head became critical: -3 %);
         # with round 3's matcher and level-0 plan that is gone (configs[2]: 482 vs 484 pairs/s), so it is on whenever the tail overlaps.
         if self._net_streams is None:
             self._net_streams = {0: torch.cuda.Stream(priority=0), -1: torch.cuda.Stream(priority=-1)}
-        prio = int(os.environ.get("RELPOSE_NET_PRIO", "-1" if self.tail_overlap else "0"))
+        prio = self.net_priority if self.net_priority is not None else (-1 if self.tail_overlap else 0)
         new_stream = self._net_streams[-1 if prio < 0 else 0]
         if self._net_stream is not None and new_stream is not self._net_stream:
             new_stream.wait_stream(self._net_stream)            # forwards of the previous call stay ordered before this call's

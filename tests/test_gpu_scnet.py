@@ -257,6 +257,19 @@ def test_scnet_pose_outputs_are_bitwise_the_full_forward_on_the_pose_channels():
     log("scnet_pose_outputs", bitwise=True)
 
 
+def test_scnet_is_a_torch_module_with_the_reference_state_dict():
+    """The reference's call sites treat the network as a torch.nn.Module (isinstance, .cuda(), .eval(), state_dict()): the shim is one,
+    its state_dict() returns the loaded parameters under the reference's key names (mymodel.py:142-257)."""
+    import torch
+    tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
+    net, sd = make_net(S, tanh, seed)
+    assert isinstance(net, torch.nn.Module) and net.cuda() is net and net.eval() is net and net.to("cuda") is net
+    got = net.state_dict()
+    assert set(got) == set(sd) and all(np.array_equal(got[k].numpy(), np.asarray(sd[k], dtype=np.float32)) for k in sd)
+    x = torch.from_numpy(oracle_scnet_input(601, ds, mm)).cuda()
+    assert torch.equal(net(x), net.forward(x))
+
+
 def test_scnet_rejects_odd_batch_like_reference():
     import torch
     tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
