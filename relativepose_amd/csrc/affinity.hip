@@ -590,41 +590,17 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
     const float ti1 = (thr_imp - be1) / al1 - 1e-6f * fabsf((thr_imp - be1) / al1);
     const float ti0 = (thr_imp - be0) / al0 - 1e-6f * fabsf((thr_imp - be0) / al0);
 
-    // ---- pooled exact distances: items [from, from + count) of the wave's queue, one per lane
-    auto evaluate = [&](const float (&fs)[RP_FEAT], int from, int count) {
-        const bool act = lane < count;
-        const int item = act ? queue[from + lane] : 0;
-        const int pidx = (item >> 9) << 2;
-        const float* tj = &ftT[(item & 511) * AT_LDT];
-        float r8[8];
-#pragma unroll
-        for (int c8 = 0; c8 < RP_FEAT / 8; ++c8) {
-            const float4 ta = *reinterpret_cast<const float4*>(tj + 8 * c8), tb = *reinterpret_cast<const float4*>(tj + 8 * c8 + 4);
-            const float tt[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float df = rp_bperm_f(pidx, fs[8 * c8 + k]) - tt[k];
-                const float sq = df * df;
-                if (c8 == 0) r8[k] = sq; else r8[k] = r8[k] + sq;
-            }
-            __builtin_amdgcn_sched_barrier(0);                                  // (8 gathers in flight, not 32: registers)
-        }
-        const float d = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-        if (act) resd[from + lane] = d;
-    };
-
-    // ---- P2: ONE selection sweep; candidates through the wave's queue, evaluated 64 at a time
-    int cnt = 0, qtot = 0;                                                      // qtot: wave-uniform
-    bool over = false;
-    for (int T = 0; T < ntiles; T += 2) {
-        unsigned m = 0, mi = 0;                                                 // candidates / the important ones among them
+    // candidate masks of the tile pair (T, T + 1) for this lane's row: bit 31 - (16 u + r) <-> sorted position pos_of(T + u, r);
+    // m = candidates (e~ >= thr), mi = the important ones among them
+    auto pair_masks = [&](int T, unsigned& m, unsigned& mi) {
+        m = 0; mi = 0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const floatx16 g = tile_g(T + u);
             if (T + u != tmix) {
-                // g >= t  <=>  the sign bit of g - t is clear (g, t finite; -0 cannot come out of x - y with x != y ... and x == y gives +0):
-                // one packed subtraction per two entries and one v_alignbit per entry ({m, d} >> 31 = (m << 1) | sign(d)) -- a v_cmp +
-                // v_cndmask + shift / or chain through VCC is 3 instructions and a hazard nop per entry.  m collects the "below" bits.
+                // g >= t  <=>  the sign bit of g - t is clear (g, t finite; x - y with x == y gives +0): one packed subtraction per two
+                // entries and one v_alignbit per entry ({m, d} >> 31 = (m << 1) | sign(d)) -- a v_cmp + v_cndmask + shift / or chain through
+                // VCC is 3 instructions and a hazard nop per entry.  m collects the "below" bits.
                 const bool c1 = 32 * (T + u) < n1;
                 const float tg = c1 ? tg1 : tg0, ti = c1 ? ti1 : ti0;
 #pragma unroll
@@ -652,27 +628,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
         }
         m = ~m;                                                                 // candidates = not below
         mi = WRITE_WIJ ? ~mi : m;
-        while (__ballot(m != 0)) {
-            int jc = INT_MAX;
-            bool imp = false;
-            if (m) { const int bit = __builtin_ctz(m); m &= m - 1; imp = (mi >> bit) & 1u; const int idx = 31 - bit; jc = pos_of(T + (idx >> 4), idx & 15); }
-            const bool push = jc < nt;
-            const unsigned long long bm = __ballot(push);
-            const int slot = qtot + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
-            if (push) {
-                if (slot < AT2_CAPW) queue[slot] = (unsigned short)((n << 9) | jc);
-                else over = true;
-                if (imp) {
-                    if (slot < AT2_CAPW && cnt < istk_cap) istk[cnt * 64 + lane] = (unsigned short)slot; else over = true;
-                    ++cnt;
-                }
-            }
-            qtot = min(qtot + __popcll(bm), AT2_CAPW);
-        }
-    }
-    rp_wave_lds_order();
-    {   // the exact distances of the queued candidates, 64 at a time, one per lane whatever row they belong to
-        float fs[RP_FEAT];
+    };
+    auto load_source_row = [&](float (&fs)[RP_FEAT]) {       // the 32 exact features of this lane's row again (L2-resident)
         long long soff = (long long)(si * RP_FEAT);
         asm volatile("" : "+v"(soff));                                          // (a second load the compiler cannot merge with the first)
 #pragma unroll
@@ -680,7 +637,69 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
             const float4 v = rp_div100(rowok ? rp_ldg4(kp.feat_s + soff + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f));
             fs[4 * c4] = v.x; fs[4 * c4 + 1] = v.y; fs[4 * c4 + 2] = v.z; fs[4 * c4 + 3] = v.w;
         }
-        for (int from = 0; from < qtot; from += 64) evaluate(fs, from, min(64, qtot - from));
+    };
+
+    // ---- pooled exact distances: one queue item per lane whatever row it belongs to -- the numpy-order float32 distance, the source row
+    // gathered from its owner lane 8 features at a time
+    auto exact_dist_item = [&](const float (&fs)[RP_FEAT], int item) {
+        const int pidx = (item >> 9) << 2;
+        const float* tj = &ftT[(item & 511) * AT_LDT];
+        float r8[8];
+#pragma unroll
+        for (int c8 = 0; c8 < RP_FEAT / 8; ++c8) {
+            const float4 ta = *reinterpret_cast<const float4*>(tj + 8 * c8), tb = *reinterpret_cast<const float4*>(tj + 8 * c8 + 4);
+            const float tt[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float df = rp_bperm_f(pidx, fs[8 * c8 + k]) - tt[k];
+                const float sq = df * df;
+                if (c8 == 0) r8[k] = sq; else r8[k] = r8[k] + sq;
+            }
+            __builtin_amdgcn_sched_barrier(0);                                  // (8 gathers in flight, not 32: registers)
+        }
+        return ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+    };
+
+    auto evaluate = [&](const float (&fs)[RP_FEAT], int from, int count) {          // queue items [from, from + count): distance -> resd
+        const bool act = lane < count;
+        const float d = exact_dist_item(fs, act ? queue[from + lane] : 0);
+        if (act) resd[from + lane] = d;
+    };
+    // ---- P2: ONE selection sweep; candidates into the wave's queue.  Important candidates (ranked by their row's owner lanes) fill it
+    // from the front, window-only ones (a wij value each, nothing else) from the back; when the two meet the window is DENSE (a wide
+    // sigmaFeat: a large part of the row lies within e^-75 of its maximum): the window-only items are dropped and the wave writes its
+    // rows the other way (below) -- the important ones always have room up to the whole queue.
+    int cnt = 0, qimp = 0, qwin = 0;                                            // qimp / qwin: wave-uniform
+    bool over = false, dense = false;                                           // dense: wave-uniform
+    for (int T = 0; T < ntiles; T += 2) {
+        unsigned m, mi;
+        pair_masks(T, m, mi);
+        while (__ballot(m != 0)) {
+            int jc = INT_MAX;
+            bool imp = false;
+            if (m) { const int bit = __builtin_ctz(m); m &= m - 1; imp = (mi >> bit) & 1u; const int idx = 31 - bit; jc = pos_of(T + (idx >> 4), idx & 15); }
+            const bool push = jc < nt;
+            const unsigned long long bi = __ballot(push && imp), bw = __ballot(push && !imp);
+            const int ni = __popcll(bi), nw = __popcll(bw);
+            if (qimp + ni + qwin + (dense ? 0 : nw) > AT2_CAPW) { dense = true; qwin = 0; }
+            if (push && imp) {
+                const int slot = qimp + __builtin_amdgcn_mbcnt_hi((unsigned)(bi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bi, 0));
+                if (slot < AT2_CAPW) queue[slot] = (unsigned short)((n << 9) | jc);
+                if (slot < AT2_CAPW && cnt < istk_cap) istk[cnt * 64 + lane] = (unsigned short)slot; else over = true;
+                ++cnt;
+            }
+            if (push && !imp && !dense)
+                queue[AT2_CAPW - 1 - (qwin + __builtin_amdgcn_mbcnt_hi((unsigned)(bw >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bw, 0)))] = (unsigned short)((n << 9) | jc);
+            qimp = min(qimp + ni, AT2_CAPW);
+            if (!dense) qwin += nw;
+        }
+    }
+    rp_wave_lds_order();
+    {   // the exact distances of the queued candidates, 64 at a time, one per lane whatever row they belong to
+        float fs[RP_FEAT];
+        load_source_row(fs);
+        for (int from = 0; from < qimp; from += 64) evaluate(fs, from, min(64, qimp - from));
+        for (int from = AT2_CAPW - qwin; from < AT2_CAPW; from += 64) evaluate(fs, from, min(64, AT2_CAPW - from));
     }
     rp_wave_lds_order();
     const int ncand = over ? 0 : cnt;
@@ -786,52 +805,100 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
     }
     if (!WRITE_WIJ) return;
 
-    // ---- window values: item slot = lane + 64 q -> (row, target, wij) in registers; wij = exp(e - e_max) * (exp(e_max) / norm)
+    // ---- window values: wij = exp(e - e_max) * (exp(e_max) / norm) of one queued / re-found candidate, evaluated by whichever lane holds it
     const float rsf = (redo || !(nm > 0.0)) ? 0.f : (float)(lw[0] / nm);
     const double emx = le[0];
-    int it_rj[AT2_IPL];
-    float it_v[AT2_IPL];
-#pragma unroll
-    for (int q = 0; q < AT2_IPL; ++q) {
-        const int slot = lane + 64 * q;
-        const bool act = slot < qtot;
-        const int item = act ? queue[slot] : 0;
-        const int rown = item >> 9, jp = item & 511, pidx = rown << 2;
+    auto window_value = [&](int rown, int jp, float d) {
+        const int pidx = rown << 2;
         const float rs_i = rp_bperm_f(pidx, rsf);
         const int one_i = __builtin_amdgcn_ds_bpermute(pidx, rowone ? 1 : 0);
         const double em_i = __hiloint2double(__builtin_amdgcn_ds_bpermute(pidx, __double2hiint(emx)), __builtin_amdgcn_ds_bpermute(pidx, __double2loint(emx)));
         const bool cls = one_i && jp < n1;
-        const double x = rp_exponent(act ? resd[slot] : 0.f, cls ? ac.den[1] : ac.den[0], cls ? ac.rden[1] : ac.rden[0]) - em_i;
+        const double x = rp_exponent(d, cls ? ac.den[1] : ac.den[0], cls ? ac.rden[1] : ac.rden[0]) - em_i;
         const double tl = x * 1.4426950408889634;
         const double nr = __builtin_rint(tl);
         const float p2 = __builtin_amdgcn_exp2f((float)(tl - nr));
         float val = ldexpf(p2 * rs_i, (int)fmax(nr, -300.0));
         if (!(x >= -RP_AFF_WINDOW && x <= 0.0)) val = 0.f;                      // exact zeros below the window, like affinity_rows_kernel (and for rows without a list)
-        it_rj[q] = act ? ((rown << 9) | (int)perm[jp]) : -1;
-        it_v[q] = val;
-    }
-    rp_wave_lds_order();                                                         // every lane has its items: the wave's LDS area becomes the staging buffer
-    // ---- the wave's rows, a few at a time: zeros, the rows' items over them, coalesced stores of the finished lines
-    float* stage = (float*)warea;
+        return val;
+    };
     float* wbase = wij + ((size_t)b * kp.ns_max + i0w) * kp.nt_max;
     const int ntm = kp.nt_max;
-    const int crow = max(1, min(nrows, (wbytes / 4) / ntm));                    // rows per chunk
     const bool vec4 = (ntm & 3) == 0;
-    for (int r0 = 0; r0 < nrows; r0 += crow) {
-        const int rows = min(crow, nrows - r0), nfl = rows * ntm;
-        if (vec4) for (int q4 = lane; q4 < (nfl >> 2); q4 += 64) *reinterpret_cast<float4*>(stage + 4 * q4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        else for (int q1 = lane; q1 < nfl; q1 += 64) stage[q1] = 0.f;
-        rp_wave_lds_order();
+    if (!dense) {
+        // sparse window (the usual case): item idx = lane + 64 q of the queue's two ends -> (row, target, value) in registers, then the
+        // wave's rows a few at a time through LDS: zeros, the rows' items over them, coalesced stores of the finished lines -- every
+        // 128-byte line of wij is stored exactly once
+        const int nitem = qimp + qwin;
+        int it_rj[AT2_IPL];
+        float it_v[AT2_IPL];
 #pragma unroll
         for (int q = 0; q < AT2_IPL; ++q) {
-            const int rr = (it_rj[q] >> 9) - r0;
-            if (it_rj[q] >= 0 && rr >= 0 && rr < rows) stage[rr * ntm + (it_rj[q] & 511)] = it_v[q];
+            const int idx = lane + 64 * q;
+            const bool act = idx < nitem;
+            const int slot = act ? (idx < qimp ? idx : AT2_CAPW - 1 - (idx - qimp)) : 0;
+            const int item = queue[slot];
+            const float val = window_value(item >> 9, item & 511, act ? resd[slot] : 0.f);
+            it_rj[q] = act ? (((item >> 9) << 9) | (int)perm[item & 511]) : -1;
+            it_v[q] = val;
         }
-        rp_wave_lds_order();
-        float* dst = wbase + (size_t)r0 * ntm;
-        if (vec4) for (int q4 = lane; q4 < (nfl >> 2); q4 += 64) rp_stg4(dst + 4 * q4, *reinterpret_cast<const float4*>(stage + 4 * q4));
-        else for (int q1 = lane; q1 < nfl; q1 += 64) rp_stg(dst + q1, stage[q1]);
-        rp_wave_lds_order();
+        rp_wave_lds_order();                                                     // every lane has its items: the wave's LDS area becomes the staging buffer
+        float* stage = (float*)warea;
+        const int crow = max(1, min(nrows, (wbytes / 4) / ntm));                // rows per chunk
+        for (int r0 = 0; r0 < nrows; r0 += crow) {
+            const int rows = min(crow, nrows - r0), nfl = rows * ntm;
+            if (vec4) for (int q4 = lane; q4 < (nfl >> 2); q4 += 64) *reinterpret_cast<float4*>(stage + 4 * q4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else for (int q1 = lane; q1 < nfl; q1 += 64) stage[q1] = 0.f;
+            rp_wave_lds_order();
+#pragma unroll
+            for (int q = 0; q < AT2_IPL; ++q) {
+                const int rr = (it_rj[q] >> 9) - r0;
+                if (it_rj[q] >= 0 && rr >= 0 && rr < rows) stage[rr * ntm + (it_rj[q] & 511)] = it_v[q];
+            }
+            rp_wave_lds_order();
+            float* dst = wbase + (size_t)r0 * ntm;
+            if (vec4) for (int q4 = lane; q4 < (nfl >> 2); q4 += 64) rp_stg4(dst + 4 * q4, *reinterpret_cast<const float4*>(stage + 4 * q4));
+            else for (int q1 = lane; q1 < nfl; q1 += 64) rp_stg(dst + q1, stage[q1]);
+            rp_wave_lds_order();
+        }
+        return;
+    }
+    // ---- dense window: more window entries than the queue holds.  The rows are zero-filled with coalesced stores, then the targets are
+    // swept once more and every candidate goes through a ring of 128, 64 at a time: exact distance, value, a 4-byte store over the zero
+    // (round 3's write path: partial-line stores, but a dense window means most lines are touched anyway)
+    {
+        const int nfl = nrows * ntm;
+        if (vec4) for (int q4 = lane; q4 < (nfl >> 2); q4 += 64) rp_stg4(wbase + 4 * q4, make_float4(0.f, 0.f, 0.f, 0.f));
+        else for (int q1 = lane; q1 < nfl; q1 += 64) rp_stg(wbase + q1, 0.f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the zeros of this wave have landed: same-address order
+        float fs[RP_FEAT];
+        load_source_row(fs);
+        int qhead = 0, qn = 0;                                                  // ring state (wave-uniform); slots [0, 128) of the queue
+        auto flush = [&](int count) {
+            rp_wave_lds_order();
+            const bool act = lane < count;
+            const int item = act ? queue[(qhead + lane) & 127] : 0;
+            const float d = exact_dist_item(fs, item);
+            const float val = window_value(item >> 9, item & 511, d);
+            if (act) rp_stg(wbase + (size_t)(item >> 9) * ntm + perm[item & 511], val);
+            qhead = (qhead + 64) & 127;
+        };
+        for (int T = 0; T < ntiles; T += 2) {
+            unsigned m, mi;
+            pair_masks(T, m, mi);
+            if (!rowok || redo) m = 0;
+            while (__ballot(m != 0)) {
+                int jc = INT_MAX;
+                if (m) { const int bit = __builtin_ctz(m); m &= m - 1; const int idx = 31 - bit; jc = pos_of(T + (idx >> 4), idx & 15); }
+                const bool push = jc < nt;
+                const unsigned long long bm = __ballot(push);
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+                if (push) queue[(qhead + qn + pos) & 127] = (unsigned short)((n << 9) | jc);
+                qn += __popcll(bm);
+                if (qn >= 64) { flush(64); qn -= 64; }
+            }
+        }
+        if (qn) flush(qn);
     }
 }
 

@@ -12,7 +12,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 Ns = [int(a) for a in sys.argv[3:]] or [200, 400]
 dev = torch.device("cuda", 0)
-para = rpmodule.opts(*FINAL_PARAMS["suncg"][0])
+para = rpmodule.opts(*FINAL_PARAMS[os.environ.get("RELPOSE_AFF_PARAMS", "suncg")][0])     # (scannet: sigmaFeat 0.0115 -> a dense wij window)
 if os.environ.get("RELPOSE_AFF_SEL"):          # A/B: force a kernel variant (relpose_set_tuning) for the whole run
     from relativepose_amd import _lib
     _lib.lib().relpose_set_tuning(_lib.TUNE_KEYS["affinity_kernel"], _lib.AFFINITY_KERNELS[os.environ["RELPOSE_AFF_SEL"]])
