@@ -255,7 +255,9 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
  * channels (7+S:), evaluation.py:246-253 / rpmodule.py:629-636 -- and skip the decoder branches that feed nothing else (deconv3/2/1 of the
  * rgb and semantic heads, mymodel.py:312-316,364-368); channels 0:3 and 7:7+S of `out` are written as zeros, the other channels are
  * bitwise those of the full forward.  Opt-in for callers that only want poses; never the default. */
-enum { RELPOSE_FWD_ZERO_WARP = 1, RELPOSE_FWD_POSE_OUTPUTS = 2 };
+/* RELPOSE_FWD_NEW_WORKSPACE (relpose_scnet_forward4): the caller (re)allocated the workspace since its last forward -- possibly at the
+ * same address --: whatever self-stream cache the library associates with the pointer is dropped before this forward. */
+enum { RELPOSE_FWD_ZERO_WARP = 1, RELPOSE_FWD_POSE_OUTPUTS = 2, RELPOSE_FWD_NEW_WORKSPACE = 4 };
 int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
                            void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags);
 /* relpose_scnet_forward3 with a self-stream cache.  Inside one scan pair's recurrence (evaluation.py:217-242) the masked own views --

@@ -2893,11 +2893,12 @@ int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_
 int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                            size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags, uint64_t self_tag) {
     if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0 || n >= (1 << 24)) return RELPOSE_EINVAL;
-    if (flags & ~(RELPOSE_FWD_ZERO_WARP | RELPOSE_FWD_POSE_OUTPUTS)) return RELPOSE_EINVAL;
+    if (flags & ~(RELPOSE_FWD_ZERO_WARP | RELPOSE_FWD_POSE_OUTPUTS | RELPOSE_FWD_NEW_WORKSPACE)) return RELPOSE_EINVAL;
     const int G = n / 2;
     // (nothing to share with one BatchNorm group; the tile kernels' patch pairing wants the 2-image members' patch count even as well)
     const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2;
     const bool pose_only = (flags & RELPOSE_FWD_POSE_OUTPUTS) != 0;
+    if (flags & RELPOSE_FWD_NEW_WORKSPACE) net->self_state.erase(workspace);      // the memory behind this pointer is not what the last forward left
     // Self-stream cache: the previous forward on this workspace carried the same non-zero tag (and shape) -> the self-view encoder
     // streams it left in the workspace are what this forward would compute.  Anything else runs (and re-fills) them.
     bool self_cached = false;

@@ -127,7 +127,8 @@ class SCNet(torch.nn.Module):
             raise RuntimeError("relpose_scnet_workspace_bytes: invalid shape (n must be even) or weights not loaded")
         key = (torch.cuda.current_stream().cuda_stream if ws_key is None else ("key", ws_key), n, dev.index)
         ws = self._wss.pop(key, None)                      # (re-inserted below: the dict keeps least-recently-used order)
-        if ws is None or ws.numel() < nbytes:
+        self._ws_new = ws is None or ws.numel() < nbytes   # a fresh allocation (maybe at a recycled address): forward tells the library
+        if self._ws_new:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             while len(self._wss) >= self.MAX_WORKSPACES:
                 # evict ONE entry, the least recently used.  Dropping it is stream-safe: every stream that ever ran a kernel on a
@@ -175,7 +176,7 @@ class SCNet(torch.nn.Module):
         s0 = _lib.stream_ptr()
         rc = _lib.lib().relpose_scnet_forward4(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), s0,
                                                s0 if tail_stream is None else C.c_void_p(tail_stream.cuda_stream),
-                                               (1 if zero_warp else 0) | {"all": 0, "pose": 2}[outputs], int(self_tag))
+                                               (1 if zero_warp else 0) | {"all": 0, "pose": 2}[outputs] | (4 if self._ws_new else 0), int(self_tag))
         _lib.check(rc, "relpose_scnet_forward")
         return out
 

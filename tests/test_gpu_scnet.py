@@ -235,6 +235,16 @@ def test_scnet_self_stream_cache_is_bitwise_the_full_forward(prec):
     # a fresh workspace (another batch size) whose first forward already carries a known tag
     y2 = net.forward(xb[:2].contiguous(), self_tag=t3)
     assert torch.equal(y2, refb[0][:2])
+    # the workspace is dropped and re-created at a recycled address with other contents: the tag must not be trusted (RELPOSE_FWD_NEW_WORKSPACE)
+    t5 = net.new_self_tag()
+    same(fwd(x1, self_tag=t5), ref1, "fill before the workspace is dropped")
+    nbytes = net._ws.numel()
+    net._wss.clear(); net._ws = None
+    poison = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda")       # NaN patterns where the cache was
+    torch.cuda.synchronize()
+    del poison
+    same(fwd(x2, self_tag=t5), ref2, "same tag on a re-created workspace: full forward")
+    same(fwd(x1, self_tag=t5), ref1, "and cached again afterwards")
     log("scnet_self_stream_cache", prec=prec, images=int(xa.shape[0]), bitwise=True)
 
 
