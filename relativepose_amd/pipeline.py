@@ -240,6 +240,11 @@ class RelativePosePipeline:
         x[:, :8].copy_(view)
         # a fresh name for this content of channels 0:8 (whoever finds the same tag on its workspace may reuse the self-view streams)
         st["self_tag"] = self.net.new_self_tag() if self.self_stream_cache else 0
+        # the network output of this batch, reused by every level and every pass (a torch.empty per level is 1.4 GB at 160x640 and 5.7 GB at
+        # 320x1280: blocks that the caching allocator cannot always recycle in time across streams -> hipMalloc inside the loop)
+        f = st.get("f")
+        if f is None or f.shape[1] != self.net.out_channels:
+            st["f"] = torch.empty(2 * B, self.net.out_channels, h, 4 * h, dtype=torch.float32, device=view.device)
         return x
 
     def _run_gen(self, st):
@@ -263,20 +268,19 @@ class RelativePosePipeline:
                     # the convolutions on the SCNet stream, the HBM-bound tail (heads + resize, 1.9 ms) on this batch's own stream: the
                     # SCNet stream goes straight on to the other batch's forward, whose MFMA-bound convs overlap this tail.  Overlapping
                     # forwards need separate workspaces: one per stream (= per in-flight slot).
-                    f = torch.empty(x.shape[0], self.net.out_channels, x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+                    f = st["f"]
                     with torch.cuda.stream(ns):
                         self.net.forward(x, out=f, tail_stream=ms, ws_key=ms.cuda_stream, zero_warp=(step == 0), outputs=self.outputs,
                                          self_tag=st["self_tag"])
                 else:
                     with torch.cuda.stream(ns):
-                        f = self.net.forward(x, zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"])
+                        f = self.net.forward(x, out=st["f"], zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"])
                         done = torch.cuda.Event()
                         done.record()
                     ms.wait_event(done)
-                    f.record_stream(ms)        # allocated under the net stream, consumed on the batch stream
                 yield                                            # one yield per level: the other batches enqueue theirs
             else:
-                f = self.net.forward(x, zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"])
+                f = self.net.forward(x, out=st["f"], zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"])
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
                                                     self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
