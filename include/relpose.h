@@ -160,6 +160,11 @@ int relpose_warp(const float* view, const double* pose, float* out, void* worksp
  * warped by pose[i] -- i.e. torch.cat((view, warping(other, pose)), 1) without materialising `other`
  * or the concatenation.  Same workspace as relpose_warp. */
 int relpose_warp_pairs(float* x, const double* pose, void* workspace, int32_t n, int32_t h, int32_t dataset, void* stream);
+/* The same with flags.  RELPOSE_WARP_KEYS_CLEAN: the first 4 n h 4h bytes of the workspace (the per-pixel winner keys of the scatter
+ * pass) are all zeros -- true for a workspace that was zero-initialised once and has only been used by relpose_warp / relpose_warp_pairs*
+ * since: every call resets the keys it consumed.  The 26 MB memset in front of the scatter pass (64 panoramas) is then skipped. */
+enum { RELPOSE_WARP_KEYS_CLEAN = 1 };
+int relpose_warp_pairs2(float* x, const double* pose, void* workspace, int32_t n, int32_t h, int32_t dataset, int32_t flags, void* stream);
 
 /* np.linalg.inv of n 4x4 poses (evaluation.py:235). */
 int relpose_pose_inverse(const double* pose, double* inv, int32_t n, void* stream);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "relpose_warp_workspace_bytes": (c_size_t, [c_int, c_int]),
     "relpose_warp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "relpose_warp_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "relpose_warp_pairs2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "relpose_pose_inverse": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "relpose_sample_primitives": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -185,8 +185,10 @@ __global__ void warp_scatter_kernel(const float* __restrict__ view, const double
     }
 }
 
-// pass 2: every output pixel gathers from the winning point.
-__global__ void warp_gather_kernel(const float* view, const double* __restrict__ pose, const int* __restrict__ keys,
+// pass 2: every output pixel gathers from the winning point -- and resets the key it consumed, so that the key image is all zeros
+// again when the call returns (a caller that keeps its workspace never needs the 4 n h 4h-byte memset in front of the scatter pass:
+// relpose_warp_pairs2 with RELPOSE_WARP_KEYS_CLEAN).
+__global__ void warp_gather_kernel(const float* view, const double* __restrict__ pose, int* __restrict__ keys,
                                    float* out, int n, int h, int dataset, WarpSrc s, size_t vstride, int swap, size_t ostride) {
     const int img = blockIdx.y;
     const double* T = pose + (size_t)img * 16;
@@ -198,6 +200,7 @@ __global__ void warp_gather_kernel(const float* view, const double* __restrict__
         float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int key = ident ? 0 : keys[(size_t)img * hw + pix];
         if (key > 0) {
+            keys[(size_t)img * hw + pix] = 0;
             const int p = key - 1;
             double q[3]; int py, px;
             warp_point(vw, T, h, dataset, s, p, q, py, px);
@@ -515,10 +518,10 @@ int relpose_pano2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, i
 size_t relpose_warp_workspace_bytes(int32_t n, int32_t h) { return (n <= 0 || h <= 0) ? 0 : rp_align((size_t)n * h * 4 * h * 4); }
 
 static int launch_warp(const float* view, size_t vstride, int swap, const double* pose, float* out, size_t ostride, void* workspace,
-                       int32_t n, int32_t h, int32_t dataset, hipStream_t s) {
+                       int32_t n, int32_t h, int32_t dataset, hipStream_t s, bool keys_clean = false) {
     const size_t hw = (size_t)h * 4 * h;
     int* keys = (int*)workspace;
-    RP_HIP(hipMemsetAsync(keys, 0, (size_t)n * hw * 4, s));
+    if (!keys_clean) RP_HIP(hipMemsetAsync(keys, 0, (size_t)n * hw * 4, s));
     const WarpSrc src = warp_src(dataset, h);
     hipLaunchKernelGGL(warp_scatter_kernel, dim3((src.npts + 255) / 256, n), dim3(256), 0, s, view, pose, keys, n, h, dataset, src, vstride,
                        swap);
@@ -539,6 +542,12 @@ int relpose_warp_pairs(float* x, const double* pose, void* workspace, int32_t n,
     if (!x || !pose || !workspace || n <= 0 || (n & 1) || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
     const size_t hw = (size_t)h * 4 * h;
     return launch_warp(x, 16 * hw, 1, pose, x + 8 * hw, 16 * hw, workspace, n, h, dataset, (hipStream_t)stream);
+}
+
+int relpose_warp_pairs2(float* x, const double* pose, void* workspace, int32_t n, int32_t h, int32_t dataset, int32_t flags, void* stream) {
+    if (!x || !pose || !workspace || n <= 0 || (n & 1) || h <= 0 || dataset < 0 || dataset > 2 || (flags & ~RELPOSE_WARP_KEYS_CLEAN)) return RELPOSE_EINVAL;
+    const size_t hw = (size_t)h * 4 * h;
+    return launch_warp(x, 16 * hw, 1, pose, x + 8 * hw, 16 * hw, workspace, n, h, dataset, (hipStream_t)stream, (flags & RELPOSE_WARP_KEYS_CLEAN) != 0);
 }
 
 int relpose_pose_inverse(const double* pose, double* inv, int32_t n, void* stream) {

@@ -59,7 +59,7 @@ def warping_dev(view, pose, dataset, out=None):
     key = (view.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _warp_ws.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=view.device)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=view.device)       # (zeros: every warp call leaves its keys reset, see warp_pairs_dev)
         _warp_ws[key] = ws
     if out is None:
         out = torch.empty_like(view)
@@ -79,10 +79,11 @@ def warp_pairs_dev(x, pose, dataset):
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _warp_ws.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
         _warp_ws[key] = ws
-    rc = L.relpose_warp_pairs(_lib.ptr(x), _lib.ptr(pose), _lib.ptr(ws), n, h, dataset_id(dataset), _lib.stream_ptr())
-    _lib.check(rc, "relpose_warp_pairs")
+    # the workspace was zero-initialised and every call resets the keys it consumed: no memset in front of the scatter pass
+    rc = L.relpose_warp_pairs2(_lib.ptr(x), _lib.ptr(pose), _lib.ptr(ws), n, h, dataset_id(dataset), 1, _lib.stream_ptr())
+    _lib.check(rc, "relpose_warp_pairs2")
     return x
 
 
