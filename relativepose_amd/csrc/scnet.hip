@@ -2423,8 +2423,14 @@ void Builder::end_group() {
         }
         if (!no_auto128 && !u256 && u128 && (cfg == 1 || cfg == 2)) cfg = cfg == 1 ? 4 : 5;
     }
-    int BMt = (cfg == 0 || cfg >= 4) ? 128 : 256;
-    const int BNt = cfg == 6 ? 256 : ((cfg == 0 || cfg == 3) ? 128 : cp);
+    // 7 = 64 x 64 tiles (2 x 2 waves of one 32 x 32 block) for the bottleneck layers (conv7-9, deconv9-7: <= 1024 output rows at the
+    // nominal batch): with 128 x 128 tiles they have 1-9 M tiles and are split 64-128 ways along K -- 3 k-tiles per workgroup, 75 MB
+    // of partial sums per layer for the reduce pass to add up; 64 x 64 tiles give 4x the tiles, an 8x smaller split and partial buffer
+    static const bool no_small = RP_ENV("RELPOSE_NO_TILE64") != nullptr;
+    const bool small = !no_small && cfg == 0 && big_m <= 1024 && cp % 64 == 0;
+    if (small) cfg = 7;
+    int BMt = cfg == 7 ? 64 : ((cfg == 0 || cfg >= 4) ? 128 : 256);
+    const int BNt = cfg == 7 ? 64 : (cfg == 6 ? 256 : ((cfg == 0 || cfg == 3) ? 128 : cp));
     // Fused-phase kernel (deconv_tile_kernel): the 4 phases of stride-2 4x4 transposed convs with Cout 32 / 64 whose input grid
     // tiles into 16 x 16 (Cout 32) / 8 x 16 (Cout 64) patches -- deconv2 (112 x 112); fp32 products only.
     bool dtile = false;
@@ -2486,7 +2492,10 @@ void Builder::end_group() {
     }
     // split along K until the launch has >= ~3000 tiles (>= 4 waves of resident blocks), keeping >= 8 k-tiles per slice
     int ksplit = 1;
-    while (!dtile && s2_cfg < 0 && tiles * ksplit < 3000 && ksplit < 64 && min_kt / (ksplit * 2) >= 8) ksplit *= 2;
+    // (64 x 64 tiles: ~2 workgroups per CU are enough -- these launches are latency-bound chains, not throughput -- with >= 16 k-tiles each)
+    const long want_tiles = cfg == 7 ? 2048 : 3000;
+    const int min_slice = 8;
+    while (!dtile && s2_cfg < 0 && tiles * ksplit < want_tiles && ksplit < 64 && min_kt / (ksplit * 2) >= min_slice) ksplit *= 2;
     if (force_ksplit && !dtile && s2_cfg < 0) ksplit = force_ksplit;
     size_t pf = 0;
     for (int i = first; i < first + count; ++i) {
@@ -2586,7 +2595,7 @@ void Builder::end_group() {
         const ConvDesc& d = plan->descs[i];
         const int hw = d.Hp * d.Wp;
         const int ng = (BMt - 1) / (2 * hw) + 2;
-        if ((long)ng * d.Cin > ((cfg == 0 || cfg == 3 || cfg == 6) ? 2048 : 512) || d.src[0].sstride == 0) o.sslds = 0;
+        if ((long)ng * d.Cin > ((cfg == 0 || cfg == 3 || cfg == 6 || cfg == 7) ? 2048 : 512) || d.src[0].sstride == 0) o.sslds = 0;
         if ((2 * hw) % BMt) o.uni = 0;             // some tile would straddle two BatchNorm groups
     }
     if (!o.sslds) o.uni = 0;
@@ -3004,6 +3013,7 @@ int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_
             else if (op.cfg == 2) RP_LAUNCH_T(4, 1, 2, 1);
             else if (op.cfg == 4) RP_LAUNCH_T(4, 1, 1, 2);
             else if (op.cfg == 6) RP_LAUNCH_T(2, 2, 2, 4);
+            else if (op.cfg == 7) RP_LAUNCH_T(2, 2, 1, 1);
             else RP_LAUNCH_T(4, 1, 1, 1);
 #undef RP_LAUNCH_T
 #undef RP_LAUNCH_V
