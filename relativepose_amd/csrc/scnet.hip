@@ -1591,6 +1591,10 @@ struct HeadsDesc {
     const float* d2; const float* a1; const float2* ss_d2; const float2* ss_a1;
     const float* w; const float* bias; float* out;
     int n, S, cf, use_tanh;
+    // self-stream cache: the skip source of the rgb / n / d heads (the self-view blocks of A1) is level-invariant and is accumulated FIRST
+    // in every plan; snap_mode 1 stores the three heads' accumulators after it (12 floats per pixel), snap_mode 2 starts from them and
+    // does not read A1 at all (384 of the 1280 bytes a pixel reads)
+    int snap_mode; float* snap;
 };
 constexpr int HEADS_W = 4352;
 
@@ -1644,16 +1648,46 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
             }                                                                                            \
         }                                                                                                \
     }
-    // line order: [rgb: D2, A1 skip]  n: D2, A1  d: D2, A1  [s: 2 lines of D2]  f: 2 lines of D2
+    // line order: A1 skip lines of [rgb,] n, d (level-invariant: the snapshot point), then the D2 lines of [rgb,] n, d, [s: 2 lines,] f: 2 lines
     float4 xa[8], xb[8];
     constexpr int M0 = POSE ? 1 : 0;
-    RP_HEAD_LOAD(xa, pd + M0 * 32)
+    float4* snp = reinterpret_cast<float4*>(hd.snap) + pix * 3;
+    // (two register sets, strictly alternating: a line's NEXT load goes to the set the line does not read)
+#define RP_HEAD_SKIP(X8, NEXT, M_) RP_HEAD_LINE(X8, NEXT, 224 + (M_) * 32, (96 + (M_) * 32) * 4, 4, 1, a3, (M_) * 4)
+#define RP_HEAD_D2(X8, NEXT, M_) RP_HEAD_LINE(X8, NEXT, (M_) * 32, ((M_) * 32) * 4, 4, 1, a3, (M_) * 4)
+    if (hd.snap_mode == 2) {
 #pragma unroll
-    for (int m = M0; m < 3; ++m) {                     // rgb, n, d: 32 channels of D2 + 32 skip channels of A1
-        RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pa + m * 64), m * 32, (m * 32) * 4, 4, 1, a3, m * 4)
-        if (m < 2) { RP_HEAD_LINE(xb, RP_HEAD_LOAD(xa, pd + (m + 1) * 32), 224 + m * 32, (96 + m * 32) * 4, 4, 1, a3, m * 4) }
-        else { RP_HEAD_LINE(xb, RP_HEAD_LOAD(xa, pd + (POSE ? 160 : 96)), 224 + m * 32, (96 + m * 32) * 4, 4, 1, a3, m * 4) }
+        for (int m = 0; m < 3; ++m) {
+            const float4 v = rp_ldg4(reinterpret_cast<const float*>(snp + m));
+            a3[4 * m] = v.x; a3[4 * m + 1] = v.y; a3[4 * m + 2] = v.z; a3[4 * m + 3] = v.w;
+        }
+        if constexpr (POSE) { RP_HEAD_LOAD(xa, pd + 32) } else { RP_HEAD_LOAD(xb, pd) }
+    } else {
+        if constexpr (POSE) {
+            RP_HEAD_LOAD(xa, pa + 64)
+            RP_HEAD_SKIP(xa, RP_HEAD_LOAD(xb, pa + 128), 1)
+            RP_HEAD_SKIP(xb, RP_HEAD_LOAD(xa, pd + 32), 2)
+        } else {
+            RP_HEAD_LOAD(xa, pa)
+            RP_HEAD_SKIP(xa, RP_HEAD_LOAD(xb, pa + 64), 0)
+            RP_HEAD_SKIP(xb, RP_HEAD_LOAD(xa, pa + 128), 1)
+            RP_HEAD_SKIP(xa, RP_HEAD_LOAD(xb, pd), 2)
+        }
+        if (hd.snap_mode == 1) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) rp_stg4(reinterpret_cast<float*>(snp + m), make_float4(a3[4 * m], a3[4 * m + 1], a3[4 * m + 2], a3[4 * m + 3]));
+        }
     }
+    if constexpr (POSE) {
+        RP_HEAD_D2(xa, RP_HEAD_LOAD(xb, pd + 64), 1)
+        RP_HEAD_D2(xb, RP_HEAD_LOAD(xa, pd + 160), 2)
+    } else {
+        RP_HEAD_D2(xb, RP_HEAD_LOAD(xa, pd + 32), 0)
+        RP_HEAD_D2(xa, RP_HEAD_LOAD(xb, pd + 64), 1)
+        RP_HEAD_D2(xb, RP_HEAD_LOAD(xa, pd + 96), 2)
+    }
+#undef RP_HEAD_SKIP
+#undef RP_HEAD_D2
     if (!POSE) {
         RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 128), 96, 768, 24, 6, as_, 0)                                                // s
         RP_HEAD_LINE(xb, RP_HEAD_LOAD(xa, pd + 160), 128, 768 + 32 * 24, 24, 6, as_, 0)
@@ -2275,7 +2309,8 @@ struct Plan {
     bool pose_only = false;      // RELPOSE_FWD_POSE_OUTPUTS plan
     bool self_cached = false;    // self-stream cache plan (relpose_scnet_forward4): the self-view encoder streams are not recomputed
     size_t persist_floats = 0;   // conv4's split-K partial sums (a region of their own: the self slices outlive the forward)
-    size_t snap_floats = 0;      // accumulator snapshots of the skip-connection halves of deconv3 / deconv2 (ConvDesc::snap)
+    size_t snap_floats = 0;      // accumulator snapshots of the skip-connection halves of deconv3 / deconv2 (ConvDesc::snap) and the heads
+    size_t heads_snap_off = 0;
     int snap_mode = 0;           // 0 = plain forward, 1 = fills the snapshots (a tagged forward), 2 = self-cached forward
     std::vector<ConvDesc> descs;
     std::vector<Op> ops;
@@ -2711,7 +2746,11 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
             else R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 64), nullptr, 224, "OUT", ooff[m]);
         }
         R.end_group();
-    } else { Op o; o.type = OP_HEADS; o.first = o.count = o.cfg = 0; R.plan->ops.push_back(o); }
+    } else {
+        Op o; o.type = OP_HEADS; o.first = o.count = o.cfg = 0; R.plan->ops.push_back(o);
+        R.plan->heads_snap_off = R.plan->snap_floats;              // the heads' skip-half accumulators (HeadsDesc::snap): 12 floats per pixel
+        R.plan->snap_floats += (size_t)n * RS * RS * 12;
+    }
     (void)n;
 }
 
@@ -3089,6 +3128,7 @@ int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_
             hd.ss_d2 = ssp + net->bufs["D2"].ss_off * G; hd.ss_a1 = ssp + net->bufs["A1"].ss_off * G;
             hd.w = net->d_w + net->wh_off; hd.bias = net->d_w + net->bh_off; hd.out = act + net->bufs["OUT"].off * n;
             hd.n = n; hd.S = net->S; hd.cf = net->cf; hd.use_tanh = net->use_tanh;
+            hd.snap_mode = plan->snap_mode; hd.snap = (float*)(ws + o.snap) + plan->heads_snap_off;
             mark(1);
             const dim3 hg((unsigned)((size_t)n * RS * RS / 256));
             if (plan->pose_only) {
