@@ -671,28 +671,54 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
     // rows the other way (below) -- the important ones always have room up to the whole queue.
     int cnt = 0, qimp = 0, qwin = 0;                                            // qimp / qwin: wave-uniform
     bool over = false, dense = false;                                           // dense: wave-uniform
+    // exclusive prefix sum over the lanes of a small per-lane count (<= 32) + the wave total, from ballots of its bit planes
+    auto lane_prefix = [&](int c, int& total) {
+        int ex = 0; total = 0;
+#pragma unroll
+        for (int bpl = 0; bpl < 6; ++bpl) {
+            const unsigned long long bm = __ballot((c >> bpl) & 1);
+            if (bm) {
+                ex += (__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0))) << bpl;
+                total += __popcll(bm) << bpl;
+            }
+        }
+        return ex;
+    };
     for (int T = 0; T < ntiles; T += 2) {
         unsigned m, mi;
         pair_masks(T, m, mi);
-        while (__ballot(m != 0)) {
-            int jc = INT_MAX;
-            bool imp = false;
-            if (m) { const int bit = __builtin_ctz(m); m &= m - 1; imp = (mi >> bit) & 1u; const int idx = 31 - bit; jc = pos_of(T + (idx >> 4), idx & 15); }
-            const bool push = jc < nt;
-            const unsigned long long bi = __ballot(push && imp), bw = __ballot(push && !imp);
-            const int ni = __popcll(bi), nw = __popcll(bw);
-            if (qimp + ni + qwin + (dense ? 0 : nw) > AT2_CAPW) { dense = true; qwin = 0; }
-            if (push && imp) {
-                const int slot = qimp + __builtin_amdgcn_mbcnt_hi((unsigned)(bi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bi, 0));
-                if (slot < AT2_CAPW) queue[slot] = (unsigned short)((n << 9) | jc);
-                if (slot < AT2_CAPW && cnt < istk_cap) istk[cnt * 64 + lane] = (unsigned short)slot; else over = true;
-                ++cnt;
-            }
-            if (push && !imp && !dense)
-                queue[AT2_CAPW - 1 - (qwin + __builtin_amdgcn_mbcnt_hi((unsigned)(bw >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bw, 0)))] = (unsigned short)((n << 9) | jc);
-            qimp = min(qimp + ni, AT2_CAPW);
-            if (!dense) qwin += nw;
+        // (padding positions >= nt carry g = AT2_PADG: they only pass a threshold of -inf -- rows with fewer than K finite groups -- and are
+        // dropped here, before the slots are counted)
+        if (32 * (T + 2) > nt) {
+            unsigned vm = 0;
+#pragma unroll
+            for (int idx = 0; idx < 32; ++idx) vm = (vm << 1) | (pos_of(T + (idx >> 4), idx & 15) < nt ? 1u : 0u);
+            m &= vm;
         }
+        mi &= m;
+        // slots: the wave's important candidates of this tile pair take [qimp, qimp + ni) lane by lane, the window-only ones the next nw
+        // slots from the back; every lane then writes its own (one ballot per bit plane of the counts instead of two per candidate)
+        int ni, nw;
+        int si_ = qimp + lane_prefix(__popc(mi), ni);
+        int sw_ = lane_prefix(__popc(m & ~mi), nw);
+        if (qimp + ni + qwin + (dense ? 0 : nw) > AT2_CAPW) { dense = true; qwin = 0; }
+        sw_ += qwin;
+        while (m) {
+            const int bit = __builtin_ctz(m);
+            m &= m - 1;
+            const int idx = 31 - bit;
+            const int jc = pos_of(T + (idx >> 4), idx & 15);
+            if ((mi >> bit) & 1u) {
+                if (si_ < AT2_CAPW) queue[si_] = (unsigned short)((n << 9) | jc);
+                if (si_ < AT2_CAPW && cnt < istk_cap) istk[cnt * 64 + lane] = (unsigned short)si_; else over = true;
+                ++si_; ++cnt;
+            } else if (!dense) {
+                queue[AT2_CAPW - 1 - sw_] = (unsigned short)((n << 9) | jc);
+                ++sw_;
+            }
+        }
+        qimp = min(qimp + ni, AT2_CAPW);
+        if (!dense) qwin += nw;
     }
     rp_wave_lds_order();
     {   // the exact distances of the queued candidates, 64 at a time, one per lane whatever row they belong to
