@@ -78,9 +78,13 @@ void relpose_default_params(RelposeParams* p_host);
  *                                   forces RELPOSE_NOT_CONVERGED
  *   RELPOSE_TUNE_FIT_CLUSTER        0 = by problem size (default), n = workgroups per scan pair in the fit (1, 2, 4, 8)
  *   RELPOSE_TUNE_FIT_GLOBAL_VECTORS 0 = by problem size, 1 = keep the fit's per-correspondence vectors in global memory
- *                                   (the > 4500-correspondence layout) whatever the size */
+ *                                   (the > 4500-correspondence layout) whatever the size
+ *   RELPOSE_TUNE_FIT_FIXED_CHECKS   0 = the eigen-solve places its convergence tests where the residual estimate is predicted to
+ *                                   reach the tolerance (default), 1 = a test every 8 products (the earlier rule; A/B switch).  The
+ *                                   one knob whose settings agree to round-off only (both converge to 1e-13; the number of Lanczos
+ *                                   steps differs) */
 enum { RELPOSE_TUNE_AFFINITY_KERNEL = 0, RELPOSE_TUNE_FIT_MAX_PRODUCTS = 1, RELPOSE_TUNE_FIT_CLUSTER = 2,
-       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_COUNT = 8 };
+       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_COUNT = 8 };
 int relpose_set_tuning(int32_t key, int32_t value);
 const char* relpose_version(void);
 

@@ -366,6 +366,7 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     double* part2;              // partial sums of the products done with helper workgroups (only ever written write-through)
     double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
     int C, Cmax, nseg, tri_rounds, max_prod;
+    int fixed_checks;           // RELPOSE_TUNE_FIT_FIXED_CHECKS: convergence test every RP_LZ_CHECK steps (the round-2/3 rule; A/B switch)
     struct FitCtl* ctl;         // helper workgroups (G > 1): the pair's control block; xu = the published vectors [2][Cmax] (u, then h), part2 behind them
     double* xu;
     int G;
@@ -694,8 +695,12 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
 
 // Leading eigenvector of the pair's matrix (seg_pass MODE 1) into f.vec, starting from the unit vector already in f.vec;
 // returns the number of products.  *converged = 0 when the residual estimate stays above tolerance.
-template <int DEPTH>
-__device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
+// (out of line: the logarithms are evaluated a few times per eigen-solve and must not cost the Lanczos loop registers)
+__device__ __attribute__((noinline)) double lz_rate(double r_a, int m_a, double r_b, int m_b, double prev) { return rp_lz_rate(r_a, m_a, r_b, m_b, prev); }
+__device__ __attribute__((noinline)) int lz_steps_to_check(double r, double lrate, int max_steps) { return rp_lz_steps_to_check(r, lrate, RP_LZ_TOL, max_steps); }
+
+template <int DEPTH, int VB>    // VB: basis-vector entries a lane keeps in flight in the re-orthogonalisation (16 in the 512-thread kernel, 8 at 1024 threads: 128 VGPRs)
+__device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* lrate) {
     const int C = f.C, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     int nprod = 0;
     *converged = 1;
@@ -705,6 +710,10 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
         int m = 0;
         double beta_last = 0.0, theta = 0.0;
         bool done = false;
+        // where the next convergence test goes (rp_lz_steps_to_check in rp_math.h; every thread computes the same numbers from the
+        // same LDS values): (m_a, r_a) = the last data point of the relative residual estimate
+        int next_check = RP_LZ_CHECK, m_a = 0;
+        double r_a = 0.0;
         for (int j = 0; j < RP_LZ_M && !done; ++j) {
             long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
             if (f.G > 1 && f.epoch[3] == 0) fit_dist_product<DEPTH>(f, f.yy, (int*)(f.epoch + 2));     // yy = A v_j with the helper workgroups
@@ -718,12 +727,12 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 for (int i = wave; i <= j; i += nw) {
                     const double* vi = f.V + (size_t)i * f.Cmax;
                     double d = 0.0;
-                    for (int c0 = lane; c0 < C; c0 += 64 * 8) {           // 8 loads in flight, then accumulated in order
-                        double v8[8];
+                    for (int c0 = lane; c0 < C; c0 += 64 * VB) {          // VB loads in flight (one L2 round trip for C <= 1024 with VB = 16), then accumulated in order
+                        double v8[VB];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v8[q] = (c0 + 64 * q < C) ? rp_ldg(vi + c0 + 64 * q) : 0.0;
+                        for (int q = 0; q < VB; ++q) v8[q] = (c0 + 64 * q < C) ? rp_ldg(vi + c0 + 64 * q) : 0.0;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) if (c0 + 64 * q < C) d += v8[q] * f.yy[c0 + 64 * q];
+                        for (int q = 0; q < VB; ++q) if (c0 + 64 * q < C) d += v8[q] * f.yy[c0 + 64 * q];
                     }
                     d = rp_wave_sum(d);
                     if (lane == 0) f.cbuf[i] = d;
@@ -732,6 +741,28 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 if (pass == 0) for (int c = tid; c < C; c += blockDim.x) nn[0] += f.yy[c] * f.yy[c];
                 __syncthreads();
                 alpha += f.cbuf[j];
+                if constexpr (VB == 16) {
+                    // two entries of the vector per thread at a time, 8 basis vectors' entries of each in flight (the same sums in the
+                    // same order as below; half the L2 round trips)
+                    for (int c = tid; c < C; c += 2 * blockDim.x) {
+                        const int c2 = c + blockDim.x;
+                        const bool two = c2 < C;
+                        double acc = f.yy[c], acc2 = two ? f.yy[c2] : 0.0;
+                        for (int i0 = 0; i0 <= j; i0 += 8) {
+                            double v8[8], w8[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                v8[q] = (i0 + q <= j) ? rp_ldg(f.V + (size_t)(i0 + q) * f.Cmax + c) : 0.0;
+                                w8[q] = (two && i0 + q <= j) ? rp_ldg(f.V + (size_t)(i0 + q) * f.Cmax + c2) : 0.0;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) if (i0 + q <= j) { acc -= f.cbuf[i0 + q] * v8[q]; acc2 -= f.cbuf[i0 + q] * w8[q]; }
+                        }
+                        f.yy[c] = acc;
+                        nn[1] += acc * acc;
+                        if (two) { f.yy[c2] = acc2; nn[1] += acc2 * acc2; }
+                    }
+                } else
                 for (int c = tid; c < C; c += blockDim.x) {
                     double acc = f.yy[c];
                     for (int i0 = 0; i0 <= j; i0 += 8) {                   // 8 basis vectors' entries in flight
@@ -762,7 +793,11 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; rp_stg(vn + c, v); f.vec[c] = v; }
             }
             __syncthreads();
-            if (invariant || m == RP_LZ_M || (m % RP_LZ_CHECK) == 0) {
+            if (j == 0 && !f.fixed_checks) {                                       // the start vector's own residual: free
+                r_a = beta / fabs(alpha); m_a = 1;
+                next_check = (r_a <= RP_LZ_TOL) ? 1 : 1 + lz_steps_to_check(r_a, *lrate, RP_LZ_CHECK - 1);
+            }
+            if (invariant || m == RP_LZ_M || m == next_check || nprod >= f.max_prod) {
                 // Ritz pair of the m x m tridiagonal matrix, residual estimate beta_m |s_m|
                 long long t2_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
                 if (wave == 0) {
@@ -776,6 +811,12 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged) {
                 if (invariant || m == RP_LZ_M || resid <= RP_LZ_TOL * fabs(theta) || nprod >= f.max_prod) {
                     done = true;
                     if (resid <= RP_LZ_TOL * fabs(theta)) beta_last = 0.0;         // flag: converged
+                } else if (f.fixed_checks) next_check = m + RP_LZ_CHECK;
+                else {
+                    const double r_b = resid / fabs(theta);
+                    *lrate = lz_rate(r_a, m_a, r_b, m, *lrate);
+                    r_a = r_b; m_a = m;
+                    next_check = m + lz_steps_to_check(r_b, *lrate, RP_LZ_CHECK);
                 }
                 __syncthreads();
             }
@@ -1020,6 +1061,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     f.prof = prof;
     f.tri_rounds = tri_rounds & 0xff;
     f.max_prod = (tri_rounds >> 8) & 0xffff;
+    f.fixed_checks = (tri_rounds >> 24) & 1;
     const long long tstart_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     f.C = C; f.Cmax = g.Cmax;
     f.ctl = ctl; f.xu = xu_all + (size_t)b * (2 * (size_t)g.Cmax + g.seg_cap); f.part2 = f.xu + 2 * (size_t)g.Cmax; f.G = G; f.epoch = &cl_s[0];
@@ -1078,12 +1120,13 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
         const bool sm = (method == RELPOSE_FIT_IRLS_SM);
         const double u0 = 1.0 / sqrt((double)C);
         for (int c = tid; c < C; c += blockDim.x) f.vec[c] = u0;          // round 0 starts from the uniform vector
+        double lrate = 0.0;                                                // decay of the residual estimate per Lanczos step (log), carried from round to round; 0 = not known yet
         for (int round = 0; round < 5; ++round) {
             for (int c = tid; c < C; c += blockDim.x) { const double v = RP_OFFSET - fc.rsum[c]; f.hh[c] = v < 0.0 ? 0.0 : v; }
             __syncthreads();
             if (G > 1) fit_publish_h(f);
             int conv = 1;
-            const int np = lanczos_top<DEPTH>(f, (!sm && round > 0) ? kc.mu : 0.0, &conv);       // rounds > 0: warm start from f.vec
+            const int np = lanczos_top<DEPTH, (THREADS == 512 ? 16 : 8)>(f, (!sm && round > 0) ? kc.mu : 0.0, &conv, &lrate);       // rounds > 0: warm start from f.vec
             all_converged &= conv;
             if (eig_iters_out && tid == 0) eig_iters_out[b * 5 + round] = np;
             long long tf_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -1243,7 +1286,8 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
         }
         // (multisection rounds | product budget << 8); RELPOSE_TUNE_FIT_MAX_PRODUCTS is a test hook: a tiny budget forces RELPOSE_NOT_CONVERGED
         const int tri_rounds = (RP_ENV("RELPOSE_TRI_ROUNDS") ? atoi(RP_ENV("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS) |
-                               ((g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] > 0 ? g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] : RP_LZ_MAXPROD) << 8);
+                               ((g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] > 0 ? g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] : RP_LZ_MAXPROD) << 8) |
+                               ((g_rp_tune[RELPOSE_TUNE_FIT_FIXED_CHECKS] != 0 ? 1 : 0) << 24);
         // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences,
         // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 1024 overrides (experiments build).
         const int fit_threads = RP_ENV("RELPOSE_FIT_THREADS") ? atoi(RP_ENV("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);

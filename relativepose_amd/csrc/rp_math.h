@@ -45,6 +45,28 @@ RP_HD int rp_fit_chunk_size(int nseg, int G) { const int c = ((nseg + G) / (G + 
 RP_HD int rp_fit_chunk_count(int nseg, int csz) { const int r = (nseg - 2 * csz + csz - 1) / csz; return 1 + (r < 0 ? 0 : r); }
 RP_HD int rp_fit_chunk_begin(int ch, int csz) { return ch == 0 ? 0 : (ch + 1) * csz; }
 
+// Placement of the Lanczos convergence tests (matcher.hip, lanczos_top).  A test (tridiagonal eigen-solve on one wave) costs about
+// half a {product, re-orthogonalisation} step and a step taken after convergence a whole one, so instead of testing every 8th step
+// (3.5 wasted steps per eigen-solve on average) the next test goes where the relative residual estimate r = beta_m |s_m| / |theta| is
+// predicted to cross the tolerance, assuming geometric decay at the rate between the last two data points (the first data point,
+// after step 1, is free: beta_1 / |alpha_1|; the rate carries over from the previous eigen-solve of the same scan pair, whose matrix
+// differs only by the reweighting).  Convergence accelerates, so the prediction errs late: 0.85 of the predicted distance.
+//   rp_lz_rate: log of the decay per step from (m_a, r_a) -> (m_b, r_b), clamped to [-12, -0.05]; `prev` when the points carry no information
+//   rp_lz_steps_to_check: steps from the last data point to the next test, 1..max_steps (lrate >= 0: unknown -> max_steps)
+RP_HD double rp_lz_rate(double r_a, int m_a, double r_b, int m_b, double prev) {
+    if (!(r_a > 0.0) || !(r_b > 0.0) || !(r_b < r_a) || !(r_a < 1e300) || m_b <= m_a) return prev;
+    const double lr = log(r_b / r_a) / (double)(m_b - m_a);
+    return lr > -0.05 ? -0.05 : (lr < -12.0 ? -12.0 : lr);
+}
+RP_HD int rp_lz_steps_to_check(double r, double lrate, double tol, int max_steps) {
+    if (!(lrate < 0.0) || !(r > 0.0) || !(r < 1e300)) return max_steps;
+    if (!(r > tol)) return 1;
+    const double n = 0.85 * (log(tol / r) / lrate);
+    if (!(n < (double)max_steps)) return max_steps;
+    const int k = (int)n;
+    return k < 1 ? 1 : k;
+}
+
 RP_HD double rp_norm3(double x, double y, double z) { return sqrt((x * x + y * y) + z * z); }
 RP_HD double rp_dot3(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 RP_HD double rp_clip1(double v) { return v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v); }   // NaN stays NaN

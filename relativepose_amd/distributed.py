@@ -37,8 +37,11 @@ def peer_access_summary():
     """hipDeviceCanAccessPeer over the visible GPUs (one node: xGMI links make every pair peer-accessible): {"gpus", "peer_pairs",
     "peer_accessible"} -- the pose all_gather runs over those links; reported in the bench line, not relied upon."""
     import torch
-    n = torch.cuda.device_count()
-    ok = sum(1 for i in range(n) for j in range(n) if i != j and torch.cuda.can_device_access_peer(i, j))
+    try:        # diagnostic only: a runtime that refuses the query must not take the bench line down with it
+        n = torch.cuda.device_count()
+        ok = sum(1 for i in range(n) for j in range(n) if i != j and torch.cuda.can_device_access_peer(i, j))
+    except Exception as e:      # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
     return {"gpus": n, "peer_pairs": n * (n - 1), "peer_accessible": ok}
 
 

@@ -72,6 +72,31 @@ def test_fit_helper_workgroups_change_nothing(G):
     assert int(one.status[3]) == 1 and int((one.status == 0).sum()) >= 4
 
 
+def test_predicted_convergence_tests_save_products_not_accuracy():
+    """The eigen-solve places its convergence tests where the residual estimate is predicted to reach the tolerance
+    (rp_lz_steps_to_check, csrc/rp_math.h; host model in tests/test_host_math.py) instead of every 8th product
+    (relpose_set_tuning(RELPOSE_TUNE_FIT_FIXED_CHECKS, 1) = the earlier rule): same status, the pose after every alternation equal to
+    round-off (both rules stop at a residual estimate <= 1e-13), no pair with more products, clearly fewer in total."""
+    import torch
+    from relativepose_amd import _lib, rpmodule
+    cases = [synth.make_match_case(n, 900 + n + int(100 * i), inlier=i)[:2] for n, i in ((200, 0.6), (200, 0.3), (200, 0.1), (400, 0.3), (120, 0.5), (300, 0.2), (64, 0.4), (2, 0.6))]
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.009)
+    with _lib.tuning(fit_fixed_checks=1):
+        fixed = _run(cases, para, debug=True)
+    pred = _run(cases, para, debug=True)
+    again = _run(cases, para, debug=True)
+    assert torch.equal(pred.pose, again.pose) and torch.equal(pred.eig_iters, again.eig_iters)
+    assert torch.equal(pred.status, fixed.status)
+    ok = (pred.status == 0).cpu().numpy()
+    assert ok.sum() >= 6
+    d = (pred.trace - fixed.trace).abs().reshape(len(cases), -1).max(1).values.cpu().numpy()
+    pf, pp = fixed.eig_iters.cpu().numpy(), pred.eig_iters.cpu().numpy()
+    log("fit_predicted_checks", products_fixed=pf[ok].sum(0).tolist(), products_predicted=pp[ok].sum(0).tolist(), trace_max_diff=float(d[ok].max()))
+    assert d[ok].max() < 1e-9
+    assert (pp[ok].sum(1) <= pf[ok].sum(1)).all()              # no pair pays for it ...
+    assert pp[ok].sum() <= 0.92 * pf[ok].sum()                  # ... and the batch saves clearly (about a fifth on the bench's graphs)
+
+
 def test_thousand_keypoints_fit_converges_and_matches_reference(golden_dir):
     """N = 1000 keypoints per view: 5000 correspondences (more than the fit's LDS layout holds: vectors in global scratch), 12.5 M
     candidate pairs.  The same Lanczos solver with the same residual test runs there -- status 0 means CONVERGED -- and the pose equals

@@ -30,6 +30,8 @@ void t_horn_fast(const double* M, double* R) { double m[3][3], r[3][3]; for(int 
 void t_div100(const float* x, float* out, int* ok, int n) { for (int i = 0; i < n; ++i) { out[i] = rp_div100_fast(x[i]); ok[i] = rp_div100_ok(x[i]) ? 1 : 0; } }
 void t_chunks(int nseg, int G, int* out) { const int c = rp_fit_chunk_size(nseg, G); out[0] = c; out[1] = rp_fit_chunk_count(nseg, c);
     for (int k = 0; k <= out[1] && k < 62; ++k) out[2 + k] = rp_fit_chunk_begin(k, c); }
+double t_lz_rate(double ra, int ma, double rb, int mb, double prev) { return rp_lz_rate(ra, ma, rb, mb, prev); }
+int t_lz_steps(double r, double lrate, double tol, int mx) { return rp_lz_steps_to_check(r, lrate, tol, mx); }
 int t_eig4_fast(const double* N, double* q) { double n[4][4]; for(int i=0;i<16;++i) n[i/4][i%4]=N[i]; return rp_sym4_max_eigvec_fast(n, q); }
 }
 '''
@@ -185,3 +187,102 @@ def test_fit_chunk_geometry_covers_every_segment_once(shim):
         assert begins[cnt] >= nseg                            # ... and reaches the end (the kernel clamps it to nseg)
         if nseg >= 64 * (G + 1):
             assert cnt <= G, (nseg, G, csz, cnt)              # everybody there: one chunk each
+
+
+def _lanczos_products(A, v0, shim, adaptive, lrate, tol=1e-13, basis=24, every=8):
+    """numpy model of csrc/matcher.hip lanczos_top (full re-orthogonalisation, restart from the Ritz vector at `basis` steps) with the
+    convergence tests placed by rp_lz_steps_to_check / rp_lz_rate (adaptive) or every 8th step; returns (eigenvector, products, tests, lrate)."""
+    nprod = ntest = 0
+    vec = v0.copy()
+    while True:
+        V, al, be = [vec], [], []
+        conv = False
+        nxt, m_a, r_a = every, 0, 0.0
+        for j in range(basis):
+            y = A @ V[j]
+            nprod += 1
+            alpha = 0.0
+            for _ in range(2):
+                c = np.array([v @ y for v in V])
+                nb = y @ y
+                y = y - sum(ci * v for ci, v in zip(c, V))
+                alpha += c[j]
+                if y @ y > 0.25 * nb:
+                    break
+            beta = float(np.sqrt(y @ y))
+            al.append(alpha)
+            be.append(beta)
+            m = j + 1
+            inv = not (beta > 1e-14 * (abs(alpha) + beta))
+            if not inv and m < basis:
+                V.append(y / beta)
+            if j == 0 and adaptive:
+                r_a, m_a = beta / abs(alpha), 1
+                nxt = 1 if r_a <= tol else 1 + shim.t_lz_steps(r_a, lrate, tol, every - 1)
+            if inv or m == basis or m == nxt:
+                ntest += 1
+                T = np.diag(al) + np.diag(be[:m - 1], 1) + np.diag(be[:m - 1], -1)
+                w, S = np.linalg.eigh(T)
+                th, sv = w[-1], S[:, -1]
+                resid = 0.0 if inv else beta * abs(sv[m - 1])
+                if inv or m == basis or resid <= tol * abs(th):
+                    conv = resid <= tol * abs(th)
+                    break
+                if adaptive:
+                    r_b = resid / abs(th)
+                    lrate = shim.t_lz_rate(r_a, m_a, r_b, m, lrate)
+                    r_a, m_a = r_b, m
+                    nxt = m + shim.t_lz_steps(r_b, lrate, tol, every)
+                else:
+                    nxt = m + every
+        vec = sum(si * v for si, v in zip(sv, V[:m]))
+        vec /= np.linalg.norm(vec)
+        if conv or nprod > 190:
+            return vec, nprod, ntest, lrate
+
+
+def test_lanczos_check_placement_never_costs_products(shim):
+    """rp_lz_steps_to_check / rp_lz_rate (the placement of the eigen-solve's convergence tests): on sequences of slowly changing
+    nonnegative sparse matrices with small and large spectral gaps (warm-started like the fit's five rounds) the predicted placement
+    converges to the same eigenvector as the test-every-8th-step rule, never with more products, with clearly fewer in total, and
+    with a bounded number of extra tests.  Edge cases of the two functions: no information -> the fixed interval; converged -> test now."""
+    shim.t_lz_rate.restype = C.c_double
+    shim.t_lz_rate.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int, C.c_double]
+    shim.t_lz_steps.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
+    assert shim.t_lz_steps(1e-3, 0.0, 1e-13, 8) == 8 and shim.t_lz_steps(float("nan"), -1.0, 1e-13, 8) == 8
+    assert shim.t_lz_steps(float("inf"), -1.0, 1e-13, 8) == 8 and shim.t_lz_steps(1e-14, -1.0, 1e-13, 8) == 1
+    assert shim.t_lz_steps(1e-3, np.log(0.1), 1e-13, 8) == 8 and shim.t_lz_steps(1e-10, np.log(0.1), 1e-13, 8) == 2
+    assert shim.t_lz_steps(1e-12, np.log(0.5), 1e-13, 8) == 2 and shim.t_lz_steps(0.5, -0.05, 1e-13, 8) == 8
+    assert shim.t_lz_rate(1e-2, 3, 1e-5, 6, -9.0) == pytest.approx(np.log(0.1)) and shim.t_lz_rate(1e-2, 3, 1e-1, 6, -9.0) == -9.0
+    assert shim.t_lz_rate(1e-2, 3, 1e-2 * 0.999, 4, 0.0) == -0.05 and shim.t_lz_rate(1.0, 1, 1e-300, 2, 0.0) == -12.0
+    assert shim.t_lz_rate(float("inf"), 1, 1e-3, 4, -2.0) == -2.0 and shim.t_lz_rate(1e-2, 4, 1e-3, 4, -2.0) == -2.0
+    rng = np.random.default_rng(5)
+    tot = {False: [0, 0], True: [0, 0]}
+    for case in range(12):
+        n = int(rng.integers(150, 600))
+        dens = float(rng.choice([0.02, 0.06, 0.2]))
+        B = np.triu((rng.random((n, n)) < dens) * rng.random((n, n)), 1)
+        k = int(rng.integers(8, n // 3))
+        B[:k, :k] += np.triu(rng.random((k, k)) * float(rng.choice([0.3, 1.0, 3.0])), 1)        # a planted consistent cluster: the gap
+        B = B + B.T
+        h = 1.0 + rng.random(n)
+        for adaptive in (False, True):
+            u = np.full(n, 1.0 / np.sqrt(n))
+            lrate, hh, us = 0.0, h.copy(), []
+            rs = np.random.default_rng(100 + case)
+            for rnd in range(5):
+                A = B * (hh[:, None] + hh[None, :])
+                u, nprod, ntest, lrate = _lanczos_products(A, u, shim, adaptive, lrate)
+                assert np.linalg.norm(A @ u - (u @ A @ u) * u) <= 1e-11 * abs(u @ A @ u), (case, adaptive, rnd)
+                tot[adaptive][0] += nprod
+                tot[adaptive][1] += ntest
+                us.append((u.copy(), nprod))
+                hh = hh * (1.0 + 0.05 * rs.standard_normal(n) / (1 + rnd))                          # the next round's reweighting
+            if adaptive:
+                for (ua, pa), (uf, pf) in zip(us, fixed_us):
+                    assert min(np.linalg.norm(ua - uf), np.linalg.norm(ua + uf)) < 1e-9
+                    assert pa <= pf, (case, pa, pf)
+            else:
+                fixed_us = us
+    assert tot[True][0] < 0.9 * tot[False][0], tot                    # >= 10 % fewer products ...
+    assert tot[True][1] <= 1.8 * tot[False][1] + 5, tot               # ... for a bounded number of extra tests (a test costs 0.3-0.5 of a product step)

@@ -28,7 +28,8 @@ args = (k["pc"][:, 0].contiguous(), k["nn"][:, 0].contiguous(), k["ft"][:, 0].co
         k["pc"][:, 1].contiguous(), k["nn"][:, 1].contiguous(), k["ft"][:, 1].contiguous(), st["w_t"], st["ns"], st["nt"])
 para = rpmodule.opts(*sig[0])
 from relativepose_amd import _lib
-for name, tune in (("fit, default", {}), ("fit, 1 workgroup per pair", {"fit_cluster": 1}), ("fit, leader + 3 helper workgroups per pair", {"fit_cluster": 4}),
+for name, tune in (("fit, default", {}), ("fit, 1 workgroup per pair", {"fit_cluster": 1}),
+                   ("fit, 1 workgroup per pair, convergence test every 8 products (the round-2/3 rule)", {"fit_cluster": 1, "fit_fixed_checks": 1}), ("fit, leader + 3 helper workgroups per pair", {"fit_cluster": 4}),
                    ("fit, leader + 7 helper workgroups per pair", {"fit_cluster": 8}),
                    ("fit, vectors in global scratch (the > 4500-correspondence layout)", {"fit_global_vectors": 1})):
     with _lib.tuning(**tune):
