@@ -513,9 +513,15 @@ __device__ __forceinline__ void seg_row_sums(const Fit1& f, double* out) {
 }
 template <int MODE, int RP_SEG_DEPTH>
 __device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_xe, bool store_x) {
+    const long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
     for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<MODE, RP_SEG_DEPTH, false>(f, sgm, mu_xe, store_x);
+    const long long t1_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
     __syncthreads();
+    const long long t2_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
     seg_row_sums<false>(f, out);
+    if (f.prof && threadIdx.x == 0 && blockIdx.y == 0) {     // (experiments build) thread 0's segments | barrier = the slowest wave + the partial sums' stores | row sums
+        f.prof[12] += t1_ - t0_; f.prof[13] += t2_ - t1_; f.prof[14] += (long long)__builtin_readcyclecounter() - t2_;
+    }
 }
 
 // claim-and-process loop of one product (leader and helpers).  word = the product's control word with next chunk = 1.
@@ -1320,7 +1326,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
             long long h[16];
             RP_HIP(hipStreamSynchronize(s));
             RP_HIP(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[fit prof, pair 0, cycles] products %lld (%lld calls) reorth+norm %lld tridiag %lld irls %lld finish %lld setup %lld | with helpers: publish %lld own chunks %lld wait %lld row sums %lld\n", h[0], h[6], h[1], h[2], h[4], h[5], h[7], h[8], h[9], h[10], h[11]);
+            fprintf(stderr, "[fit prof, pair 0, cycles] products %lld (%lld calls) reorth+norm %lld tridiag %lld irls %lld finish %lld setup %lld | with helpers: publish %lld own chunks %lld wait %lld row sums %lld | edge passes of one workgroup: thread 0's segments %lld barrier %lld row sums %lld\n", h[0], h[6], h[1], h[2], h[4], h[5], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
         }
     }
     if (dbg && dbg->corres_j)
