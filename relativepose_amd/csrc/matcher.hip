@@ -358,6 +358,8 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     double* yy;                 // [C] product output
     int32_t* rp;                // [C + 1] CSR row pointers (row lengths)
     int32_t* sp;                // [C + 1] first segment of every row
+    int32_t* meta;              // [meta_cap] LDS: row | length << 16 of the pair's first meta_cap segments (constant over the fit; 0 entries: helpers, global layout)
+    int meta_cap;
     double* red;                // [160] reduction scratch
     double* cbuf;               // [RP_LZ_M + 1] Gram-Schmidt coefficients
     double* tri;                // [4 * (RP_LZ_M + 1)] alpha, beta, s, scratch of the tridiagonal solve
@@ -409,15 +411,24 @@ __device__ __forceinline__ void rp_drain_stores() { asm volatile("s_waitcnt vmcn
 //   MODE 0: val = w                                   (weighted degrees)
 //   MODE 1: val = (base * (h[r] + h[cc])) * u[cc]      (rpmodule.py:262-267; base = w, or mu * xe for 'spectral' rounds > 0)
 //   MODE 2: val = x = relu(u[r] * u[cc]) * w           (rpmodule.py:277-280); x is stored to xe when store_x
-// RP_SEG_DEPTH = register batches of 8 edges in flight per lane: 4 (the whole segment) in the 512-thread kernel, 2 in the 1024-thread one (128 VGPRs)
-template <int MODE, int RP_SEG_DEPTH, bool SC1>
+// RP_SEG_CFG = (register batches of 8 edges in flight per lane: 2, or 4 = the whole segment) | (edges whose LDS gathers are in flight together: 8 in
+// the 512-thread kernel, 4 in the 1024-thread one with its 128 VGPRs) << 4
+template <int MODE, int RP_SEG_CFG, bool SC1>
 __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, bool store_x) {
     const double* base = (MODE == 1 && mu_xe != 0.0) ? f.xe : f.wv;
     constexpr int U = 8;                                  // edges per register batch; two batches in flight
+    constexpr int RP_SEG_DEPTH = RP_SEG_CFG & 15, GQ = RP_SEG_CFG >> 4;
+    static_assert((RP_SEG_DEPTH == 2 || RP_SEG_DEPTH == 4) && (GQ == 2 || GQ == 4 || GQ == 8), "seg_body configuration");
     {
-        const int r = f.segrow[sgm];
-        const int k0 = (sgm - f.sp[r]) * RP_SEG;
-        const int len = min(RP_SEG, (f.rp[r + 1] - f.rp[r]) - k0);
+        // the segment's row and length: one LDS word (filled once per fit) instead of a global load of the row followed by three
+        // dependent LDS reads in front of every segment's first edge load
+        int r, len;
+        if (sgm < f.meta_cap) { const int mw = f.meta[sgm]; r = mw & 0xffff; len = mw >> 16; }
+        else {
+            r = f.segrow[sgm];
+            const int k0 = (sgm - f.sp[r]) * RP_SEG;
+            len = min(RP_SEG, (f.rp[r + 1] - f.rp[r]) - k0);
+        }
         const size_t e0 = seg_edge_index(sgm, 0);
         const double hr = (MODE == 1) ? f.hh[r] : 0.0, ur = (MODE == 2) ? f.vec[r] : 0.0;
         double acc = 0.0;
@@ -433,22 +444,36 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
                 w[buf][q] = *(RP_GLOBAL const double*)(base + e);
             }
         };
+        // The gathers of GQ edges are issued together, for dead slots too (their column is the segment's first one: a valid index),
+        // and only the ACCUMULATION is predicated (a select on the sum): with `if (live) { gather; multiply; add }` per edge every edge
+        // paid its own LDS round trip in a serial chain.  Same operations in the same order on the live slots: bitwise the same sums.
         auto consume = [&](int buf, int kb) {
 #pragma unroll
-            for (int q = 0; q < U; ++q) {
-                if (kb + q < len) {
+            for (int q0 = 0; q0 < U; q0 += GQ) {
+                double hv[GQ], uv[GQ];
+#pragma unroll
+                for (int q = 0; q < GQ; ++q) {
+                    const int c = cc[buf][q0 + q];
+                    hv[q] = (MODE == 1) ? f.hh[c] : 0.0;
+                    uv[q] = (MODE != 0) ? f.vec[c] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < GQ; ++q) {
+                    const bool live = kb + q0 + q < len;
+                    const double wq = w[buf][q0 + q];
                     double val;
-                    if (MODE == 0) val = w[buf][q];
+                    if (MODE == 0) val = wq;
                     else if (MODE == 1) {
-                        const double bb = (mu_xe != 0.0) ? mu_xe * w[buf][q] : w[buf][q];
-                        val = (bb * (hr + f.hh[cc[buf][q]])) * f.vec[cc[buf][q]];
+                        const double bb = (mu_xe != 0.0) ? mu_xe * wq : wq;
+                        val = (bb * (hr + hv[q])) * uv[q];
                     } else {
-                        double x = ur * f.vec[cc[buf][q]];
-                        x = (x < 0.0 ? 0.0 : x) * w[buf][q];
-                        if (store_x) *(RP_GLOBAL double*)(f.xe + e0 + (size_t)(kb + q) * 64) = x;
+                        double x = ur * uv[q];
+                        x = (x < 0.0 ? 0.0 : x) * wq;
+                        if (store_x && live) *(RP_GLOBAL double*)(f.xe + e0 + (size_t)(kb + q0 + q) * 64) = x;
                         val = x;
                     }
-                    acc += val;
+                    const double sum = acc + val;
+                    acc = live ? sum : acc;
                 }
             }
         };
@@ -992,13 +1017,19 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
                                                                     double* __restrict__ pose, double* __restrict__ trace,
                                                                     int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out,
                                                                     long long* __restrict__ prof, int tri_rounds, FitCtl* __restrict__ ctl_all,
-                                                                    double* __restrict__ xu_all) {
+                                                                    double* __restrict__ xu_all, int meta_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[160];
     __shared__ double Rt[12];
     __shared__ int st_s;
     __shared__ unsigned cl_s[4];        // helper-workgroup protocol: leader [0] products / [1] h versions published; helper [0] / [1] the control word as polled (high / low half); [2] claimed chunk; leader [3] helpers given up on (a claimed chunk did not arrive in time)
-    constexpr int DEPTH = 2;            // (4 = the whole segment in flight: measured 13 % slower at 512 threads, spills at 1024)
+#ifndef RP_SEG_GQ
+#define RP_SEG_GQ(T_) ((T_) == 512 ? 4 : 2)      // measured (matcher alone, B=32): N=200 3.63 ms with per-edge gathers, 3.48 / 3.45 with 8 / 4 together; N=400 6.47, 6.63 / 6.41 / 6.34 with 8 / 4 / 2
+#endif
+#ifndef RP_SEG_NB
+#define RP_SEG_NB(T_) 2
+#endif
+    constexpr int DEPTH = RP_SEG_NB(THREADS) | (RP_SEG_GQ(THREADS) << 4);      // seg_body's RP_SEG_CFG (depth 4 = the whole segment in flight: measured 13 % slower at 512 threads, spills at 1024)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int G = gridDim.x;            // workgroups per scan pair: 1 leader + G - 1 helpers for the matrix-vector products
     const int C = pair_C(kp, g, b);
@@ -1011,6 +1042,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             f.ctl = ctl; f.xu = xu_all + (size_t)b * (2 * (size_t)g.Cmax + g.seg_cap); f.part2 = f.xu + 2 * (size_t)g.Cmax; f.G = G;
             f.vec = (double*)smem; f.hh = f.vec + g.Cmax;                        // the published u and h
             f.rp = g.rowptr + (size_t)b * (g.Cmax + 1); f.sp = g.segptr + (size_t)b * (g.Cmax + 1);      // (global: read in place)
+            f.meta = nullptr; f.meta_cap = 0;
             const size_t eoffh = (size_t)b * g.estride;
             f.col = g.col + eoffh; f.wv = g.wv + eoffh; f.xe = g.xe + eoffh;
             f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
@@ -1079,9 +1111,11 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     if constexpr (GVEC) {   // more correspondences than LDS holds: the three vectors in global scratch, row / segment pointers read in place
         f.vec = gvec + (size_t)b * 3 * g.Cmax; f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
         f.rp = const_cast<int32_t*>(rpg); f.sp = const_cast<int32_t*>(spg);
+        f.meta = nullptr; f.meta_cap = 0;
     } else {
         f.vec = f.cbuf + (RP_LZ_M + 1); f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
         f.rp = (int32_t*)(f.yy + g.Cmax); f.sp = f.rp + (g.Cmax + 1);
+        f.meta = f.sp + (g.Cmax + 1); f.meta_cap = 0;          // (set once the table is filled, below)
     }
     f.red = red;
     const size_t eoff = (size_t)b * g.estride;
@@ -1093,6 +1127,17 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     }
     __syncthreads();
     f.nseg = f.sp[C];
+    if constexpr (!GVEC) {
+        const int32_t* segrow_g = g.segrow + (size_t)b * g.seg_cap;
+        const int nm = min(f.nseg, meta_cap);
+        for (int sgm = tid; sgm < nm; sgm += blockDim.x) {
+            const int r = segrow_g[sgm];
+            const int k0 = (sgm - f.sp[r]) * RP_SEG;
+            f.meta[sgm] = r | (min(RP_SEG, (f.rp[r + 1] - f.rp[r]) - k0) << 16);
+        }
+        __syncthreads();
+        f.meta_cap = nm;
+    }
     FitCtx fc;
     fc.b = b; fc.C = C; fc.mu = kc.mu;
     fc.deg = g.state + ((size_t)b * 4 + 0) * g.Cmax; fc.gP = g.state + ((size_t)b * 4 + 1) * g.Cmax;
@@ -1164,6 +1209,15 @@ bool kp_ok(const RelposeKeypoints* kp, const RelposeParams* p) {
 static bool fit_in_lds(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && g_rp_tune[RELPOSE_TUNE_FIT_GLOBAL_VECTORS] == 0; }
 static size_t fit_lds_bytes(int32_t Cmax, bool in_lds) {
     return (size_t)(5 * (RP_LZ_M + 1)) * 8 + 16 + (in_lds ? (size_t)Cmax * 24 + (size_t)(Cmax + 1) * 8 : 0);
+}
+// entries of the LDS segment table (row | length of a pair's first segments) behind that: enough for ~3 segments per row, within the CU's 160 KB
+static int fit_meta_cap(int32_t Cmax, int32_t seg_cap, bool in_lds) {
+    if (!in_lds) return 0;
+    const long long room = (160 * 1024 - 2048 - (long long)fit_lds_bytes(Cmax, true)) / 4;
+    long long want = 3ll * Cmax + 512;
+    if (want > seg_cap) want = seg_cap;
+    if (want > room) want = room;
+    return want < 0 ? 0 : (int)want;
 }
 #define RP_MAX_CORRES RELPOSE_MAX_CORRESPONDENCES      // correspondences per pair (ns_max * topK): the fill kernel's row lists are uint16 in 8 * Cmax bytes of LDS
 
@@ -1283,7 +1337,8 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     const int m = p->method;
     {
         const bool in_lds = fit_in_lds(L.Cmax);
-        const size_t lds = fit_lds_bytes(L.Cmax, in_lds);
+        const int meta_cap = fit_meta_cap(L.Cmax, L.seg_cap, in_lds);
+        const size_t lds = fit_lds_bytes(L.Cmax, in_lds) + (size_t)meta_cap * 4;
         double* gvec = in_lds ? nullptr : (double*)(ws + L.gvec);
         static long long* prof = nullptr;
         if (RP_ENV("RELPOSE_FIT_PROF")) {
@@ -1316,7 +1371,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
             RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<T_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
             hipLaunchKernelGGL((fit_pair_kernel<T_, G_>), dim3(G, kp->B), dim3(T_), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), gvec,  \
                                status, pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds, (FitCtl*)(ws + L.ctl),      \
-                               (double*)(ws + L.xu));                                                                                   \
+                               (double*)(ws + L.xu), meta_cap);                                                                         \
         }
         if (fit_threads == 512) { if (in_lds) RP_FIT_LAUNCH(512, false) else RP_FIT_LAUNCH(512, true) }
         else { if (in_lds) RP_FIT_LAUNCH(1024, false) else RP_FIT_LAUNCH(1024, true) }
