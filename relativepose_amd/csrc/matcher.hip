@@ -636,6 +636,10 @@ __device__ __forceinline__ void fit_publish_h(const Fit1& f) {
     __syncthreads();
 }
 
+__device__ __forceinline__ double rp_readlane_f64(double v, int l) {       // l: wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 // fast a / b for the Sturm counts (sign and rough size matter, not the last bits)
 __device__ __forceinline__ double rp_fast_div(double a, double b) {
     double r = __builtin_amdgcn_rcp(b);
@@ -646,8 +650,9 @@ __device__ __forceinline__ double rp_fast_div(double a, double b) {
 // Largest eigenpair of the symmetric tridiagonal T (alpha[0..m), beta[0..m-1)) on ONE wave: eigenvalue by 64-way
 // multisection on Sturm counts, eigenvector by inverse iteration with theta shifted just above the spectrum
 // (theta I - T is then positive definite: LDL^T without pivoting).  s is normalised.  Returns theta.
-__device__ double tridiag_top(const double* alpha, const double* beta, int m, double* s, double* dscr, int rounds) {
+__device__ double tridiag_top(const double* alpha, const double* beta, int m, double* s, double* dscr, int rounds, long long* prof) {
     const int lane = threadIdx.x & 63;
+    const long long tp0_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     double lo = -INFINITY, hi = -INFINITY, scale = 0.0;
     for (int k = 0; k < m; ++k) {
         const double bl = k > 0 ? fabs(beta[k - 1]) : 0.0, br = k < m - 1 ? fabs(beta[k]) : 0.0;
@@ -679,6 +684,7 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
     // lambda_max(T_{m-1}); Newton from the LEFT end of the bracket therefore climbs monotonically to the root.  d and d' by the
     // pivot recurrence d_k = (x - alpha_k) - beta_{k-1}^2 / d_{k-1}.  (All lanes compute the same numbers.)
     double theta = hi;
+    const long long tp1_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     if (rounds < 9) {
         double x = lo;
         for (int it = 0; it < 8; ++it) {
@@ -698,28 +704,41 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
         }
         if (!(theta >= lo && theta <= hi)) theta = hi;
     }
-    if (lane == 0) {
+    const long long tp2_ = prof ? (long long)__builtin_readcyclecounter() : 0;
+    {
+        // Inverse iteration, one matrix row per LANE (m <= 64): the serial sweeps of the bidiagonal solves pass s_k from lane to lane
+        // through v_readlane (a scalar register, ~10 cycles) -- the same operations in the same order as the one-lane loop over LDS
+        // arrays this replaces, whose every step paid an LDS store -> load round trip (554 k of the 856 k cycles of all tests of a fit
+        // at N = 200; profiles/r04_matcher.txt).  The pivots are computed redundantly by every lane (uniform operands, like the polish).
         const double sh = theta + scale * 4e-16;
-        double* id = dscr;                      // reciprocal pivots of theta I - T
-        double d = sh - alpha[0];
-        if (!(d > tiny)) d = tiny;
-        id[0] = 1.0 / d;
-        for (int k = 1; k < m; ++k) {
-            d = (sh - alpha[k]) - (beta[k - 1] * beta[k - 1]) * id[k - 1];
-            if (!(d > scale * 1e-18)) d = scale * 1e-18;
-            id[k] = 1.0 / d;
+        double idk = 0.0, idprev = 0.0;                  // reciprocal pivots of theta I - T: idk = lane's own
+        for (int k = 0; k < m; ++k) {
+            double d = (k == 0) ? sh - alpha[0] : (sh - alpha[k]) - (beta[k - 1] * beta[k - 1]) * idprev;
+            if (k == 0) { if (!(d > tiny)) d = tiny; }
+            else if (!(d > scale * 1e-18)) d = scale * 1e-18;
+            idprev = 1.0 / d;
+            if (lane == k) idk = idprev;
         }
-        for (int k = 0; k < m; ++k) s[k] = 1.0;
+        const double idm1 = __shfl_up(idk, 1);
+        // (theta I - T) = L D L^T with L unit lower bidiagonal, l_k = -beta_k / d_k
+        const double ck = (lane >= 1 && lane < m) ? beta[lane - 1] * idm1 : 0.0;        // forward:  s_k += (beta_{k-1} / d_{k-1}) s_{k-1}
+        const double ek = (lane < m - 1) ? beta[lane] * idk : 0.0;                      // backward: s_k += (beta_k / d_k) s_{k+1}
+        double sk = 1.0;
         for (int it = 0; it < 3; ++it) {
-            // (theta I - T) = L D L^T with L unit lower bidiagonal, l_k = -beta_k / d_k
-            for (int k = 1; k < m; ++k) s[k] = s[k] + (beta[k - 1] * id[k - 1]) * s[k - 1];     // L z = b
-            for (int k = 0; k < m; ++k) s[k] = s[k] * id[k];                                    // D
-            for (int k = m - 2; k >= 0; --k) s[k] = s[k] + (beta[k] * id[k]) * s[k + 1];        // L^T
+            for (int k = 1; k < m; ++k) { const double prev = rp_readlane_f64(sk, k - 1); if (lane == k) sk = sk + ck * prev; }      // L z = b
+            sk = sk * idk;                                                                                                        // D
+            for (int k = m - 2; k >= 0; --k) { const double nxt = rp_readlane_f64(sk, k + 1); if (lane == k) sk = sk + ek * nxt; }  // L^T
+            const double sq = sk * sk;
             double nn = 0.0;
-            for (int k = 0; k < m; ++k) nn += s[k] * s[k];
+            for (int k = 0; k < m; ++k) nn += rp_readlane_f64(sq, k);
             nn = 1.0 / sqrt(nn);
-            for (int k = 0; k < m; ++k) s[k] *= nn;
+            sk *= nn;
         }
+        if (lane < m) s[lane] = sk;
+        (void)dscr;
+    }
+    if (prof && lane == 0 && blockIdx.y == 0) {      // (experiments build) multisection | Newton polish | inverse iteration
+        prof[3] += tp1_ - tp0_; prof[10] += tp2_ - tp1_; prof[15] += (long long)__builtin_readcyclecounter() - tp2_;
     }
     return theta;
 }
@@ -832,7 +851,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
                 // Ritz pair of the m x m tridiagonal matrix, residual estimate beta_m |s_m|
                 long long t2_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
                 if (wave == 0) {
-                    const double th = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri + 3 * (RP_LZ_M + 1), f.tri_rounds);
+                    const double th = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri + 3 * (RP_LZ_M + 1), f.tri_rounds, f.prof);
                     if (lane == 0) f.red[159] = th;
                 }
                 __syncthreads();
@@ -1381,7 +1400,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
             long long h[16];
             RP_HIP(hipStreamSynchronize(s));
             RP_HIP(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[fit prof, pair 0, cycles] products %lld (%lld calls) reorth+norm %lld tridiag %lld irls %lld finish %lld setup %lld | with helpers: publish %lld own chunks %lld wait %lld row sums %lld | edge passes of one workgroup: thread 0's segments %lld barrier %lld row sums %lld\n", h[0], h[6], h[1], h[2], h[4], h[5], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14]);
+            fprintf(stderr, "[fit prof, pair 0, cycles] products %lld (%lld calls) reorth+norm %lld tridiag %lld irls %lld finish %lld setup %lld | with helpers: publish %lld own chunks %lld wait %lld row sums %lld | edge passes of one workgroup: thread 0's segments %lld barrier %lld row sums %lld | tridiagonal: multisection %lld newton %lld (= 'wait' column without helpers) inverse iteration %lld\n", h[0], h[6], h[1], h[2], h[4], h[5], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[3], h[10], h[15]);
         }
     }
     if (dbg && dbg->corres_j)
