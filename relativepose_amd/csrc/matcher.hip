@@ -413,9 +413,12 @@ __device__ __forceinline__ void rp_drain_stores() { asm volatile("s_waitcnt vmcn
 //   MODE 2: val = x = relu(u[r] * u[cc]) * w           (rpmodule.py:277-280); x is stored to xe when store_x
 // RP_SEG_CFG = (register batches of 8 edges in flight per lane: 2, or 4 = the whole segment) | (edges whose LDS gathers are in flight together: 8 in
 // the 512-thread kernel, 4 in the 1024-thread one with its 128 VGPRs) << 4
-template <int MODE, int RP_SEG_CFG, bool SC1>
+// SCALED (MODE 1 only): base = mu * xe, the 'spectral' method's rounds > 0 -- a compile-time choice: as a run-time one it cost every edge of
+// every method a multiplication and two selects
+template <int MODE, int RP_SEG_CFG, bool SC1, bool SCALED = false>
 __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, bool store_x) {
-    const double* base = (MODE == 1 && mu_xe != 0.0) ? f.xe : f.wv;
+    static_assert(!SCALED || MODE == 1, "SCALED is a MODE 1 variant");
+    const double* base = SCALED ? f.xe : f.wv;
     constexpr int U = 8;                                  // edges per register batch; two batches in flight
     constexpr int RP_SEG_DEPTH = RP_SEG_CFG & 15, GQ = RP_SEG_CFG >> 4;
     static_assert((RP_SEG_DEPTH == 2 || RP_SEG_DEPTH == 4) && (GQ == 2 || GQ == 4 || GQ == 8), "seg_body configuration");
@@ -464,7 +467,7 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
                     double val;
                     if (MODE == 0) val = wq;
                     else if (MODE == 1) {
-                        const double bb = (mu_xe != 0.0) ? mu_xe * wq : wq;
+                        const double bb = SCALED ? mu_xe * wq : wq;
                         val = (bb * (hr + hv[q])) * uv[q];
                     } else {
                         double x = ur * uv[q];
@@ -539,7 +542,8 @@ __device__ __forceinline__ void seg_row_sums(const Fit1& f, double* out) {
 template <int MODE, int RP_SEG_DEPTH>
 __device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_xe, bool store_x) {
     const long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
-    for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<MODE, RP_SEG_DEPTH, false>(f, sgm, mu_xe, store_x);
+    if (MODE == 1 && mu_xe != 0.0) { for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<1, RP_SEG_DEPTH, false, true>(f, sgm, mu_xe, store_x); }
+    else for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<MODE, RP_SEG_DEPTH, false>(f, sgm, mu_xe, store_x);
     const long long t1_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
     __syncthreads();
     const long long t2_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
