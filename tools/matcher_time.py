@@ -1,6 +1,6 @@
 """Time relpose_match_pairs alone (HIP events, no other work on the GPU) on the bench workload's own level-0 primitives, with the fit's
 vectors in LDS (default) and in global scratch (the layout of pairs with more than 4500 correspondences).
-    python tools/matcher_time.py [config 1|2|3] [pairs]"""
+    python tools/matcher_time.py [config 1|2|3] [pairs] [variant indices, e.g. 1 or 0,3]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,10 +28,13 @@ args = (k["pc"][:, 0].contiguous(), k["nn"][:, 0].contiguous(), k["ft"][:, 0].co
         k["pc"][:, 1].contiguous(), k["nn"][:, 1].contiguous(), k["ft"][:, 1].contiguous(), st["w_t"], st["ns"], st["nt"])
 para = rpmodule.opts(*sig[0])
 from relativepose_amd import _lib
-for name, tune in (("fit, default", {}), ("fit, 1 workgroup per pair", {"fit_cluster": 1}),
+ONLY = [int(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else None
+for vi, (name, tune) in enumerate((("fit, default", {}), ("fit, 1 workgroup per pair", {"fit_cluster": 1}),
                    ("fit, 1 workgroup per pair, convergence test every 8 products (the round-2/3 rule)", {"fit_cluster": 1, "fit_fixed_checks": 1}), ("fit, leader + 3 helper workgroups per pair", {"fit_cluster": 4}),
                    ("fit, leader + 7 helper workgroups per pair", {"fit_cluster": 8}),
-                   ("fit, vectors in global scratch (the > 4500-correspondence layout)", {"fit_global_vectors": 1})):
+                   ("fit, vectors in global scratch (the > 4500-correspondence layout)", {"fit_global_vectors": 1}))):
+    if ONLY is not None and vi not in ONLY:
+        continue
     with _lib.tuning(**tune):
         res = rpmodule.match_pairs(*args, para, debug=True, max_edges=pipe.max_edges)
         for _ in range(2):
