@@ -78,6 +78,11 @@ class RelativePosePipeline:
         st["ns"] = t(npts[:, 0], torch.int32)
         st["nt"] = t(npts[:, 1], torch.int32)
         st["eye"] = torch.eye(4, dtype=torch.float64, device=device).repeat(B, 1, 1).contiguous()
+        # the batch's network input and output live as long as the prepared batch: allocated HERE, not at first use inside a serving loop
+        # (1.7 + 5.7 GB per batch at 320x1280: a hipMalloc of that size in the loop stalls every stream -- bench configs[4] ran at 613, 851
+        # or 965-983 pairs/s depending on which of the rotated batches the caching allocator could serve from freed blocks)
+        st["x"] = torch.empty(2 * B, 16, h, w, dtype=torch.float32, device=device)
+        st["f"] = torch.empty(2 * B, self.net.out_channels, h, w, dtype=torch.float32, device=device)
         if keep_host:      # pinned host copies of the per-batch inputs, for upload_inputs (PCIe-inclusive timing)
             st["host"] = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dt).pin_memory() for k, a, dt in (
                 ("rgb", rgb.reshape(2 * B, 3, h, w), torch.float32), ("norm", norm.reshape(2 * B, 3, h, w), torch.float32),
