@@ -404,6 +404,17 @@ __device__ __forceinline__ double rp_ld_sc1(const double* p) { return __longlong
 __device__ __forceinline__ void rp_st_sc1(rp_u64* p, rp_u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ rp_u64 rp_ld_sc1(const rp_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rp_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Formal side of the protocol (HSA memory model): every flag store / read-modify-write that publishes data is preceded by an agent-scope
+// RELEASE fence, every flag observation that licenses reading such data is followed by an agent-scope ACQUIRE fence (fences rather than
+// ordered atomics: the polls stay relaxed, one invalidate per observation instead of one per poll).  The write-through payload and
+// vmcnt(0) drains above are what makes it work on gfx950; the fences are what makes it a data-race-free program.  RP_FIT_FENCES=0 builds
+// without them (A/B, matcher alone at B=32, same box: leader + 3 helpers 2.87 -> 3.00-3.07 ms at N=200, 4.81 -> 4.96 at N=400; leader + 7: 3.14 ->
+// 3.37-3.44 and 4.50 -> 4.83; one workgroup per pair -- the throughput configurations -- unchanged: no flag is touched).
+#ifndef RP_FIT_FENCES
+#define RP_FIT_FENCES 1
+#endif
+__device__ __forceinline__ void rp_release_agent() { if (RP_FIT_FENCES) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void rp_acquire_agent() { if (RP_FIT_FENCES) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // (chunk geometry of the distributed products: rp_fit_chunk_size / _count / _begin in rp_math.h, CPU-tested)
 
 // One pass over the pair's edges: thread <-> segment (<= 32 edges of one row, read with stride 64 so that a wave's loads
@@ -567,7 +578,7 @@ __device__ __forceinline__ void fit_work_loop(const Fit1& f, rp_u64 word, int* s
     int prev = -1;
     for (int it = 0;; ++it) {
         if (threadIdx.x == 0) {
-            if (prev > 0) __hip_atomic_fetch_add(&f.ctl->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (its stores were drained below; chunk 0 is not counted)
+            if (prev > 0) { rp_release_agent(); __hip_atomic_fetch_add(&f.ctl->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (its stores were drained below; chunk 0 is not counted)
             int got = -1;
             if (LEADER && it == 0) got = 0;
             else {
@@ -583,7 +594,7 @@ __device__ __forceinline__ void fit_work_loop(const Fit1& f, rp_u64 word, int* s
                     }
                     if (!LEADER) break;                                                 // nothing left to claim
                     // leader: every chunk is claimed; wait until the nchunks - 1 claimed ones are counted done
-                    if (rp_ld_sc1(&f.ctl->done) == ((word >> 40 << 40) | (rp_u64)(nchunks - 1))) break;
+                    if (rp_ld_sc1(&f.ctl->done) == ((word >> 40 << 40) | (rp_u64)(nchunks - 1))) { rp_acquire_agent(); break; }     // (then reads part2)
                     __builtin_amdgcn_s_sleep(1);
                     // ~2 s without the claimed chunks being counted: never a hang -- and never a silently wrong product either: -2 makes the
                     // leader redo every chunk itself (below) and finish the fit without helpers
@@ -626,7 +637,7 @@ __device__ __forceinline__ void fit_dist_product(const Fit1& f, double* out, int
     if (threadIdx.x == 0) rp_st_sc1(&f.ctl->done, (rp_u64)e << 40);
     rp_drain_stores();
     __syncthreads();
-    if (threadIdx.x == 0) { f.epoch[0] = e; rp_st_sc1(&f.ctl->claim, word); }
+    if (threadIdx.x == 0) { f.epoch[0] = e; rp_release_agent(); rp_st_sc1(&f.ctl->claim, word); }
     const long long tb_ = pr ? (long long)__builtin_readcyclecounter() : 0;
     fit_work_loop<DEPTH, true>(f, word, s_chunk, [] {});
     const long long td_ = pr ? (long long)__builtin_readcyclecounter() : 0;
@@ -1079,6 +1090,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
                         __builtin_amdgcn_s_sleep(2);
                         if ((long long)__builtin_readcyclecounter() - t0 > (last == 0 ? (1ll << 26) : (1ll << 32))) { w = (rp_u64)RP_FIT_DONE << 40; break; }   // no leader within ~30 ms: leave
                     }
+                    rp_acquire_agent();         // (then everyone loads the published vectors)
                     cl_s[0] = (unsigned)(w >> 32); cl_s[1] = (unsigned)w;
                 }
                 __syncthreads();
