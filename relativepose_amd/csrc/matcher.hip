@@ -362,7 +362,7 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     int meta_cap;
     double* red;                // [160] reduction scratch
     double* cbuf;               // [RP_LZ_M + 1] Gram-Schmidt coefficients
-    double* tri;                // [4 * (RP_LZ_M + 1)] alpha, beta, s, scratch of the tridiagonal solve
+    double* tri;                // [4 * (RP_LZ_M + 1)] alpha, beta, s of the tridiagonal solve (the fourth block is spare)
     const int32_t* col; const double* wv; double* xe;      // this pair's edges (global, segment layout)
     const int32_t* segrow; double* part;
     double* part2;              // partial sums of the products done with helper workgroups (only ever written write-through)
@@ -665,7 +665,7 @@ __device__ __forceinline__ double rp_fast_div(double a, double b) {
 // Largest eigenpair of the symmetric tridiagonal T (alpha[0..m), beta[0..m-1)) on ONE wave: eigenvalue by 64-way
 // multisection on Sturm counts, eigenvector by inverse iteration with theta shifted just above the spectrum
 // (theta I - T is then positive definite: LDL^T without pivoting).  s is normalised.  Returns theta.
-__device__ double tridiag_top(const double* alpha, const double* beta, int m, double* s, double* dscr, int rounds, long long* prof) {
+__device__ double tridiag_top(const double* alpha, const double* beta, int m, double* s, int rounds, long long* prof) {
     const int lane = threadIdx.x & 63;
     const long long tp0_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     double lo = -INFINITY, hi = -INFINITY, scale = 0.0;
@@ -750,7 +750,6 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
             sk *= nn;
         }
         if (lane < m) s[lane] = sk;
-        (void)dscr;
     }
     if (prof && lane == 0 && blockIdx.y == 0) {      // (experiments build) multisection | Newton polish | inverse iteration
         prof[3] += tp1_ - tp0_; prof[10] += tp2_ - tp1_; prof[15] += (long long)__builtin_readcyclecounter() - tp2_;
@@ -866,7 +865,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
                 // Ritz pair of the m x m tridiagonal matrix, residual estimate beta_m |s_m|
                 long long t2_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
                 if (wave == 0) {
-                    const double th = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri + 3 * (RP_LZ_M + 1), f.tri_rounds, f.prof);
+                    const double th = tridiag_top(f.tri, f.tri + (RP_LZ_M + 1), m, f.tri + 2 * (RP_LZ_M + 1), f.tri_rounds, f.prof);
                     if (lane == 0) f.red[159] = th;
                 }
                 __syncthreads();
