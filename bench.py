@@ -82,6 +82,7 @@ def parse_args(argv=None):
                     help="levels 1-2 recompute the self-view encoder streams (A/B switch; the default reuses level 0's, bitwise the same poses)")
     ap.add_argument("--no-tail-overlap", action="store_true", help="A/B: the whole SCNet forward on the SCNet stream (no head / tail on the slot streams)")
     ap.add_argument("--net-priority", type=int, default=None, help="A/B: HIP stream priority of the SCNet stream (default: -1 = high when the tail overlaps)")
+    ap.add_argument("--fit-cluster", type=int, default=1, help="A/B: workgroups per scan pair in the fit inside the loop (default 1: no helper workgroups)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
     ap.add_argument("--batches", type=int, default=4, help="distinct prepared batches rotated through the in-flight slots")
@@ -237,7 +238,7 @@ def worker(args):
     Cc = N * 5
     pipe = RelativePosePipeline(net, ds, mm, sigmas, max_edges=min(Cc * (Cc - 1), (1 << 20) * max(1, (N // 200) ** 2)),
                                 outputs="pose" if args.pose_outputs else "all", self_stream_cache=not args.no_self_cache,
-                                tail_overlap=not args.no_tail_overlap, net_priority=args.net_priority)
+                                tail_overlap=not args.no_tail_overlap, net_priority=args.net_priority, loop_fit_cluster=args.fit_cluster)
     batches, first = [], None
     for j in range(nbatch):
         seed = 1000 * (args.config + 1) + lo + 100000 * j      # seed = 1000*config + pair index; slot j>0: other pairs

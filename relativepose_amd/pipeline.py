@@ -22,7 +22,7 @@ class RelativePosePipeline:
     _net_streams = None
 
     def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0, compose=0, outputs="all",
-                 self_stream_cache=True, tail_overlap=True, net_priority=None):
+                 self_stream_cache=True, tail_overlap=True, net_priority=None, loop_fit_cluster=1):
         self.net = net
         # the masked own views (channels 0:8 of the net input) are written once per pass and only the warped partner view changes from
         # level to level (evaluation.py:217-242): levels >= 1 reuse level 0's self-view encoder streams (SCNet.forward(self_tag=...),
@@ -47,6 +47,9 @@ class RelativePosePipeline:
         # variable).  net_priority: HIP stream priority of the SCNet stream, None = -1 (high) when the tail overlaps, else 0.
         self.tail_overlap = bool(tail_overlap)
         self.net_priority = net_priority
+        # workgroups per scan pair in the fit while several batches are in flight (run_pipelined; 1 = no helper workgroups: they take CUs from the
+        # other slot's convolutions; A/B switch)
+        self.loop_fit_cluster = int(loop_fit_cluster)
 
     def prepare(self, rgb, norm, depth, pts, ptw, device, keep_host=False):
         """Host arrays (dataset dict layout: rgb/norm [B,2,3,h,4h], depth [B,2,h,4h] f32; pts [B,2,N,2],
@@ -194,7 +197,7 @@ class RelativePosePipeline:
         # batches in flight = a throughput loop: the fit's helper workgroups (a latency tool for a lone small batch)
         # would take CUs from the other slot's convolutions, so the matcher calls enqueued here use one workgroup per pair
         import contextlib
-        with (_lib.tuning(fit_cluster=1) if depth > 1 else contextlib.nullcontext()):
+        with (_lib.tuning(fit_cluster=self.loop_fit_cluster) if depth > 1 else contextlib.nullcontext()):
             while nxt < steps or live:
                 for slot in range(depth):
                     if slot not in live and nxt < steps:
