@@ -117,6 +117,24 @@ def test_thousand_keypoints_fit_converges_and_matches_reference(golden_dir):
     assert e_ref < 1e-6 and t_ref < 1e-6, (e_ref, t_ref)
 
 
+def test_largest_lds_resident_fit_equals_global_layout():
+    """The largest pair whose per-correspondence vectors still live in LDS (900 keypoints x topK 5 = 4500 correspondences = RP_FIT1_MAXC: the
+    1024-thread kernel with ~158 KB of dynamic LDS incl. the segment table) against the same pair forced into the global-scratch layout:
+    the two run the same arithmetic in the same order -> bitwise equal poses, status and product counts; converged; the planted motion."""
+    import torch
+    from relativepose_amd import _lib, rpmodule
+    S, T, G = synth.make_match_case(900, 4200, inlier=0.5, noise=0.002)
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.009)
+    lds = _run([(S, T)], para, debug=True)
+    with _lib.tuning(fit_global_vectors=1):
+        glob = _run([(S, T)], para, debug=True)
+    assert torch.equal(lds.pose, glob.pose) and torch.equal(lds.status, glob.status) and torch.equal(lds.eig_iters, glob.eig_iters)
+    pose = lds.pose[0].cpu().numpy()
+    log("fit_lds_limit", status=int(lds.status[0]), products_per_round=lds.eig_iters[0].cpu().tolist(), surviving_pairs=int(lds.counts[0, 1]),
+        rot_err_vs_ground_truth=float(np.linalg.norm(pose[:3, :3] - G[:3, :3])))
+    assert int(lds.status[0]) == 0 and np.linalg.norm(pose[:3, :3] - G[:3, :3]) < 5e-2
+
+
 def test_capacity_limits_largest_pair_runs_and_beyond_is_refused():
     """include/relpose.h: RELPOSE_MAX_TARGETS = 1152 keypoints per view (the affinity kernel's LDS beyond 512 targets) and
     RELPOSE_MAX_CORRESPONDENCES = 8192 = ns_max x topK (pair_fill_rows_kernel then asks for the full 64 KB of dynamic LDS).  A pair AT
