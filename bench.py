@@ -279,7 +279,7 @@ def worker(args):
     # creates its streams -- one pass per slot, so that the timed region is the steady-state loop for any --warmup the caller picks (the default
     # --warmup 2 covers both slots by itself)
     if args.warmup < depth:
-        pipe.run_pipelined(batches, depth, None, depth=depth)
+        run_steps(depth)                    # (through the gather as well: the first collective creates the RCCL communicator)
     if args.warmup:
         run_steps(args.warmup)
     ncoll0 = D.COLLECTIVES["all_gather"]
