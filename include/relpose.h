@@ -282,6 +282,40 @@ int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_
 int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
                            void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags, uint64_t self_tag);
 
+/* ONE entry point for every forward variant above (round 5): the four relpose_scnet_forward* functions are thin wrappers that fill this
+ * block.  Replaces the reference call `f = net(x)` (evaluation.py:242, rpmodule.py:623; SCNet.forward, model/mymodel.py:259-380).
+ *   struct_size           sizeof(RelposeForwardArgs) as the CALLER compiled it: fields beyond it take their defaults (0), so the block can grow
+ *   flags                 RELPOSE_FWD_* (as relpose_scnet_forward3)
+ *   x, out, n_images, H, W, workspace, workspace_bytes   as relpose_scnet_forward
+ *   stream, tail_stream   as relpose_scnet_forward2 (tail_stream NULL = stream)
+ *   self_tag              as relpose_scnet_forward4 (0 = always recompute the self-view streams)
+ *   workspace_generation  the caller's name for THIS ALLOCATION of `workspace` (e.g. a counter bumped whenever the buffer is re-allocated),
+ *                         sent with every call: the self-stream cache is used only when the previous forward on the pointer carried the
+ *                         same generation -- a workspace re-created at a recycled address is never mistaken for the old one, whichever call
+ *                         touches it first (RELPOSE_FWD_NEW_WORKSPACE needs the first call to carry the flag).  0 = not tracked.
+ * Error behaviour: a call that returns != 0 leaves no self-stream record on the workspace (the next forward recomputes everything); a
+ * self-cached plan that cannot be built falls back to the full forward (same output) instead of failing. */
+typedef struct RelposeForwardArgs {
+    uint32_t struct_size;
+    int32_t flags;
+    const float* x;
+    float* out;
+    int32_t n_images, H, W, reserved0;
+    void* workspace;
+    size_t workspace_bytes;
+    void* stream;
+    void* tail_stream;
+    uint64_t self_tag;
+    uint64_t workspace_generation;
+} RelposeForwardArgs;
+int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args);
+
+/* Multiply-accumulates one forward of a plan family executes (host-only, no device access): flags as above, self_cached != 0 = the plan
+ * a forward takes when it finds its self_tag on the workspace.  The full forward (flags 0, self_cached 0) counts every member of
+ * model/mymodel.py:259-380; the level-0 plan and the self-stream cache count what they really launch.  bench.py divides the two for
+ * its plan-aware in-loop roofline ("roofline.in_loop"). */
+int relpose_scnet_plan_macs(RelposeSCNet* net, int32_t n_images, int32_t flags, int32_t self_cached, double* macs_host);
+
 /* Debug: copy a raw (pre-BatchNorm) layer output of the last forward, NHWC float32, to out (device).
  * Returns the number of floats written (or needed if out is NULL), <0 if unknown. */
 int64_t relpose_scnet_read_tap(RelposeSCNet* net, const char* layer, float* out, void* workspace, void* stream);

@@ -30,6 +30,14 @@ class MatchDebug(C.Structure):
                 ("counts", c_void_p), ("trace", c_void_p), ("eig_iters", c_void_p)]
 
 
+class ForwardArgs(C.Structure):
+    """RelposeForwardArgs (include/relpose.h): the argument block of relpose_scnet_forward_ex."""
+    _fields_ = [("struct_size", C.c_uint32), ("flags", c_int), ("x", c_void_p), ("out", c_void_p),
+                ("n_images", c_int), ("H", c_int), ("W", c_int), ("reserved0", c_int),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("stream", c_void_p), ("tail_stream", c_void_p),
+                ("self_tag", C.c_uint64), ("workspace_generation", C.c_uint64)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/relpose.h
 SIGNATURES = {
     "relpose_default_params": (None, [C.POINTER(Params)]),
@@ -68,6 +76,8 @@ SIGNATURES = {
     "relpose_scnet_forward3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
     "relpose_scnet_forward4": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int,
                                        C.c_uint64]),
+    "relpose_scnet_forward_ex": (c_int, [c_void_p, C.POINTER(ForwardArgs)]),
+    "relpose_scnet_plan_macs": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_double)]),
     "relpose_scnet_read_tap": (c_int64, [c_void_p, c_char_p, c_void_p, c_void_p, c_void_p]),
     "relpose_scnet_profile": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_int,
                                       C.POINTER(c_double), C.POINTER(c_double), C.POINTER(c_int64), c_void_p]),

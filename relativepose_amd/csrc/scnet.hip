@@ -28,6 +28,7 @@
 #include <string.h>
 #include <type_traits>
 #include <stdlib.h>
+#include <stddef.h>
 
 namespace {
 
@@ -2067,7 +2068,7 @@ struct RelposeSCNet {
     size_t w1_off = 0;           // conv1 direct-kernel weights inside d_w
     size_t wh_off = 0, bh_off = 0;   // fused-heads weight image and bias vector inside d_w
     std::map<std::pair<void*, int>, void*> plans;   // (workspace, n) -> Plan* (each with its own device descriptor table)
-    struct SelfState { uint64_t tag = 0; int n = 0, H = 0, W = 0; bool pose_only = false; };
+    struct SelfState { uint64_t tag = 0, gen = 0; int n = 0, H = 0, W = 0; bool pose_only = false; };
     std::map<void*, SelfState> self_state;          // workspace -> whose self-view streams it holds (relpose_scnet_forward4)
     std::map<std::string, Layer> layers;
     std::map<std::string, Buf> bufs;
@@ -2754,6 +2755,13 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     (void)n;
 }
 
+// snap_mode of the transposed conv that phase member i belongs to (the builder records it on the first of the 4 phase members)
+inline int plan_snap_mode(const Plan& p, int i) {
+    for (const Op& op : p.ops)
+        if (op.type == OP_DECONV_TILE && i >= op.first && i < op.first + op.count) return p.descs[op.first + ((i - op.first) & ~3)].snap_mode;
+    return 0;
+}
+
 void free_plan(RelposeSCNet* net) {
     for (auto& kv : net->plans) {
         Plan* p = (Plan*)kv.second;
@@ -2923,64 +2931,102 @@ size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n, int32_t
     return ws_offsets(const_cast<RelposeSCNet*>(net), n).total;
 }
 
+// The four historical entry points are thin wrappers of relpose_scnet_forward_ex (one argument block, include/relpose.h).
+static RelposeForwardArgs rp_fwd_args(const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, void* stream,
+                                      void* tail_stream, int32_t flags, uint64_t self_tag) {
+    RelposeForwardArgs a;
+    memset(&a, 0, sizeof(a));
+    a.struct_size = (uint32_t)sizeof(a); a.flags = flags; a.x = x; a.out = out; a.n_images = n; a.H = H; a.W = W;
+    a.workspace = workspace; a.workspace_bytes = workspace_bytes; a.stream = stream; a.tail_stream = tail_stream; a.self_tag = self_tag;
+    return a;
+}
+
 int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                           size_t workspace_bytes, void* stream) {
-    return relpose_scnet_forward2(net, x, out, n, H, W, workspace, workspace_bytes, stream, stream);
+    const RelposeForwardArgs a = rp_fwd_args(x, out, n, H, W, workspace, workspace_bytes, stream, stream, 0, 0);
+    return relpose_scnet_forward_ex(net, &a);
 }
 
 int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                            size_t workspace_bytes, void* stream, void* tail_stream) {
-    return relpose_scnet_forward3(net, x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, 0);
+    const RelposeForwardArgs a = rp_fwd_args(x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, 0, 0);
+    return relpose_scnet_forward_ex(net, &a);
 }
 
 int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                            size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags) {
-    return relpose_scnet_forward4(net, x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, flags, 0);
+    const RelposeForwardArgs a = rp_fwd_args(x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, flags, 0);
+    return relpose_scnet_forward_ex(net, &a);
 }
 
 int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
                            size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags, uint64_t self_tag) {
-    if (!net || !net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0 || n >= (1 << 24)) return RELPOSE_EINVAL;
+    const RelposeForwardArgs a = rp_fwd_args(x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, flags, self_tag);
+    return relpose_scnet_forward_ex(net, &a);
+}
+
+int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) {
+    // (fields beyond the caller's struct_size take their defaults: a caller compiled against an older header keeps working)
+    if (!net || !args || args->struct_size < offsetof(RelposeForwardArgs, self_tag)) return RELPOSE_EINVAL;
+    const float* x = args->x; float* out = args->out;
+    const int32_t n = args->n_images, H = args->H, W = args->W, flags = args->flags;
+    void* workspace = args->workspace; const size_t workspace_bytes = args->workspace_bytes;
+    void* stream = args->stream; void* tail_stream = args->tail_stream ? args->tail_stream : args->stream;
+    const uint64_t self_tag = args->struct_size >= offsetof(RelposeForwardArgs, self_tag) + sizeof(uint64_t) ? args->self_tag : 0;
+    const uint64_t ws_gen = args->struct_size >= offsetof(RelposeForwardArgs, workspace_generation) + sizeof(uint64_t) ? args->workspace_generation : 0;
+    if (!net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0 || n >= (1 << 24)) return RELPOSE_EINVAL;
     if (flags & ~(RELPOSE_FWD_ZERO_WARP | RELPOSE_FWD_POSE_OUTPUTS | RELPOSE_FWD_NEW_WORKSPACE)) return RELPOSE_EINVAL;
     const int G = n / 2;
     // (nothing to share with one BatchNorm group; the tile kernels' patch pairing wants the 2-image members' patch count even as well)
     const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2;
     const bool pose_only = (flags & RELPOSE_FWD_POSE_OUTPUTS) != 0;
     if (flags & RELPOSE_FWD_NEW_WORKSPACE) net->self_state.erase(workspace);      // the memory behind this pointer is not what the last forward left
-    // Self-stream cache: the previous forward on this workspace carried the same non-zero tag (and shape) -> the self-view encoder
-    // streams it left in the workspace are what this forward would compute.  Anything else runs (and re-fills) them.
-    bool self_cached = false;
-    {
-        RelposeSCNet::SelfState& st = net->self_state[workspace];
-        // (the accumulator snapshots are laid out per plan family: a pose-outputs forward has fewer decoder heads)
-        self_cached = self_tag != 0 && st.tag == self_tag && st.n == n && st.H == H && st.W == W && st.pose_only == pose_only && !zero_warp;
-        st.tag = self_tag; st.n = n; st.H = H; st.W = W; st.pose_only = pose_only;
-    }
-    // a tagged forward that computes the self streams also leaves the accumulator snapshots of the skip-connection halves
-    const int snap_mode = self_cached ? 2 : (self_tag != 0 ? 1 : 0);
-    const int plan_key = (int)n | (zero_warp ? 1 << 24 : 0) | (pose_only ? 1 << 25 : 0) | (self_cached ? 1 << 26 : 0) | (snap_mode == 1 ? 1 << 27 : 0);
+    // Self-stream cache: the previous forward on this workspace carried the same non-zero tag (and shape, and -- when the caller names its
+    // allocations -- the same workspace generation) -> the self-view encoder streams it left in the workspace are what this forward would
+    // compute.  Anything else runs (and re-fills) them.  The record is INVALIDATED here and committed only after this forward's kernels
+    // have been enqueued: a forward that returns an error leaves no claim on the workspace's content.
+    RelposeSCNet::SelfState prev = net->self_state[workspace];
+    net->self_state[workspace] = RelposeSCNet::SelfState();
+    // (the accumulator snapshots are laid out per plan family: a pose-outputs forward has fewer decoder heads)
+    bool self_cached = self_tag != 0 && prev.tag == self_tag && prev.n == n && prev.H == H && prev.W == W && prev.pose_only == pose_only && !zero_warp &&
+                       prev.gen == ws_gen;
     Plan* plan = nullptr;
-    {
+    int snap_mode = 0;
+    for (int attempt = 0; attempt < 2 && !plan; ++attempt) {
+        // a tagged forward that computes the self streams also leaves the accumulator snapshots of the skip-connection halves
+        snap_mode = self_cached ? 2 : (self_tag != 0 ? 1 : 0);
+        const int plan_key = (int)n | (zero_warp ? 1 << 24 : 0) | (pose_only ? 1 << 25 : 0) | (self_cached ? 1 << 26 : 0) | (snap_mode == 1 ? 1 << 27 : 0);
         auto it = net->plans.find(std::make_pair(workspace, plan_key));
-        if (it != net->plans.end()) plan = (Plan*)it->second;
-    }
-    if (!plan) {
+        if (it != net->plans.end()) { plan = (Plan*)it->second; break; }
         const WsOffsets o = ws_offsets(net, n);
         if (workspace_bytes < o.total) return RELPOSE_ENOMEM;
-        if (net->plans.size() >= 16) free_plan(net);      // callers keep a few long-lived workspaces; bound the cache
-        plan = new Plan();
-        plan->n = n; plan->ws = workspace; plan->zero_warp = zero_warp; plan->pose_only = pose_only; plan->self_cached = self_cached;
+        if (net->plans.size() >= 16) {       // callers keep a few long-lived workspaces; bound the cache
+            free_plan(net);
+            self_cached = false;             // (free_plan drops every workspace's self-stream record with the plans)
+            snap_mode = self_tag != 0 ? 1 : 0;
+        }
+        Plan* p = new Plan();
+        p->n = n; p->ws = workspace; p->zero_warp = zero_warp; p->pose_only = pose_only; p->self_cached = self_cached;
         char* ws = (char*)workspace;
-        Builder B; B.net = net; B.n = n; B.G = G; B.plan = plan; B.zero_warp = zero_warp; B.pose_only = pose_only; B.self_cached = self_cached;
+        Builder B; B.net = net; B.n = n; B.G = G; B.plan = p; B.zero_warp = zero_warp; B.pose_only = pose_only; B.self_cached = self_cached;
         B.act = (float*)(ws + o.act); B.ss = (float2*)(ws + o.ss); B.splitk = (float*)(ws + o.splitk); B.statp = (double*)(ws + o.statp);
         B.persist = (float*)(ws + o.persist);
-        B.snapbuf = (float*)(ws + o.snap); B.snap_mode = snap_mode; plan->snap_mode = snap_mode;
+        B.snapbuf = (float*)(ws + o.snap); B.snap_mode = snap_mode; p->snap_mode = snap_mode;
         build_plan(net, n, B);
-        if (B.rc) { delete plan; return B.rc; }
-        RP_HIP(hipMalloc((void**)&plan->d_descs, MAX_DESCS * sizeof(ConvDesc)));
-        RP_HIP(hipMemcpy(plan->d_descs, plan->descs.data(), plan->descs.size() * sizeof(ConvDesc), hipMemcpyHostToDevice));
-        net->plans[std::make_pair(workspace, plan_key)] = plan;
+        if (B.rc) {
+            delete p;
+            // a self-cached plan that cannot be built (e.g. conv2 / conv3 statistics not on the fused path in some kernel selection) is not an
+            // error of the call: the full forward computes the same output and refills the cache
+            if (self_cached) { self_cached = false; continue; }
+            return B.rc;
+        }
+        RP_HIP(hipMalloc((void**)&p->d_descs, MAX_DESCS * sizeof(ConvDesc)));
+        RP_HIP(hipMemcpy(p->d_descs, p->descs.data(), p->descs.size() * sizeof(ConvDesc), hipMemcpyHostToDevice));
+        const int key2 = (int)n | (zero_warp ? 1 << 24 : 0) | (pose_only ? 1 << 25 : 0) | (self_cached ? 1 << 26 : 0) | (snap_mode == 1 ? 1 << 27 : 0);
+        net->plans[std::make_pair(workspace, key2)] = p;
+        plan = p;
     }
+    if (!plan) return RELPOSE_EINVAL;
     net->last_n = n;
     // two-stream mode: the HBM-bound head (resize_in, conv1) and tail (heads, resize_out) run on tail_stream, the MFMA-bound middle on `stream`
     static const bool head_side = RP_ENV("RELPOSE_NO_HEAD_OVERLAP") == nullptr;
@@ -3183,6 +3229,64 @@ int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_
                        act + net->bufs["OUT"].off * n, out, n, net->cf, H, W);
     mark(-3);
     RP_CHECK_LAUNCH();
+    {   // everything is enqueued: the workspace now holds (stream-ordered) the self-view streams of `self_tag`
+        RelposeSCNet::SelfState& st = net->self_state[workspace];
+        st.tag = self_tag; st.n = n; st.H = H; st.W = W; st.pose_only = pose_only; st.gen = ws_gen;
+    }
+    return 0;
+}
+
+// Multiply-accumulates one forward of the given plan family EXECUTES (descriptor-based: rows x K x Cout of every launched member, with the
+// slices / chunks / members the level-0 plan and the self-stream cache leave out removed) -- bench.py's plan-aware in-loop roofline divides
+// it by the same count of the full plan.  Host-only (a dry-run plan build: no device memory is touched).
+int relpose_scnet_plan_macs(RelposeSCNet* net, int32_t n, int32_t flags, int32_t self_cached, double* macs_out) {
+    if (!net || !net->finalized || !macs_out || n <= 0 || (n & 1)) return RELPOSE_EINVAL;
+    const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2 && !self_cached;
+    const bool pose_only = (flags & RELPOSE_FWD_POSE_OUTPUTS) != 0;
+    Plan dry;
+    Builder B; B.net = net; B.n = n; B.G = n / 2; B.act = nullptr; B.ss = nullptr; B.splitk = nullptr; B.statp = nullptr; B.plan = &dry;
+    B.zero_warp = zero_warp; B.pose_only = pose_only; B.self_cached = self_cached != 0;
+    B.snapbuf = (float*)(uintptr_t)4096;       // (never dereferenced: makes the builder record ConvDesc::snap_mode in the dry run)
+    B.snap_mode = self_cached ? 2 : 1; dry.snap_mode = B.snap_mode;
+    build_plan(net, n, B);
+    if (B.rc) return B.rc;
+    double macs = 0;
+    for (const Op& op : dry.ops) {
+        if (op.type == OP_CONV || op.type == OP_CONV_S2 || op.type == OP_CONV_STRIP || op.type == OP_DECONV_TILE) {
+            for (int i = op.first; i < op.first + op.count; ++i) {
+                const ConvDesc& d = dry.descs[i];
+                double rowsK;
+                if (op.type == OP_CONV_STRIP && d.ksplit > 1 && (d.shared_slices || d.skip_slices)) {
+                    rowsK = 0;
+                    for (int ks = 0; ks < d.ksplit; ++ks) {
+                        if ((d.skip_slices >> ks) & 1) continue;
+                        const double rows = ((d.shared_slices >> ks) & 1) ? 2.0 * d.Hp * d.Wp : (double)d.M;
+                        rowsK += rows * d.K / d.ksplit;
+                    }
+                } else if (op.type == OP_DECONV_TILE && d.nsrc == 2 && plan_snap_mode(dry, i) == 2) {
+                    rowsK = (double)d.M * d.ntaps * d.src[0].C;          // the skip source's chunks come from the snapshot
+                } else rowsK = (double)d.M * d.K;
+                macs += rowsK * d.Cout;
+            }
+        } else if (op.type == OP_CONV1) {
+            // six 3x3 blocks (Cin 4 / 4 / 2 -> 32), self + warped stream each; level 0 runs the warped blocks on the first image pair only,
+            // a self-cached forward the warped blocks only
+            const double blk = 224.0 * 224 * 32 * (36 + 36 + 18);
+            const double self_imgs = self_cached ? 0 : n, warp_imgs = zero_warp ? 2 : n;
+            macs += blk * (self_imgs + warp_imgs);
+        } else if (op.type == OP_HEADS) {
+            // 1x1 heads: rgb / n / d read cat(D2 32, A1 skip 32), s / f read 64 channels of D2; a self-cached forward takes the skip halves' sums
+            // from the snapshot; the pose-outputs plan skips the rgb and semantic heads
+            const double px = (double)n * 224 * 224;
+            const int hc[5] = {3, 3, 1, net->S, 32};
+            for (int m = 0; m < 5; ++m) {
+                if (pose_only && (m == 0 || m == 3)) continue;
+                const int cin = (m < 3 && self_cached) ? 32 : 64;
+                macs += px * cin * hc[m];
+            }
+        }
+    }
+    *macs_out = macs;
     return 0;
 }
 

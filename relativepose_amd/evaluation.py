@@ -120,7 +120,9 @@ class SyntheticBatch:
     def take(self, idx):
         from . import synth
         parts = [synth.make_pairs(1, self.seed + int(b), self.dataset, h=self.h) for b in idx]
-        kps = [synth.make_keypoints(1, self.keypoints, self.seed + 7919 * int(b), self.mask_method, h=self.h) for b in idx]
+        # (both seeds are functions of the GLOBAL pair index seed + b only: the same pair gets the same panoramas and keypoints under any
+        # --batch, so result files are comparable / resumable across batch sizes)
+        kps = [synth.make_keypoints(1, self.keypoints, 7919 * (self.seed + int(b)) + 13, self.mask_method, h=self.h) for b in idx]
         out = {k: np.concatenate([p[k] for p in parts]) for k in ("rgb", "norm", "depth", "R")}
         out["pts"], out["ptw"] = np.concatenate([k[0] for k in kps]), np.concatenate([k[1] for k in kps])
         return out
@@ -188,39 +190,49 @@ def evaluate_pairs_sharded(pipe, batches, device, result_path=None, names=None, 
         dist.broadcast(t, 0)
         done = int(t.item())
     todo = [(i, max(0, done - int(starts[i]))) for i in range(len(batches)) if int(starts[i + 1]) > done]     # (batch, first pair still to do)
+    # a ROUND = the unit of gathering and saving (default: the whole list).  Device memory does NOT grow with it: the batches of a round are
+    # prepared lazily, at most `depth` at a time (run_pipelined(provider=...)), and a batch's prepared state and host arrays are dropped as
+    # soon as its records are built (the default run used to prepare every batch up front -- 140 GB at 2048 pairs).
     nround = len(todo) if round_batches is None else max(1, int(round_batches))
     for r0 in range(0, len(todo), max(1, nround)):
         chunk = todo[r0:r0 + nround]
-        states, local, subs = [], [], []
-        for i, first in chunk:
+        local, mine = [], []
+        for j, (i, first) in enumerate(chunk):
             lo, hi = D.shard_range(sizes[i] - first, rank, world)
             idx = np.arange(first + lo, first + hi)
             local.append(idx)
             if len(idx):
-                b = _batch_take(batches[i], idx)
-                subs.append(b)
-                states.append(pipe.prepare(b["rgb"], b["norm"], b["depth"], b["pts"], b["ptw"], device))
-        res = pipe.run_pipelined(states, len(states), depth=min(depth, max(1, len(states)))) if states else []
-        # records of this rank's pairs, poses stacked in (batch, pair) order
-        recs, poses, status, si = [], [], [], 0
-        for (i, first), idx in zip(chunk, local):
-            if not len(idx):
-                continue
-            pose, st = res[si][0], res[si][1]
-            si += 1
-            poses.append(pose.reshape(-1, 4, 4)); status.append(st.reshape(-1))
+                mine.append(j)
+        subs, recs, poses, status = {}, [], [None] * len(mine), [None] * len(mine)
+
+        def provider(q):
+            i, first = chunk[mine[q]]
+            b = _batch_take(batches[i], local[mine[q]])
+            subs[q] = b
+            return pipe.prepare(b["rgb"], b["norm"], b["depth"], b["pts"], b["ptw"], device)
+
+        def on_result(q, pose, st):
+            # records of this rank's pairs of batch q, built as soon as the batch is complete (the other in-flight batch keeps the GPU busy)
+            i, first = chunk[mine[q]]
+            idx, sub = local[mine[q]], subs.pop(q)
+            poses[q], status[q] = pose.reshape(-1, 4, 4), st.reshape(-1)
             ph = pose.detach().cpu().numpy().reshape(-1, 4, 4)
+            sh = st.detach().cpu().numpy().reshape(-1)
             k0 = int(starts[i])
-            sub = subs[si - 1]
             rr = record_fn(sub, idx, ph, k0) if record_fn is not None else _default_record(pipe, sub, ph, device, names, [k0 + int(b) for b in idx])
-            for b, rec in zip(idx, rr):
+            for j, (b, rec) in enumerate(zip(idx, rr)):
+                rec['status'] = int(sh[j])             # the matcher's per-pair status (0 ok, 1.. the reference's "return identity" exits)
                 recs.append((k0 + int(b), rec))
+            return None
+
+        if mine:
+            pipe.run_pipelined(None, len(mine), on_result=on_result, depth=min(depth, len(mine)), provider=provider)
         n_local = sum(len(ix) for ix in local)
         n_round = sum(sizes[i] - first for i, first in chunk)
         if world > 1:
             # ONE all_gather of this round's poses (+ status); blocks are per-rank concatenations, ragged by at most one pair per batch
             pl = torch.cat(poses) if poses else torch.zeros(0, 4, 4, dtype=torch.float64, device=device)
-            sl = torch.cat(status) if status else torch.zeros(0, dtype=torch.int32, device=device)
+            sl = torch.cat(status).to(torch.int32) if status else torch.zeros(0, dtype=torch.int32, device=device)
             counts = [sum(D.shard_range(sizes[i] - first, r, world)[1] - D.shard_range(sizes[i] - first, r, world)[0] for i, first in chunk)
                       for r in range(world)]
             bmax = max(counts)
@@ -231,21 +243,38 @@ def evaluate_pairs_sharded(pipe, batches, device, result_path=None, names=None, 
             D.COLLECTIVES["all_gather"] += 1
             gathered = [None] * world if rank == 0 else None
             dist.gather_object(recs, gathered, dst=0)
+            problem = None
             if rank == 0:
                 allrecs = [kr for part in gathered for kr in part]
-                # cross-check: the gathered poses are the ones the records were built from
+                # cross-check: the gathered poses are the ones the records were built from (NaN poses -- e.g. from NaN depth -- compare
+                # equal to themselves: a degenerate pair is a result, not a harness failure); the gathered status goes into the record
                 by_k = {}
                 for r in range(world):
                     ks = [int(starts[i]) + first + q for i, first in chunk for q in range(*D.shard_range(sizes[i] - first, r, world))]
                     for row, k in zip(out[r][:counts[r]].cpu().numpy(), ks):
-                        by_k[k] = row[:16].reshape(4, 4)
+                        by_k[k] = row
                 for k, rec in allrecs:
-                    if 'R_pred_44' in rec:
-                        assert np.array_equal(by_k[k][:3, :4], np.asarray(rec['R_pred_44'])[:3, :4]), k
+                    if k not in by_k:
+                        problem = f"pair {k}: a record without a gathered pose"
+                        break
+                    if rec.get('status') != int(by_k[k][16]):
+                        problem = f"pair {k}: the gathered status differs from the status in its record"
+                        break
+                    if 'R_pred_44' in rec and not np.array_equal(by_k[k][:16].reshape(4, 4)[:3, :4], np.asarray(rec['R_pred_44'])[:3, :4], equal_nan=True):
+                        problem = f"pair {k}: the gathered pose differs from the pose its record was built from"
+                        break
+                if problem is None and len(allrecs) != n_round:
+                    problem = f"{len(allrecs)} records for {n_round} pairs"
+            # every rank learns the verdict BEFORE anyone raises: no rank is left waiting in the next round's collective
+            flag = [problem]
+            dist.broadcast_object_list(flag, src=0)
+            if flag[0] is not None:
+                raise RuntimeError("evaluate_pairs_sharded: " + flag[0])
         else:
             allrecs = recs
+            if len(allrecs) != n_round:
+                raise RuntimeError(f"evaluate_pairs_sharded: {len(allrecs)} records for {n_round} pairs")
         if rank == 0:
-            assert len(allrecs) == n_round
             stats += [rec for _, rec in sorted(allrecs, key=lambda kr: kr[0])]
             if result_path is not None:
                 save_results(result_path, stats)

@@ -120,22 +120,27 @@ class SCNet(torch.nn.Module):
 
     MAX_WORKSPACES = 8          # cached workspaces (148 MB per image each); the C side caches 16 launch plans keyed by (n, workspace)
 
+    _ws_generation = 0          # names every workspace ALLOCATION of the process (RelposeForwardArgs.workspace_generation)
+
     def _workspace(self, n, H, W, dev, ws_key=None, also_streams=()):
         import torch
         nbytes = _lib.lib().relpose_scnet_workspace_bytes(self._h, n, H, W)
         if nbytes == 0:
             raise RuntimeError("relpose_scnet_workspace_bytes: invalid shape (n must be even) or weights not loaded")
         key = (torch.cuda.current_stream().cuda_stream if ws_key is None else ("key", ws_key), n, dev.index)
-        ws = self._wss.pop(key, None)                      # (re-inserted below: the dict keeps least-recently-used order)
-        self._ws_new = ws is None or ws.numel() < nbytes   # a fresh allocation (maybe at a recycled address): forward tells the library
-        if self._ws_new:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ent = self._wss.pop(key, None)                     # (re-inserted below: the dict keeps least-recently-used order)
+        if ent is None or ent[0].numel() < nbytes:
+            # a fresh allocation (maybe at a recycled address): it gets a new generation id, which EVERY call on it carries -- the library
+            # uses the self-stream cache of a workspace pointer only under the generation that filled it, whoever touches the new block first
+            SCNet._ws_generation += 1
+            ent = (torch.empty(nbytes, dtype=torch.uint8, device=dev), SCNet._ws_generation)
             while len(self._wss) >= self.MAX_WORKSPACES:
                 # evict ONE entry, the least recently used.  Dropping it is stream-safe: every stream that ever ran a kernel on a
                 # workspace was recorded on it (record_stream below), so the caching allocator keeps the block until those kernels
                 # have finished, whichever stream asks for memory next.
                 self._wss.pop(next(iter(self._wss)))
-        self._wss[key] = ws
+        self._wss[key] = ent
+        ws, self._ws_gen = ent
         ws.record_stream(torch.cuda.current_stream())
         for s in also_streams:
             ws.record_stream(s)
@@ -150,6 +155,8 @@ class SCNet(torch.nn.Module):
         cls._tag_counter += 1
         return cls._tag_counter
 
+    FLAG_ZERO_WARP, FLAG_POSE_OUTPUTS = 1, 2       # RELPOSE_FWD_* (include/relpose.h)
+
     def forward(self, x, out=None, tail_stream=None, ws_key=None, zero_warp=False, outputs="all", self_tag=0):
         """tail_stream (a torch stream; not part of the reference interface): run the HBM-bound tail of the forward (heads + final
         resize) there, behind the convolutions on the current stream (relpose_scnet_forward2) -- `out` is then valid on tail_stream only.
@@ -163,22 +170,48 @@ class SCNet(torch.nn.Module):
         self_tag: non-zero = the caller's name for the content of x[:, 0:8] (the masked own views, constant across the levels of a scan
         pair's recurrence, evaluation.py:217-242): a forward that finds the previous forward of its workspace carried the same tag reuses
         that forward's self-view encoder streams (relpose_scnet_forward4; bitwise the same output).  0 = always recompute."""
+        flags = (self.FLAG_ZERO_WARP if zero_warp else 0) | {"all": 0, "pose": self.FLAG_POSE_OUTPUTS}[outputs]
+        return self.forward_flags(x, out, flags, self_tag, tail_stream, ws_key)
+
+    def forward_flags(self, x, out=None, flags=0, self_tag=0, tail_stream=None, ws_key=None):
+        """The forward as the C ABI sees it (relpose_scnet_forward_ex): `flags` = RELPOSE_FWD_* bits, `tail_stream` a torch stream, a raw
+        HIP stream handle (int) or None.  `forward` and torch.ops.relpose.scnet_forward both end here."""
         import torch
-        dev = _lib.require_gpu()
+        _lib.require_gpu()
         if not self._loaded:
             raise RuntimeError("load_state_dict first")
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 16
         x = x.contiguous()
         n, _, H, W = x.shape
+        if isinstance(tail_stream, int):
+            tail_stream = None if tail_stream == 0 else torch.cuda.ExternalStream(tail_stream)
         ws = self._workspace(n, H, W, x.device, ws_key, () if tail_stream is None else (tail_stream,))
+        if tail_stream is not None:
+            x.record_stream(tail_stream)                   # (the input resize runs there)
         if out is None:
             out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
-        s0 = _lib.stream_ptr()
-        rc = _lib.lib().relpose_scnet_forward4(self._h, _lib.ptr(x), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(), s0,
-                                               s0 if tail_stream is None else C.c_void_p(tail_stream.cuda_stream),
-                                               (1 if zero_warp else 0) | {"all": 0, "pose": 2}[outputs] | (4 if self._ws_new else 0), int(self_tag))
-        _lib.check(rc, "relpose_scnet_forward")
+            if tail_stream is not None:
+                out.record_stream(tail_stream)
+        else:
+            assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, self.out_channels, H, W)
+        a = _lib.ForwardArgs()
+        a.struct_size = C.sizeof(_lib.ForwardArgs)
+        a.flags = int(flags) & 3
+        a.x, a.out = x.data_ptr(), out.data_ptr()
+        a.n_images, a.H, a.W = n, H, W
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.stream = torch.cuda.current_stream().cuda_stream
+        a.tail_stream = a.stream if tail_stream is None else tail_stream.cuda_stream
+        a.self_tag = int(self_tag)
+        a.workspace_generation = self._ws_gen
+        _lib.check(_lib.lib().relpose_scnet_forward_ex(self._h, C.byref(a)), "relpose_scnet_forward_ex")
         return out
+
+    def plan_macs(self, n, flags=0, self_cached=False):
+        """Multiply-accumulates one forward of n images executes under a plan family (relpose_scnet_plan_macs; host-only)."""
+        v = C.c_double()
+        _lib.check(_lib.lib().relpose_scnet_plan_macs(self._h, int(n), int(flags), 1 if self_cached else 0, C.byref(v)), "relpose_scnet_plan_macs")
+        return v.value
 
     def read_tap(self, name):
         """Raw (pre-BatchNorm) NHWC activations of buffer ``name`` from the last forward: [n,H,H,C]."""

@@ -10,7 +10,9 @@ kernel: calling an op with CPU tensors raises torch's "no kernel for backend CPU
 error (no silent fallback).
 
     import relativepose_amd.ops            # registers the namespace
-    f = torch.ops.relpose.scnet_forward(x, net.handle)
+    f = torch.ops.relpose.scnet_forward(x, net.handle)                                   # = net(x)
+    f = torch.ops.relpose.scnet_forward(x, net.handle, flags, self_tag, tail_stream)     # the plans of relpose_scnet_forward_ex
+    torch.ops.relpose.scnet_forward_out(x, net.handle, f, flags, self_tag, tail_stream, ws_key)   # into a caller-owned output (the benchmarked loop)
     x16 = torch.ops.relpose.warp_pairs_(x16, poses, dataset_id)
     pc, nrm, feat = torch.ops.relpose.sample_primitives(f, feat_off, obs_n, obs_d, pts, npts, mask_id, compose, dataset_id)
     pose, status = torch.ops.relpose.match_pairs(pc_s, n_s, f_s, w_s, pc_t, n_t, f_t, w_t, ns, nt, params, topK, method, max_edges)
@@ -38,7 +40,11 @@ _INV_METHOD = {v: k for k, v in _rp.METHODS.items()}
 
 _lib = torch.library.Library("relpose", "DEF")
 
-_lib.define("scnet_forward(Tensor x, int net_handle) -> Tensor")
+# flags: RELPOSE_FWD_ZERO_WARP (1) | RELPOSE_FWD_POSE_OUTPUTS (2); self_tag: the self-stream cache tag (0 = recompute); tail_stream: a raw HIP
+# stream handle for the HBM-bound head / tail of the forward (0 = the current stream); ws_key: names the workspace (0 = one per current stream)
+# -- the arguments of relpose_scnet_forward_ex (include/relpose.h), so that the configuration bench.py measures is reachable through the ops
+_lib.define("scnet_forward(Tensor x, int net_handle, int flags=0, int self_tag=0, int tail_stream=0, int ws_key=0) -> Tensor")
+_lib.define("scnet_forward_out(Tensor x, int net_handle, Tensor(a!) out, int flags=0, int self_tag=0, int tail_stream=0, int ws_key=0) -> Tensor(a!)")
 _lib.define("apply_mask(Tensor x, int method) -> (Tensor, Tensor)")
 _lib.define("build_view(Tensor rgb, Tensor norm, Tensor depth, int method) -> Tensor")
 _lib.define("warp(Tensor view, Tensor pose, int dataset) -> Tensor")
@@ -74,9 +80,14 @@ def _para(params, topK, method=0):
     return p
 
 
-def _scnet_forward(x, net_handle):
+def _scnet_forward(x, net_handle, flags=0, self_tag=0, tail_stream=0, ws_key=0):
     net = _model.SCNet.from_handle(net_handle)
-    return net.forward(x)
+    return net.forward_flags(x, None, int(flags), int(self_tag), int(tail_stream), int(ws_key) or None)
+
+
+def _scnet_forward_out(x, net_handle, out, flags=0, self_tag=0, tail_stream=0, ws_key=0):
+    net = _model.SCNet.from_handle(net_handle)
+    return net.forward_flags(x, out, int(flags), int(self_tag), int(tail_stream), int(ws_key) or None)
 
 
 def _apply_mask(x, method):
@@ -125,10 +136,10 @@ def _match_pairs(pc_s, normal_s, feat_s, weight_s, pc_t, normal_t, feat_t, weigh
     return res.pose, res.status
 
 
-for _name, _fn in (("scnet_forward", _scnet_forward), ("apply_mask", _apply_mask), ("build_view", _build_view), ("warp", _warp),
+for _name, _fn in (("scnet_forward", _scnet_forward), ("scnet_forward_out", _scnet_forward_out), ("apply_mask", _apply_mask), ("build_view", _build_view), ("warp", _warp),
                    ("warp_pairs_", _warp_pairs_), ("pano2pc", _pano2pc), ("pose_inverse", _pose_inverse),
                    ("sample_primitives", _sample_primitives), ("affinity_topk", _affinity_topk), ("match_pairs", _match_pairs)):
     _lib.impl(_name, _fn, "CUDA")
 
-OPS = ("scnet_forward", "apply_mask", "build_view", "warp", "warp_pairs_", "pano2pc", "pose_inverse", "sample_primitives",
+OPS = ("scnet_forward", "scnet_forward_out", "apply_mask", "build_view", "warp", "warp_pairs_", "pano2pc", "pose_inverse", "sample_primitives",
        "affinity_topk", "match_pairs")

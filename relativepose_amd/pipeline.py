@@ -164,7 +164,7 @@ class RelativePosePipeline:
         self._net_stream = new_stream
         self._net_stream.wait_stream(torch.cuda.current_stream())
 
-    def run_pipelined(self, states, steps, on_result=None, depth=None, before_batch=None):
+    def run_pipelined(self, states, steps, on_result=None, depth=None, before_batch=None, provider=None):
         """`steps` consecutive batches through the hot path with `depth` of them in flight (a serving loop;
         default depth = len(states)): batch k uses the prepared buffers and the HIP stream of
         states[k % len(states)], so with more prepared states than batches in flight the loop rotates through
@@ -201,8 +201,12 @@ class RelativePosePipeline:
             while nxt < steps or live:
                 for slot in range(depth):
                     if slot not in live and nxt < steps:
-                        st = states[nxt % nst]
                         ss = self._slot_streams[slot]
+                        if provider is not None:
+                            st = provider(nxt)               # (allocates + uploads on the caller's stream)
+                            ss.wait_stream(cur)
+                        else:
+                            st = states[nxt % nst]
                         if st.get("stream") is not None and st["stream"] is not ss:
                             ss.wait_stream(st["stream"])         # the buffers' previous use (another slot / run_interleaved)
                         st["stream"] = ss
@@ -232,6 +236,8 @@ class RelativePosePipeline:
         for st in states:
             if "stream" in st:
                 cur.wait_stream(st["stream"])
+        for ss in self._slot_streams[:depth]:
+            cur.wait_stream(ss)
         cur.wait_stream(self._net_stream)
         self._chain_nets = False
         return results
@@ -299,9 +305,11 @@ class RelativePosePipeline:
             R_hat, status = res.pose, res.status
         return R_hat, status, None
 
-    def run(self, st, R_forced=None, keep=None):
+    def run(self, st, R_forced=None, keep=None, primitives=None):
         """One pass of the hot path over the prepared batch.  Returns (pose [B,4,4] f64, status [B] i32,
-        [pose after each step]).  R_forced: optional list of [B,4,4] tensors (teacher forcing, tests)."""
+        [pose after each step]).  R_forced: optional list of [B,4,4] tensors (teacher forcing, tests).
+        primitives: a dict that receives the LAST level's matching primitives (pc, nn [B,2,N,3] f64, ft [B,2,N,32] f32: what the reference's
+        tuning script caches per pair, trainRelativePoseModuleRecFD.py:207-208; tune.cache_primitives)."""
         import torch
         B, h, N = st["B"], st["h"], st["N"]
         x = self._net_input(st)                                                               # [2B,16,h,4h]
@@ -316,7 +324,9 @@ class RelativePosePipeline:
             poses = torch.stack((inv, R_hat), 1).reshape(2 * B, 4, 4).contiguous()
             util.warp_pairs_dev(x, poses, self.dataset)       # x[:, 8:] = partner view warped by the pose estimate
             # level 0 starts from the identity: util.warping returns zeros (util.py:95-96) for every image, which SCNet can exploit
-            f = self.net.forward(x, zero_warp=(step == 0 and R_forced is None), outputs=self.outputs, self_tag=st["self_tag"])
+            # (the batch's preallocated output buffer, unless the caller keeps every level's output: `keep` entries must not alias)
+            f = self.net.forward(x, out=st["f"] if keep is None else None, zero_warp=(step == 0 and R_forced is None), outputs=self.outputs,
+                                 self_tag=st["self_tag"])
             pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
                                                     self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
@@ -326,6 +336,8 @@ class RelativePosePipeline:
                                        st["ns"], st["nt"], para, max_edges=self.max_edges)
             R_hat, status = res.pose, res.status
             trace.append(R_hat)
+            if primitives is not None:
+                primitives.update(pc=pc, nn=nn, ft=ft, step=step)
             if keep is not None:
                 keep.append({"x": x.clone(), "f": f, "pc": pc, "nn": nn, "ft": ft})
         return R_hat, status, trace

@@ -26,6 +26,36 @@ class PrimitiveSet:
         return rpmodule.match_pairs(*self.args, para).pose.cpu().numpy()
 
 
+def cache_primitives(pipe, batches, device=None):
+    """The producer of the primitive cache (trainRelativePoseModuleRecFD.py:129-212): run the recurrent loop over `batches` (dicts in the
+    DataLoader layout of evaluation.evaluate_pairs: rgb / norm [B,2,3,h,4h], depth [B,2,h,4h], pts [B,2,N,2], ptw [B,2,N], R [B,2,4,4]) and keep
+    the LAST level's matching primitives of every scan pair in the reference's dict format (:207-208)
+
+        {'pc_src' [n,3], 'normal_src' [n,3], 'feat_src' [n,32] f32, 'weight_src' [n], 'pc_tgt', 'normal_tgt', 'feat_tgt', 'weight_tgt', 'R_gt' [4,4]}
+
+    -- what `PrimitiveSet` / `objective` / `tune_step` consume (the reference np.save's the list, :212).  The reference runs the matcher on
+    the levels BEFORE the last one only (:197-205: the last level's pose is what the tuning optimises); the pipeline's last-level match is
+    computed and dropped.  Pairs a level leaves without keypoints (doCompletion == 0) keep their n = 0 arrays."""
+    import torch
+    dev = device if device is not None else _lib.require_gpu()
+    out = []
+    for batch in batches:
+        st = pipe.prepare(batch["rgb"], batch["norm"], batch["depth"], batch["pts"], batch["ptw"], dev)
+        prim = {}
+        pipe.run(st, primitives=prim)
+        pc, nn, ft = (prim[k].cpu().numpy() for k in ("pc", "nn", "ft"))
+        ns, nt = st["ns"].cpu().numpy(), st["nt"].cpu().numpy()
+        ws, wt = st["w_s"].cpu().numpy(), st["w_t"].cpu().numpy()
+        for b in range(st["B"]):
+            R_gt = np.matmul(batch["R"][b, 1], np.linalg.inv(batch["R"][b, 0]))          # evaluation.py:213 / trainRelativePoseModuleRecFD.py:118
+            out.append({'pc_src': pc[b, 0, :ns[b]].copy(), 'normal_src': nn[b, 0, :ns[b]].copy(), 'feat_src': ft[b, 0, :ns[b]].copy(),
+                        'weight_src': ws[b, :ns[b]].copy(),
+                        'pc_tgt': pc[b, 1, :nt[b]].copy(), 'normal_tgt': nn[b, 1, :nt[b]].copy(), 'feat_tgt': ft[b, 1, :nt[b]].copy(),
+                        'weight_tgt': wt[b, :nt[b]].copy(), 'R_gt': R_gt})
+        del st, prim
+    return out
+
+
 def objective(prims, para):
     """trainRelativePoseModuleRecFD.py:215-233: (mean squared Frobenius rotation error, mean angular distance)."""
     if not isinstance(prims, PrimitiveSet):

@@ -84,14 +84,28 @@ class _StubPipe:
     def prepare(self, rgb, norm, depth, pts, ptw, device):
         return {"tags": rgb[:, 0, 0, 0, 0].copy()}
 
-    def run_pipelined(self, states, steps, depth=None, **kw):
+    alive = 0          # prepared states currently held by the pipeline
+    max_alive = 0
+
+    def run_pipelined(self, states, steps, on_result=None, depth=None, before_batch=None, provider=None):
+        """The protocol of RelativePosePipeline.run_pipelined(provider=...): batch k is prepared right before it starts, `depth` batches are
+        in flight, a batch's state is released when its result has been handed to on_result."""
         import torch
-        out = []
-        for st in states[:steps]:
+        cls = type(self)
+        live, nxt, out = [], 0, [None] * steps
+        while nxt < steps or live:
+            while len(live) < max(1, depth or 1) and nxt < steps:
+                live.append((nxt, provider(nxt) if provider is not None else states[nxt]))
+                nxt += 1
+                cls.alive += 1
+                cls.max_alive = max(cls.max_alive, cls.alive)
+            k, st = live.pop(0)
             t = torch.from_numpy(st["tags"]).to(torch.float64)
             pose = torch.eye(4, dtype=torch.float64).repeat(len(t), 1, 1)
             pose[:, 0, 3] = t
-            out.append((pose, (t.to(torch.int32) % 3)))
+            status = t.to(torch.int32) % 3
+            out[k] = on_result(k, pose, status) if on_result is not None else (pose, status)
+            cls.alive -= 1
         return out
 
 
@@ -170,6 +184,36 @@ def test_sharded_evaluation_resumes_in_units_of_100_pairs(tmp_path):
     again = E.evaluate_pairs_sharded(Counting(), _stub_batches(sizes), torch.device("cpu"), result_path=path, record_fn=_stub_record,
                                      round_batches=1)
     assert [s["k"] for s in again] == list(range(222)) and Counting.prepared == 122
+    assert [s["status"] for s in again[100:]] == [k % 3 for k in range(100, 222)]          # the matcher's status travels into the records
     assert len(E.load_results(path)) == 222
     fresh = E.evaluate_pairs_sharded(Counting(), _stub_batches(sizes), torch.device("cpu"), result_path=path, record_fn=_stub_record, resume=False)
     assert len(fresh) == 222
+
+
+def test_sharded_evaluation_prepares_at_most_depth_batches_at_a_time():
+    """ADVICE r4 / VERDICT r4 weak #8: device memory must not grow with the number of batches -- with the default round (the whole list) a
+    run over 12 global batches holds at most `depth` prepared batches at any time (each pins ~2.2 GB at 32 pairs on the real pipeline)."""
+    import torch
+    from relativepose_amd import evaluation as E
+
+    class Bounded(_StubPipe):
+        alive = 0
+        max_alive = 0
+
+    sizes = [8] * 12
+    stats = E.evaluate_pairs_sharded(Bounded(), _stub_batches(sizes), torch.device("cpu"), record_fn=_stub_record, depth=2)
+    assert [s["k"] for s in stats] == list(range(96))
+    assert Bounded.max_alive == 2 and Bounded.alive == 0
+    Bounded.max_alive = 0
+    E.evaluate_pairs_sharded(Bounded(), _stub_batches(sizes), torch.device("cpu"), record_fn=_stub_record, depth=3)
+    assert Bounded.max_alive == 3
+
+
+def test_synthetic_batch_seeds_depend_on_the_global_pair_index_only():
+    """the same global pair gets the same panoramas AND keypoints however the split is cut into batches."""
+    from relativepose_amd import evaluation as E
+    a = E.SyntheticBatch(8, 4000, "suncg", "second", 20).take([5])
+    b = E.SyntheticBatch(4, 4004, "suncg", "second", 20).take([1])            # the same global pair 4005 in another batching
+    assert all(np.array_equal(a[k], b[k]) for k in ("rgb", "depth", "pts", "ptw", "R"))
+    c = E.SyntheticBatch(8, 4000, "suncg", "second", 20).take([4, 5])
+    assert not np.array_equal(c["pts"][0], c["pts"][1])

@@ -97,3 +97,33 @@ def test_config4_320x1280_f16x3_three_levels_vs_parameterised_oracle():
             matcher_iso_rot_err=iso_err)
         assert nbad <= 8 and f_err < 1e-3 and pc_err < 1e-3 and ft_err < 1e-3 and iso_err < 1e-4
     assert int(status[0]) == 0
+
+
+def test_config4_full_size_batch32_320x1280_f16x3_properties():
+    """BASELINE configs[4] at its BENCH size (32 scan pairs x 320x1280, f16x3 conv arithmetic, 3 free-running levels, N=200, max_edges as the
+    bench sets it): run-to-run deterministic (bitwise), every status 0, proper rotations, and bitwise equal to single-pair runs for sampled
+    pairs -- the same properties tests/test_gpu_e2e.py asserts for configs[1] and the test above for configs[2-3] (VERDICT r4 next #1b).
+    (Values are unpinnable at h=320 -- the reference asserts 160x640; the arithmetic itself is pinned at h=160 by
+    test_free_running_well_conditioned_16bit_conv_arithmetic.)"""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, mm, h, S, N, B = "suncg", "second", 320, 15, 200, 32
+    d = synth.make_pairs(B, 5000, ds, h=h)
+    pts, ptw = synth.make_keypoints(B, N, 5000, mm, h=h)
+    Cc = N * 5
+    pipe = RelativePosePipeline(_net(S, 1, weights.make_state_dict(7, S), "f16x3"), ds, mm, params.final_params(ds), max_edges=min(Cc * (Cc - 1), 1 << 20))
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    pose, status, _ = pipe.run(st)
+    pose2, status2, _ = pipe.run(st)
+    assert torch.equal(pose, pose2) and torch.equal(status, status2)
+    assert (status == 0).all(), status.cpu().tolist()
+    assert torch.isfinite(pose).all()
+    R = pose[:, :3, :3]
+    orth = (R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64, device=dev)).abs().max().item()
+    for b in (0, 13, 31):
+        st1 = pipe.prepare(d["rgb"][b:b + 1], d["norm"][b:b + 1], d["depth"][b:b + 1], pts[b:b + 1], ptw[b:b + 1], dev)
+        p1, s1, _ = pipe.run(st1)
+        assert torch.equal(p1[0], pose[b]) and int(s1[0]) == 0, b
+    log("config4_batch32_320x1280_f16x3", orthogonality=orth, status_ok=int((status == 0).sum().item()))
+    assert orth < 1e-9

@@ -29,10 +29,11 @@ pytestmark = pytest.mark.gpu
 ENV_SLACK = 3.0      # the GPU run is one more sample of a heavy-tailed distribution of which the envelope holds 8
 
 
-def _net(S, tanh, sd):
+def _net(S, tanh, sd, prec="f32"):
     from relativepose_amd.model import SCNet
     net = SCNet(SimpleNamespace(batchnorm=1, useTanh=tanh, skipLayer=1, outputType="rgbdnsf", snumclass=S))
     net.load_state_dict(sd)
+    net.set_precision(prec)
     return net
 
 
@@ -121,6 +122,55 @@ def test_free_running_well_conditioned_other_conventions_within_1e4(ci, golden_d
     for s in range(3):
         assert errs[s] < 1e-4, (s, errs)
         assert terr[s] < 1e-4, (s, terr)
+
+
+# ---- the 16-bit conv arithmetic of BASELINE configs[4] on the reference-pinned fixtures (VERDICT r4 next #1a) ------------------------------
+# configs[4] itself (320x1280) is unpinnable: the reference asserts 160x640 panoramas.  Its ARITHMETIC is pinnable: the seven well-conditioned
+# fixtures above are reference outputs at h=160, and the conv kernels do not depend on the panorama size (every input is resized to 224x224).
+#   f16x3  (3 fp16 MFMA terms per fp32 product: what `bench.py --config 4` runs)  -> the north-star bar, 1e-4, after every level
+#   f16    (one fp16 MFMA per product, SURVEY 8d config 5's literal "fp16 MFMA convs": an accuracy trade the caller opts into)
+#          -> asserted against F16_ROT_BOUND / F16_TRANS_BOUND, measured on the MI355X (profiles/r05_parity_full_suite.jsonl) with 3x slack;
+#          it does NOT meet the 1e-4 parity bar on every fixture and bench.py's `dtype` string says so.
+F16_ROT_BOUND = 5e-3
+F16_TRANS_BOUND = 5e-3
+_WC_ALL = [("wc", i) for i in range(len(WC_CASES))] + [("wc2", i) for i in range(len(WC2_CASES))]
+
+
+def _wc_fixture(kind, ci, golden_dir):
+    if kind == "wc":
+        g = np.load(os.path.join(golden_dir, "e2e_wc.npz"))
+        d, pts, ptw, T = synth.make_wc_pair(WC_CASES[ci], **WC_KW)
+        return ("suncg", "second", WC_S, 1, d, pts, ptw, T, [g[f"wc_{ci}_R{s}"] for s in range(3)], g[f"wc_{ci}_T"], g[f"wc_env_{ci}"])
+    g = np.load(os.path.join(golden_dir, "e2e_wc2.npz"))
+    ds, mm, S, tanh, seed, kw = WC2_CASES[ci]
+    d, pts, ptw, T = synth.make_wc_pair(seed, dataset=ds, mask_method=mm, **kw)
+    return (ds, mm, S, tanh, d, pts, ptw, T, [g[f"wc2_{ci}_R{s}"] for s in range(3)], g[f"wc2_{ci}_T"], g[f"wc2_env_{ci}"])
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+@pytest.mark.parametrize("kind,ci", _WC_ALL)
+def test_free_running_well_conditioned_16bit_conv_arithmetic(kind, ci, prec, golden_dir):
+    """The whole free-running loop (the GPU's own pose fed back, three levels) with the conv stack in the 16-bit MFMA modes against the
+    REFERENCE's pose after every level, on all seven reference-pinned fixtures (SUNCG, Matterport, ScanNet conventions).
+    Reference: model/mymodel.py:15-39 (conv2d / deconv2d blocks), evaluation.py:232-284."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    ds, mm, S, tanh, d, pts, ptw, T, Rref, Tg, env = _wc_fixture(kind, ci, golden_dir)
+    assert np.array_equal(T, Tg)
+    dev = torch.device("cuda:0")
+    sig = np.tile(np.array([WC_SIGMAS]), (3, 1))
+    pipe = RelativePosePipeline(_net(S, tanh, weights.make_descriptor_state_dict(WC_WEIGHT_SEED, S), prec), ds, mm, sig)
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+    pose, status, trace = pipe.run(st)
+    errs = [_rot_err(trace[s][0].cpu().numpy(), Rref[s]) for s in range(3)]
+    terr = [float(np.linalg.norm(trace[s][0].cpu().numpy()[:3, 3] - Rref[s][:3, 3])) for s in range(3)]
+    log("e2e_wc_free_running_16bit", fixture=kind, case=ci, dataset=ds, mask=mm, conv_precision=prec, gpu_rot_err_vs_reference=errs,
+        gpu_trans_err_vs_reference=terr, reference_envelope_max=env.max(0), bar=1e-4 if prec == "f16x3" else F16_ROT_BOUND)
+    assert int(status[0]) == 0
+    rb, tb = (1e-4, 1e-4) if prec == "f16x3" else (F16_ROT_BOUND, F16_TRANS_BOUND)
+    for s in range(3):
+        assert errs[s] < rb, (prec, s, errs)
+        assert terr[s] < tb, (prec, s, terr)
 
 
 def test_wc_teacher_forcing_changes_nothing_but_feedback_matters(golden_dir):

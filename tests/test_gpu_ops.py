@@ -85,6 +85,66 @@ def test_scnet_and_sampling_ops_equal_cabi(ctx):
     assert not torch.equal(n0, n1)                 # the two composition variants really differ (unobserved keypoints)
 
 
+def test_scnet_forward_op_reaches_every_plan_of_forward_ex(ctx):
+    """torch.ops.relpose.scnet_forward(x, handle, flags, self_tag, tail_stream, ws_key) / scnet_forward_out: the level-0 plan, the
+    pose-outputs plan, the self-stream cache and the two-stream tail -- i.e. the configuration bench.py measures -- through the custom-op
+    surface, bitwise equal to SCNet.forward with the same plan AND to the plain forward.
+    Reference call replaced: f = net(x), evaluation.py:242."""
+    torch, dev, net, S = ctx.torch, ctx.dev, ctx.net, ctx.S
+    from relativepose_amd import util
+    from relativepose_amd.model import SCNet
+    ops = torch.ops.relpose
+    rgb, nrm, dep, d = _inputs(ctx, B=2, seed=641)
+    view = util.build_view_dev(rgb, nrm, dep, "second")
+    x0 = torch.cat((view, torch.zeros_like(view)), 1).contiguous()            # level 0: warped view all zeros
+    x1 = x0.clone()
+    x1[:, 8:] = view.flip(0) * 0.5                                            # a later level: some non-zero warped view
+    ref0, ref1 = net(x0), net(x1)
+    ZW, PO = SCNet.FLAG_ZERO_WARP, SCNet.FLAG_POSE_OUTPUTS
+    # level-0 plan
+    assert torch.equal(ops.scnet_forward(x0, net.handle, ZW), ref0)
+    assert torch.equal(ops.scnet_forward(x0, net.handle, ZW), net.forward(x0, zero_warp=True))
+    # pose-outputs plan: normal / depth / features bitwise, rgb / semantic zero
+    fp = ops.scnet_forward(x1, net.handle, PO)
+    assert torch.equal(fp, net.forward(x1, outputs="pose"))
+    assert torch.equal(fp[:, 3:7], ref1[:, 3:7]) and torch.equal(fp[:, 7 + S:], ref1[:, 7 + S:]) and not fp[:, :3].any() and not fp[:, 7:7 + S].any()
+    # self-stream cache through the op: level 0 fills (tag), levels 1.. reuse; outputs bitwise those of tag-less forwards
+    tag = net.new_self_tag()
+    a0 = ops.scnet_forward(x0, net.handle, ZW, tag, 0, 77)
+    a1 = ops.scnet_forward(x1, net.handle, 0, tag, 0, 77)
+    a2 = ops.scnet_forward(x1, net.handle, 0, tag, 0, 77)
+    assert torch.equal(a0, ref0) and torch.equal(a1, ref1) and torch.equal(a2, ref1)
+    # ... into a caller-owned output, with the HBM-bound head / tail on a second stream (what run_pipelined enqueues)
+    side = torch.cuda.Stream()
+    out = torch.empty_like(ref1)
+    tag = net.new_self_tag()
+    torch.cuda.synchronize()
+    r0 = ops.scnet_forward_out(x0, net.handle, out, ZW, tag, side.cuda_stream, 78)
+    assert r0.data_ptr() == out.data_ptr()
+    side.synchronize()
+    assert torch.equal(out, ref0)
+    ops.scnet_forward_out(x1, net.handle, out, 0, tag, side.cuda_stream, 78)
+    side.synchronize()
+    assert torch.equal(out, ref1)
+
+
+def test_plan_macs_full_plan_equals_survey_count_and_cached_plans_are_smaller(ctx):
+    """relpose_scnet_plan_macs: the full plan's descriptor-based count against SURVEY 2.3(i)'s 18.07 GMAC per image (the launched
+    members execute a few padded taps of the 3x3 bottleneck transposed convs on top: < 1 %), and the level-0 / self-cached plans strictly
+    below it -- bench.py's roofline.in_loop is the ratio."""
+    net = ctx.net
+    from relativepose_amd.model import SCNet
+    n = 64
+    full = net.plan_macs(n)
+    assert abs(full / n / 18.07e9 - 1) < 0.01, full / n
+    lvl0 = net.plan_macs(n, SCNet.FLAG_ZERO_WARP)
+    cached = net.plan_macs(n, 0, self_cached=True)
+    pose = net.plan_macs(n, SCNet.FLAG_POSE_OUTPUTS)
+    from gpu_util import log
+    log("plan_macs", full_gmac_per_image=full / n / 1e9, level0_fraction=lvl0 / full, cached_fraction=cached / full, pose_outputs_fraction=pose / full)
+    assert 0.6 < cached / full < lvl0 / full < 1.0 and 0.6 < pose / full < 1.0
+
+
 def test_matcher_ops_equal_cabi(ctx):
     torch, dev = ctx.torch, ctx.dev
     from relativepose_amd import ops as O
