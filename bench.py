@@ -86,6 +86,11 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
     ap.add_argument("--batches", type=int, default=4, help="distinct prepared batches rotated through the in-flight slots")
+    ap.add_argument("--keypoint-mode", choices=["given", "reference"], default="given",
+                    help="given (default, the BASELINE workload: one injected keypoint set per view for all levels, SURVEY 8d) | reference: every "
+                         "level derives its keypoints from its own feature maps like rputil.getKeypoint (synthetic SIFT detections given once; "
+                         "descriptor gather + fused distance-map / NMS + random fill on the device INSIDE the timed region) -- reported beside the headline")
+    ap.add_argument("--sift", type=int, default=120, help="--keypoint-mode reference: synthetic SIFT detections per view (+ <= 60 / <= 90 derived ones)")
     return ap.parse_args(argv)
 
 
@@ -221,6 +226,10 @@ def worker(args):
     prec = args.precision or cfg["precision"]
     ds, mm, h, S = cfg["dataset"], cfg["mask"], cfg["h"], cfg["S"]
     N = args.keypoints or cfg["N"]
+    if args.keypoint_mode == "reference":
+        N = args.sift + 120                 # capacity: detections + <= 60 cross-view picks + <= 60 picks / 30 random points per view ('second')
+        if mm == "kinect":
+            N = 300 + 60 + 200              # 300 sampled detections + 60 picks + <= 200 picks / 100 random points (rputil.py:240-353)
     if args.scaling == "strong":
         total = args.total_pairs
     else:
@@ -238,7 +247,11 @@ def worker(args):
     Cc = N * 5
     pipe = RelativePosePipeline(net, ds, mm, sigmas, max_edges=min(Cc * (Cc - 1), (1 << 20) * max(1, (N // 200) ** 2)),
                                 outputs="pose" if args.pose_outputs else "all", self_stream_cache=not args.no_self_cache,
-                                tail_overlap=not args.no_tail_overlap, net_priority=args.net_priority, loop_fit_cluster=args.fit_cluster)
+                                tail_overlap=not args.no_tail_overlap, net_priority=args.net_priority, loop_fit_cluster=args.fit_cluster,
+                                keypoints=args.keypoint_mode)
+    ref_kp = args.keypoint_mode == "reference"
+    if ref_kp:
+        from relativepose_amd import rputil
     batches, first = [], None
     for j in range(nbatch):
         seed = 1000 * (args.config + 1) + lo + 100000 * j      # seed = 1000*config + pair index; slot j>0: other pairs
@@ -246,7 +259,12 @@ def worker(args):
         pj, wj = synth.make_keypoints(nloc, N, seed, mm, h=h)
         if j == 0:
             first = (dj, pj, wj)
-        batches.append(pipe.prepare(dj["rgb"], dj["norm"], dj["depth"], pj, wj, dev, keep_host=not args.no_h2d))
+        if ref_kp:
+            sift = [(rputil.map_detections(a, mm, h), rputil.map_detections(c, mm, h)) for a, c in synth.make_sift_detections(nloc, args.sift, seed, mm, h)]
+            batches.append(pipe.prepare(dj["rgb"], dj["norm"], dj["depth"], None, None, dev, keep_host=not args.no_h2d, sift=sift,
+                                        kp_seeds=[[seed + 31 * b + lvl for lvl in range(3)] for b in range(nloc)]))
+        else:
+            batches.append(pipe.prepare(dj["rgb"], dj["norm"], dj["depth"], pj, wj, dev, keep_host=not args.no_h2d))
 
     # RELPOSE_BENCH_COPY_STREAM=1: upload on a separate copy stream (a fifth stream: shares a hardware queue with one of the others)
     copy_stream = torch.cuda.Stream() if os.environ.get("RELPOSE_BENCH_COPY_STREAM") else None
@@ -298,7 +316,9 @@ def worker(args):
         import torch.distributed as dist
         ms = dt / args.steps * 1e3
         f32 = prec == "f32"
-        res = {"metric": "scan-pairs/sec end-to-end (completion+feat+spectral-match), 160x640 RGB-D",
+        # BASELINE.json's metric is quoted at 160x640; configs[4] is the same pipeline on 320x1280 panoramas and its lines say so
+        res = {"metric": "scan-pairs/sec end-to-end (completion+feat+spectral-match), 160x640 RGB-D" if h == 160 else
+                         f"scan-pairs/sec end-to-end (completion+feat+spectral-match), {h}x{4 * h} RGB-D (BASELINE configs[{args.config}]; the headline metric is quoted at 160x640)",
                "value": total * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "f32" if f32 else ("f16 (plain fp16 MFMA conv products, fp32 accumulate and fp32 BatchNorm statistics; not the fp32 parity configuration)"
@@ -309,6 +329,9 @@ def worker(args):
                "config": {"workload": cfg["label"], "baseline_config_index": args.config, "dataset": ds, "mask": mm, "pano": f"{h}x{4 * h}",
                           "parity": cfg.get("parity_note", "reference goldens at this size (tests/golden/*.npz, SURVEY 8c)"),
                           "pairs_per_step_total": total, "pairs_per_gpu": nloc, "keypoints": N, "semantic_classes": S,
+                          "keypoint_mode": ("reference: re-derived at every level from the level's feature maps (rputil.getKeypoint behind the SIFT detector, "
+                                            f"{args.sift} synthetic detections per view; up to {batches[0]['N']} keypoints per view); NOT the BASELINE workload") if ref_kp
+                                           else "given (one injected set per view for all levels: the BASELINE workload, SURVEY 8d)",
                           "recurrent_levels": 3, "conv_precision": prec, "parallelism": f"pairs sharded x{world}",
                           "batches_in_flight": depth, "prepared_batches_rotated": nbatch, "setup_passes_before_warmup": depth if args.warmup < depth else 0,
                           "scnet_outputs": "pose path only (normal, depth, features): opt-in, NOT the BASELINE metric" if args.pose_outputs else "all (like the reference)",
@@ -341,13 +364,27 @@ def worker(args):
             # split-16-bit modes: every fp32 product costs three dense 16-bit MFMA products -> algorithmic peak = 2500 / 3
             peak = PEAK_F32_MFMA_TFLOPS if f32 else (PEAK_F16_MFMA_TFLOPS if prec == "f16" else PEAK_F16_MFMA_TFLOPS / 3)
             tr = _traffic(f"config{args.config}_{prec}_pairs{nloc}")
-            res["roofline"] = {"kernel": "SCNet conv stack: conv_igemm_kernel + conv_s2_tile_kernel + deconv_tile_kernel + conv1_mfma_kernel + heads_kernel (fp32 MFMA 32x32x2)"
-                                         if f32 else ("conv_igemm_kernel (fp16 MFMA 32x32x16)" if prec == "f16" else f"conv_igemm_kernel (3 x {prec[:-2]} MFMA 32x32x16)"),
+            stack16 = ("SCNet conv stack: conv_s2_tile_kernel + conv_s2_strip_kernel + deconv_tile_kernel (SPLIT instantiations) + conv_igemm_kernel (conv6-9, deconv4-9) "
+                       "+ conv1_mfma_kernel + heads_kernel (fp32)" if prec != "bf16x3" else "SCNet conv stack: conv_igemm_kernel (every layer) + conv1_mfma_kernel + heads_kernel (fp32)")
+            # plan-aware in-loop fraction: what the three forwards of a step really execute (level 0 = the zero-warp plan, levels 1-2 = the
+            # self-stream cache) over the step time -- the number that sets the headline; "frac" above it is kernel efficiency on FULL forwards
+            FW = SCNet.FLAG_ZERO_WARP | (SCNet.FLAG_POSE_OUTPUTS if args.pose_outputs else 0)
+            m_full = net.plan_macs(2 * nloc)
+            f_lvl0 = net.plan_macs(2 * nloc, FW) / m_full
+            f_next = (net.plan_macs(2 * nloc, FW & ~SCNet.FLAG_ZERO_WARP, self_cached=True) if not args.no_self_cache
+                      else net.plan_macs(2 * nloc, FW & ~SCNet.FLAG_ZERO_WARP)) / m_full
+            exec_gflop = flops / 1e9 * (f_lvl0 + 2 * f_next)
+            res["roofline"] = {"kernel": "SCNet conv stack: conv_igemm_kernel + conv_s2_tile_kernel + conv_s2_strip_kernel + deconv_tile_kernel + conv1_mfma_kernel + heads_kernel (fp32 MFMA 32x32x2)"
+                                         if f32 else (stack16 + " -- fp16 MFMA 32x32x16" if prec == "f16" else stack16 + f" -- 3 x {prec[:-2]} MFMA 32x32x16 per fp32 product"),
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": tr["bytes"] if tr else None, "traffic_unit": "HBM bytes per forward (all conv launches; rocprofv3 PMC)",
                                "traffic_profile": tr["profile"] if tr else None,
                                "launches_per_forward": int(n_gemm), "ms_per_forward_gemm": g_ms, "ms_per_forward_other": o_ms,
-                               "algorithmic_gflop_per_forward": flops / 1e9}
+                               "algorithmic_gflop_per_forward": flops / 1e9,
+                               "in_loop": {"executed_gflop_per_step": exec_gflop, "achieved": exec_gflop / ms, "frac": exec_gflop / ms / peak,
+                                           "executed_fraction_of_full_forward": {"level0_zero_warp_plan": f_lvl0, "levels_1_2": f_next},
+                                           "note": "plan-aware: multiply-accumulates the three forwards of a step really launch (relpose_scnet_plan_macs) "
+                                                   "x 2 / ms_per_step / peak; the reference's algorithmic work per step is 3 x algorithmic_gflop_per_forward"}}
             # --- N x N affinity build at the bench batch and at a batch where the bytes are meaningful
             a_small = affinity_roofline(N, nloc, dev, sigmas)
             a_big = affinity_roofline(N, 1024, dev, sigmas)
@@ -361,7 +398,27 @@ def worker(args):
                                         "note": "headline = batch 1024 (one launch at the bench batch moves only "
                                                 f"{a_small['algorithmic_bytes_per_launch'] / 1e6:.1f} MB, i.e. less than 1 us of HBM time)"}
             res["roofline_geometry"] = geometry_roofline(cfg, 2 * nloc, N, dev, net.out_channels, pipe.feat_off)
-        if world == 1 and not args.no_cpu_baseline:
+            if ref_kp:
+                # the per-level keypoint stage alone (descriptors + fused distance / NMS + assembly): HIP events, back-to-back launches on a batch's
+                # tables; algorithmic bytes = every view's 32-channel feature map read once + the keypoint lists written
+                st0 = batches[0]
+                ftest = torch.randn(2 * nloc, net.out_channels, h, 4 * h, device=dev)
+                for _ in range(2):
+                    rputil.keypoints_reference_dev(ftest, pipe.feat_off, st0["kp"][0], mm, L=st0["N"], workspace=st0["kp_ws"])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    rputil.keypoints_reference_dev(ftest, pipe.feat_off, st0["kp"][0], mm, L=st0["N"], workspace=st0["kp_ws"])
+                e1.record(); e1.synchronize()
+                k_ms = e0.elapsed_time(e1) / 10
+                kb = 2 * nloc * (32 * h * 4 * h * 4 + st0["N"] * 24)
+                nq = int(st0["kp"][0]["nq"])
+                res["roofline_keypoints"] = {"kernel": "kp_desc_kernel + kp_tile_best_kernel + kp_pick_kernel + kp_assemble_kernel (csrc/keypoints.hip)", "bound": "hbm (by bytes) / valu (in practice: 96 rounded fp32 operations per pixel and query)",
+                                             "ms_per_level": k_ms, "queries": nq, "algorithmic_bytes_per_level": kb, "achieved": kb / (k_ms * 1e-3) / 1e9, "unit": "GB/s",
+                                             "peak": PEAK_HBM_GBS, "frac": kb / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                             "valu_gflops": nq * h * 4 * h * 96 / (k_ms * 1e-3) / 1e9}
+                del ftest
+        if world == 1 and not args.no_cpu_baseline and not ref_kp:      # (the oracle loop takes injected keypoints: the BASELINE workload only)
             res["cpu_baseline"] = cpu_baseline(cfg, N, first[0], first[1], first[2], sigmas)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -216,6 +216,26 @@ int relpose_feature_distance_map(const float* query, const float* feat, float* d
 /* rputil.Sampling :355-371 on exp(-dist/2): K x {argmax, suppress a +-window box}; pts [nmaps,K,2] f64 (x,y). */
 int relpose_nms_sampling(const float* dist, double* pts, int32_t nmaps, int32_t H, int32_t W, int32_t K, int32_t window, void* stream);
 
+/* The per-level keypoint derivation of the reference behind its SIFT detector, batched over the views of a batch of scan pairs
+ * (rputil.getKeypoint :141-237 / getKeypoint_kinect :240-353, called at every recurrent level through getMatchingPrimitive,
+ * rpmodule.py:511-533, evaluation.py:278): descriptors at the query points (interpolate :43-58), for every query the `topk`
+ * non-maximum-suppressed minima of its squared descriptor distance over the OTHER view's 32-channel feature map (:182-190, :212-214,
+ * Sampling :355-371) -- the [n,H,W] distance maps are never materialised --, the validity filter (:192-196), concatenation and the
+ * weights 1 / 0.99 (:226-235).  The np.random draws of getKeypoint do not depend on the features: the host pre-draws them in the
+ * reference's call order (relativepose_amd.rputil.keypoint_plan) and passes
+ *   f [n_views, ., H, W] the network output (features = channels feat_off .. feat_off+32 of every image; image_stride floats per image)
+ *   q_src_view [nq] image whose features a query samples, q_pt [nq,2] its normalised (x/W, y/H) float32 point,
+ *   q_map_view [nq] the view whose map it searches, queries grouped by that view: q_off [n_views+1]; nq_view_max = max group size
+ *   slot_kind [n_views,L]: the keypoint slots of every view in the reference's concatenation order: -1 empty, -2 a host coordinate
+ *   (slot_xy [n_views,L,2]: SIFT detections, random points), >= 0 the pick with linear index query * topk + k
+ * Outputs: pts [n_views,L,2] f64 pixel coordinates (x,y) compacted in slot order, weight [n_views,L] f64, npts [n_views]. */
+size_t relpose_keypoints_reference_workspace_bytes(int32_t nq, int32_t H, int32_t W, int32_t topk);
+int relpose_keypoints_reference(const float* f, int64_t image_stride, int32_t feat_off, int32_t n_views, int32_t H, int32_t W,
+                                const int32_t* q_src_view, const float* q_pt, const int32_t* q_map_view, const int32_t* q_off, int32_t nq,
+                                int32_t nq_view_max, int32_t topk, int32_t window, const int32_t* slot_kind, const double* slot_xy, int32_t L,
+                                int32_t mask_method, double* pts, double* weight, int32_t* npts, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 /* -------------------------------------------------------------------- SCNet
  * Replaces SCNet (model/mymodel.py:141-380; skipLayer=1, batchnorm=1, outputType 'rgbdnsf'). */
 typedef struct RelposeSCNet RelposeSCNet;

@@ -14,6 +14,7 @@ SOURCES = [
     ("matcher.hip", ["-ffp-contract=off"]),
     ("affinity.hip", ["-ffp-contract=off"]),
     ("geometry.hip", ["-ffp-contract=off"]),
+    ("keypoints.hip", ["-ffp-contract=off"]),
     ("scnet.hip", []),
 ]
 

@@ -8,8 +8,10 @@ B scan pairs and kept on the device from the input panoramas to the 4x4 poses:
         compose + sample keypoint primitives          evaluation.py:246-253, getMatchingPrimitive
         spectral matching + robust fit -> R_hat        RelativePoseEstimation_helper
 
-Keypoints are an input of this batched pipeline (the reference detects them per level with cv2 SIFT + feature-guided + random
-sampling, rputil.getKeypoint: built in relativepose_amd.rputil around a SIFT-detector hook).
+Keypoints: either an input (keypoints="given": ONE fixed set per view for all levels -- the BASELINE benchmark workload) or
+derived at EVERY level from that level's feature maps like the reference does (keypoints="reference": rputil.getKeypoint /
+getKeypoint_kinect behind their SIFT detector -- SIFT detections are level-invariant and given once per view, the feature-guided
+augmentation + random fill + weights run on the device per level, csrc/keypoints.hip; evaluation.py:278 -> rpmodule.py:511-533).
 """
 import numpy as np
 
@@ -22,8 +24,14 @@ class RelativePosePipeline:
     _net_streams = None
 
     def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0, compose=0, outputs="all",
-                 self_stream_cache=True, tail_overlap=True, net_priority=None, loop_fit_cluster=1):
+                 self_stream_cache=True, tail_overlap=True, net_priority=None, loop_fit_cluster=1, keypoints="given"):
         self.net = net
+        # "given": prepare(pts, ptw) fixes the keypoints of every view for all levels.  "reference": prepare(sift=...) takes the views' SIFT
+        # detections (panorama coordinates, rputil.map_detections) and every level derives its keypoints from its own feature maps, as
+        # rputil.getKeypoint does in the reference (the np.random draws pre-drawn per pair and level: prepare(kp_seeds=...)).
+        if keypoints not in ("given", "reference"):
+            raise ValueError("keypoints must be 'given' or 'reference'")
+        self.keypoints = keypoints
         # the masked own views (channels 0:8 of the net input) are written once per pass and only the warped partner view changes from
         # level to level (evaluation.py:217-242): levels >= 1 reuse level 0's self-view encoder streams (SCNet.forward(self_tag=...),
         # bitwise the same output).  False: every level recomputes them, like the reference.
@@ -51,11 +59,16 @@ class RelativePosePipeline:
         # other slot's convolutions; A/B switch)
         self.loop_fit_cluster = int(loop_fit_cluster)
 
-    def prepare(self, rgb, norm, depth, pts, ptw, device, keep_host=False):
+    def prepare(self, rgb, norm, depth, pts, ptw, device, keep_host=False, sift=None, kp_seeds=None):
         """Host arrays (dataset dict layout: rgb/norm [B,2,3,h,4h], depth [B,2,h,4h] f32; pts [B,2,N,2],
-        ptw [B,2,N] f64) -> device-resident state.  Not part of the timed region."""
+        ptw [B,2,N] f64) -> device-resident state.  Not part of the timed region.
+        keypoints="reference": pts / ptw are ignored (None); sift = [(source detections [n,2], target detections [m,2])] * B in panorama
+        coordinates (rputil.map_detections), kp_seeds [B][alter_steps] = the np.random seed of pair b's getKeypoint call at each level
+        (default: 7919 * b + level)."""
         import torch
         B, _, _, h, w = rgb.shape
+        if self.keypoints == "reference":
+            return self._prepare_reference(rgb, norm, depth, device, keep_host, sift, kp_seeds)
         pts = np.asarray(pts, dtype=np.float64)
         ptw = np.asarray(ptw, dtype=np.float64)
         N = pts.shape[2]
@@ -91,6 +104,54 @@ class RelativePosePipeline:
                 ("rgb", rgb.reshape(2 * B, 3, h, w), torch.float32), ("norm", norm.reshape(2 * B, 3, h, w), torch.float32),
                 ("depth", depth.reshape(2 * B, h, w), torch.float32), ("pts", pts.reshape(2 * B, N, 2), torch.float64))}
         return st
+
+    def _prepare_reference(self, rgb, norm, depth, device, keep_host, sift, kp_seeds):
+        """prepare() for keypoints="reference": the feature-independent half of every level's getKeypoint call is drawn here, on the host, in the
+        reference's np.random call order (rputil.keypoint_plan) and uploaded as query points + slot tables; one keypoint capacity L for all levels."""
+        import torch
+        from . import rputil
+        B, _, _, h, w = rgb.shape
+        if not self.completion:
+            raise NotImplementedError("keypoints='reference' with completion=0 (rpmodule.py:534-537 drops the weight != 1 keypoints) is not built")
+        if sift is None or len(sift) != B:
+            raise ValueError("keypoints='reference': prepare(sift=[(source detections, target detections)] * B) is required")
+        kind = self.mask_method
+        tabs = []
+        for lvl in range(self.alter_steps):
+            plans = []
+            for b in range(B):
+                seed = int(kp_seeds[b][lvl]) if kp_seeds is not None else 7919 * b + lvl
+                plans.append(rputil.keypoint_plan(sift[b][0], sift[b][1], kind, h, w, np.random.RandomState(seed)))
+            tabs.append(rputil.keypoint_tables(plans, h, w))
+        L = max(t["L"] for t in tabs)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
+        st = {"B": B, "h": h, "N": L}
+        st["rgb"] = t(rgb.reshape(2 * B, 3, h, w), torch.float32)
+        st["norm"] = t(norm.reshape(2 * B, 3, h, w), torch.float32)
+        st["depth"] = t(depth.reshape(2 * B, h, w), torch.float32)
+        st["kp"] = [rputil.upload_keypoint_tables(tb, device, L) for tb in tabs]
+        nb = max(_lib.lib().relpose_keypoints_reference_workspace_bytes(tb["nq"], h, w, tb["topk"]) for tb in tabs)
+        st["kp_ws"] = torch.empty(nb, dtype=torch.uint8, device=device)
+        st["eye"] = torch.eye(4, dtype=torch.float64, device=device).repeat(B, 1, 1).contiguous()
+        st["x"] = torch.empty(2 * B, 16, h, w, dtype=torch.float32, device=device)
+        st["f"] = torch.empty(2 * B, self.net.out_channels, h, w, dtype=torch.float32, device=device)
+        if keep_host:
+            st["host"] = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dt).pin_memory() for k, a, dt in (
+                ("rgb", rgb.reshape(2 * B, 3, h, w), torch.float32), ("norm", norm.reshape(2 * B, 3, h, w), torch.float32),
+                ("depth", depth.reshape(2 * B, h, w), torch.float32))}
+        return st
+
+    def _level_keypoints(self, st, f, step):
+        """(pts [2B,N,2], npts [2B], w_s, w_t [B,N], ns, nt [B]) of this level: the prepared set, or -- keypoints="reference" -- derived from this
+        level's feature maps on the device (rputil.getKeypoint behind the detector, relpose_keypoints_reference)."""
+        if self.keypoints != "reference":
+            return st["pts"], st["npts"], st["w_s"], st["w_t"], st["ns"], st["nt"]
+        from . import rputil
+        B, N = st["B"], st["N"]
+        pts, w, npts = rputil.keypoints_reference_dev(f, self.feat_off, st["kp"][min(step, len(st["kp"]) - 1)], self.mask_method, L=N, workspace=st["kp_ws"])
+        w = w.view(B, 2, N)
+        n2 = npts.view(B, 2)
+        return pts, npts, w[:, 0].contiguous(), w[:, 1].contiguous(), n2[:, 0].contiguous(), n2[:, 1].contiguous()
 
     @staticmethod
     def upload_inputs(st, copy_stream):
@@ -295,13 +356,14 @@ class RelativePosePipeline:
                 yield                                            # one yield per level: the other batches enqueue theirs
             else:
                 f = self.net.forward(x, out=st["f"], zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"])
-            pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
+            kpts, knpts, w_s, w_t, ns, nt = self._level_keypoints(st, f, step)
+            pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], kpts, knpts,
                                                     self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
             para = rpmodule.opts(*self.sigmas[min(step, len(self.sigmas) - 1)])
-            res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), st["w_s"],
-                                       pc[:, 1].contiguous(), nn[:, 1].contiguous(), ft[:, 1].contiguous(), st["w_t"],
-                                       st["ns"], st["nt"], para, max_edges=self.max_edges)
+            res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), w_s,
+                                       pc[:, 1].contiguous(), nn[:, 1].contiguous(), ft[:, 1].contiguous(), w_t,
+                                       ns, nt, para, max_edges=self.max_edges)
             R_hat, status = res.pose, res.status
         return R_hat, status, None
 
@@ -327,17 +389,18 @@ class RelativePosePipeline:
             # (the batch's preallocated output buffer, unless the caller keeps every level's output: `keep` entries must not alias)
             f = self.net.forward(x, out=st["f"] if keep is None else None, zero_warp=(step == 0 and R_forced is None), outputs=self.outputs,
                                  self_tag=st["self_tag"])
-            pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], st["pts"], st["npts"],
+            kpts, knpts, w_s, w_t, ns, nt = self._level_keypoints(st, f, step)
+            pc, nn, ft = util.sample_primitives_dev(f, self.feat_off, st["norm"], st["depth"], kpts, knpts,
                                                     self.mask_method, self.dataset, self.compose)
             pc, nn, ft = pc.view(B, 2, N, 3), nn.view(B, 2, N, 3), ft.view(B, 2, N, 32)
             para = rpmodule.opts(*self.sigmas[min(step, len(self.sigmas) - 1)])
-            res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), st["w_s"],
-                                       pc[:, 1].contiguous(), nn[:, 1].contiguous(), ft[:, 1].contiguous(), st["w_t"],
-                                       st["ns"], st["nt"], para, max_edges=self.max_edges)
+            res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), w_s,
+                                       pc[:, 1].contiguous(), nn[:, 1].contiguous(), ft[:, 1].contiguous(), w_t,
+                                       ns, nt, para, max_edges=self.max_edges)
             R_hat, status = res.pose, res.status
             trace.append(R_hat)
             if primitives is not None:
-                primitives.update(pc=pc, nn=nn, ft=ft, step=step)
+                primitives.update(pc=pc, nn=nn, ft=ft, step=step, w_s=w_s, w_t=w_t, ns=ns, nt=nt)
             if keep is not None:
-                keep.append({"x": x.clone(), "f": f, "pc": pc, "nn": nn, "ft": ft})
+                keep.append({"x": x.clone(), "f": f, "pc": pc, "nn": nn, "ft": ft, "pts": kpts.view(B, 2, N, 2), "w_s": w_s, "w_t": w_t, "ns": ns, "nt": nt})
         return R_hat, status, trace

@@ -9,6 +9,11 @@
   getKeypoint / getKeypoint_kinect  rputil.py:141-353  everything AROUND the SIFT detector: descriptor sampling at the detected points,
                                    feature-guided augmentation (distance maps + NMS on the GPU), random fill, weights
 
+  keypoint_plan / keypoint_tables / keypoints_reference_dev   the same derivation batched over the views of a batch of scan pairs and kept
+                                   on the device (csrc/keypoints.hip): the host pre-draws getKeypoint's np.random stream (it does not depend on
+                                   the features), the device does the feature-dependent part -- what RelativePosePipeline(keypoints="reference")
+                                   runs at every recurrent level
+
 SIFT detection itself (cv2.xfeatures2d, third-party) is a hook: set_sift_detector(fn), fn(gray uint8 [h,w]) -> [[x, y], ...]; when
 cv2 with xfeatures2d is importable it is the default."""
 import numpy as np
@@ -226,3 +231,140 @@ def getKeypoint_kinect(rs, rt, feats, featt, rs_full, rt_full):
     ptt = ptt[np.random.choice(range(len(ptt)), 300), :]
     inside = lambda p: ((p[:, 0] >= x0) * (p[:, 0] <= H + H // 2 + FW // 2) * (p[:, 1] >= y0) * (p[:, 1] <= H // 2 + FH // 2))
     return _keypoints_common(pts, ptt, feats, featt, inside, n_match=30, n_random_draw=120, n_random_keep=100)
+
+
+# ---- the batched, device-resident form (RelativePosePipeline(keypoints="reference")) ------------------------------------------------------
+KINECT = dict(KW=640, KH=480, FW=88, FH=66, N_SIFT=300)
+
+
+def map_detections(det, kind, H):
+    """Detector coordinates -> panorama coordinates: 'second' = the observed face [H, 2H) (rputil.py:163, :172), 'kinect' = the 640x480
+    frame scaled into the 88x66 observed crop (:262-265)."""
+    p = np.array(det, dtype=np.float64, copy=True).reshape(-1, 2)
+    if kind == "second":
+        p[:, 0] += H
+    else:
+        K = KINECT
+        p[:, 0] = p[:, 0] / K["KW"] * K["FW"] + (H + H // 2 - K["FW"] // 2)
+        p[:, 1] = p[:, 1] / K["KH"] * K["FH"] + (H // 2 - K["FH"] // 2)
+    return p
+
+
+def _inside(kind, H):
+    if kind == "second":
+        return lambda p: (p[:, 0] >= H) * (p[:, 0] <= H * 2)
+    FW, FH = KINECT["FW"], KINECT["FH"]
+    x0, y0 = H + H // 2 - FW // 2, H // 2 - FH // 2
+    return lambda p: ((p[:, 0] >= x0) * (p[:, 0] <= H + H // 2 + FW // 2) * (p[:, 1] >= y0) * (p[:, 1] <= H // 2 + FH // 2))
+
+
+def keypoint_plan(pts, ptt, kind, H, W, rng, n_match=30, topk=2):
+    """The feature-INDEPENDENT half of getKeypoint ('second', rputil.py:141-237) / getKeypoint_kinect ('kinect', :240-353) for one scan
+    pair and one recurrent level: every np.random call of the reference in its order (kinect: choice, choice for the 300 SIFT samples; then
+    choice, choice, rand, rand, choice), drawn from `rng` (np.random.RandomState(seed) yields the stream np.random.seed(seed) would).
+    pts / ptt: the views' SIFT detections in panorama coordinates (map_detections).  Returns the query points (pixel coordinates) whose
+    descriptors are matched against the OTHER view's feature map and the host-known keypoints:
+      q1 (source detections -> target map), q2 (target detections -> source map), q3 (source random points -> target map),
+      src_a = source detections, src_b = the kept random points, tgt_a = target detections
+    The reference's keypoint lists are then  source = [src_a, picks(q2), src_b],  target = [tgt_a, picks(q1), picks(q3)]  with `topk` picks
+    per query in query order, picks on the last row / column dropped."""
+    pts, ptt = np.asarray(pts, dtype=np.float64).reshape(-1, 2), np.asarray(ptt, dtype=np.float64).reshape(-1, 2)
+    if not len(pts) or not len(ptt):
+        raise ValueError("keypoint_plan: a view without SIFT detections (the reference skips such a pair, rputil.py:157-158)")
+    if kind == "kinect":
+        pts = pts[rng.choice(range(len(pts)), KINECT["N_SIFT"]), :]
+        ptt = ptt[rng.choice(range(len(ptt)), KINECT["N_SIFT"]), :]
+        n_draw, n_keep = 120, 100
+    else:
+        n_draw, n_keep = 30, 30
+    inside = _inside(kind, H)
+    fsselect = rng.choice(range(pts.shape[0]), min(n_match, pts.shape[0]))
+    ftselect = rng.choice(range(ptt.shape[0]), min(n_match, ptt.shape[0]))
+    xs = (rng.rand(n_draw) * W).astype('int').clip(0, W - 2)
+    ys = (rng.rand(n_draw) * H).astype('int').clip(0, H - 2)
+    ptsrnd = np.stack((xs, ys), 1)
+    ptsrnd = ptsrnd[~inside(ptsrnd)]
+    sel3 = rng.choice(range(ptsrnd.shape[0]), min(n_keep, ptsrnd.shape[0])) if ptsrnd.shape[0] else np.zeros(0, dtype=np.int64)
+    rnd = ptsrnd[sel3].astype('float').reshape(-1, 2)
+    return {"q1": pts[fsselect], "q2": ptt[ftselect], "q3": rnd, "src_a": pts, "src_b": rnd, "tgt_a": ptt, "topk": topk}
+
+
+def keypoint_tables(plans, H, W):
+    """The plans of the B scan pairs of a batch (one recurrent level) -> the host arrays of relpose_keypoints_reference: queries grouped by
+    the view whose feature map they search (view 2b = source of pair b, 2b + 1 = target), slot tables in the reference's concatenation
+    order.  Returns a dict of numpy arrays + sizes."""
+    B = len(plans)
+    topk = plans[0]["topk"]
+    nrm = lambda p: (np.asarray(p, dtype=np.float64).reshape(-1, 2) / np.array([W, H], dtype=np.float64)).astype(np.float32)   # torch_op.v(ptsNorm): float32
+    q_src, q_pt, q_map, q_off, slots = [], [], [], [0], []
+    nq = 0
+    for b, P in enumerate(plans):
+        n1, n2, n3 = len(P["q1"]), len(P["q2"]), len(P["q3"])
+        # view 2b (source map): q2 (sampled on the target image 2b+1)
+        first_q2 = nq
+        q_src += [2 * b + 1] * n2; q_map += [2 * b] * n2; q_pt.append(nrm(P["q2"])); nq += n2
+        q_off.append(nq)
+        # view 2b+1 (target map): q1 then q3 (sampled on the source image 2b)
+        first_q1 = nq
+        q_src += [2 * b] * (n1 + n3); q_map += [2 * b + 1] * (n1 + n3); q_pt.append(nrm(P["q1"])); q_pt.append(nrm(P["q3"])); nq += n1 + n3
+        first_q3 = first_q1 + n1
+        q_off.append(nq)
+        picks = lambda first, n: [(-3, first * topk + i) for i in range(n * topk)]
+        host = lambda a: [(-2, tuple(p)) for p in np.asarray(a, dtype=np.float64).reshape(-1, 2)]
+        slots.append(host(P["src_a"]) + picks(first_q2, n2) + host(P["src_b"]))
+        slots.append(host(P["tgt_a"]) + picks(first_q1, n1) + picks(first_q3, n3))
+    L = max(len(s_) for s_ in slots)
+    kind = np.full((2 * B, L), -1, dtype=np.int32)
+    xy = np.zeros((2 * B, L, 2), dtype=np.float64)
+    for v, sl in enumerate(slots):
+        for i, (k, val) in enumerate(sl):
+            if k == -2:
+                kind[v, i] = -2; xy[v, i] = val
+            else:
+                kind[v, i] = val
+    q_off = np.asarray(q_off, dtype=np.int32)
+    return {"q_src": np.asarray(q_src, dtype=np.int32), "q_pt": np.concatenate(q_pt).astype(np.float32).reshape(-1, 2),
+            "q_map": np.asarray(q_map, dtype=np.int32), "q_off": q_off, "nq": int(nq), "nq_view_max": int(np.diff(q_off).max()),
+            "slot_kind": kind, "slot_xy": xy, "L": int(L), "topk": int(topk)}
+
+
+def keypoints_reference_dev(f, feat_off, tab, mask_method, window=15, L=None, workspace=None):
+    """One recurrent level's keypoints of every view on the device: f [2B, C, H, W] the network output (CUDA), `tab` = keypoint_tables(...)
+    uploaded (torch tensors on f.device; see upload_keypoint_tables).  Returns (pts [2B, L, 2] f64, weight [2B, L] f64, npts [2B] i32)."""
+    import torch
+    from .util import MASKS
+    _lib.require_gpu()
+    n, C, H, W = f.shape
+    assert f.is_contiguous() and f.dtype == torch.float32
+    Lt = tab["L"]
+    L = Lt if L is None else L
+    assert L >= Lt and tab["slot_kind"].shape == (n, L)
+    dev = f.device
+    pts = torch.empty(n, L, 2, dtype=torch.float64, device=dev)
+    w = torch.empty(n, L, dtype=torch.float64, device=dev)
+    npts = torch.empty(n, dtype=torch.int32, device=dev)
+    nbytes = _lib.lib().relpose_keypoints_reference_workspace_bytes(tab["nq"], H, W, tab["topk"])
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rc = _lib.lib().relpose_keypoints_reference(_lib.ptr(f), C * H * W, int(feat_off), n, H, W, _lib.ptr(tab["q_src"]), _lib.ptr(tab["q_pt"]),
+                                                _lib.ptr(tab["q_map"]), _lib.ptr(tab["q_off"]), tab["nq"], tab["nq_view_max"], tab["topk"], int(window),
+                                                _lib.ptr(tab["slot_kind"]), _lib.ptr(tab["slot_xy"]), L, MASKS[mask_method], _lib.ptr(pts), _lib.ptr(w),
+                                                _lib.ptr(npts), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr())
+    _lib.check(rc, "relpose_keypoints_reference")
+    return pts, w, npts
+
+
+def upload_keypoint_tables(tab, device, L=None):
+    """keypoint_tables(...) -> the same dict with its arrays as torch tensors on `device` (slot tables padded to L columns)."""
+    import torch
+    out = dict(tab)
+    Lt = tab["L"]
+    L = Lt if L is None else L
+    kind, xy = tab["slot_kind"], tab["slot_xy"]
+    if L > Lt:
+        kind = np.concatenate((kind, np.full((kind.shape[0], L - Lt), -1, dtype=np.int32)), 1)
+        xy = np.concatenate((xy, np.zeros((xy.shape[0], L - Lt, 2))), 1)
+    for k, a in (("q_src", tab["q_src"]), ("q_pt", tab["q_pt"]), ("q_map", tab["q_map"]), ("q_off", tab["q_off"]), ("slot_kind", kind), ("slot_xy", xy)):
+        out[k] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    out["L"] = L
+    return out

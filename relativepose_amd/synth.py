@@ -150,6 +150,21 @@ def make_keypoints(B, N, seed, mask_method="second", h=H):
     return pts, wts
 
 
+def make_sift_detections(B, n, seed, mask_method="second", h=H):
+    """Synthetic SIFT detections for RelativePosePipeline(keypoints="reference") (the detector itself -- cv2 -- is injected / out of scope,
+    SURVEY.md 8a a6.3): per pair (source [n,2], target [n,2]) sub-pixel detector-frame coordinates -- the observed face [h,h] ('second',
+    rputil.py:155-163) or the 640x480 kinect frame ('kinect', :255-265) -- a few pixels off the borders like SIFT's."""
+    out = []
+    for b in range(B):
+        rs = np.random.RandomState(seed + 104729 * (b + 1))
+        if mask_method == "kinect":
+            det = lambda: np.stack((rs.uniform(8, 630, n), rs.uniform(8, 470, n)), 1)
+        else:
+            det = lambda: np.stack((rs.uniform(5, h - 7, n), rs.uniform(5, h - 7, n)), 1)
+        out.append((det(), det()))
+    return out
+
+
 def make_match_case(N, seed, inlier=0.6, noise=0.005, Nt=None):
     """Matcher-only input (helper dict format, reference rpmodule.py:317-326):
     random cloud, rigidly moved + permuted target, 60 % inliers."""

@@ -44,8 +44,8 @@ def cache_primitives(pipe, batches, device=None):
         prim = {}
         pipe.run(st, primitives=prim)
         pc, nn, ft = (prim[k].cpu().numpy() for k in ("pc", "nn", "ft"))
-        ns, nt = st["ns"].cpu().numpy(), st["nt"].cpu().numpy()
-        ws, wt = st["w_s"].cpu().numpy(), st["w_t"].cpu().numpy()
+        ns, nt = prim["ns"].cpu().numpy(), prim["nt"].cpu().numpy()          # (the last level's own keypoint set: keypoints="reference" derives one per level)
+        ws, wt = prim["w_s"].cpu().numpy(), prim["w_t"].cpu().numpy()
         for b in range(st["B"]):
             R_gt = np.matmul(batch["R"][b, 1], np.linalg.inv(batch["R"][b, 0]))          # evaluation.py:213 / trainRelativePoseModuleRecFD.py:118
             out.append({'pc_src': pc[b, 0, :ns[b]].copy(), 'normal_src': nn[b, 0, :ns[b]].copy(), 'feat_src': ft[b, 0, :ns[b]].copy(),

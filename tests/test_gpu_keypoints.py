@@ -79,3 +79,112 @@ def test_getkeypoint_without_detections_returns_nones():
         assert rputil.getKeypoint(rs, rt, torch.from_numpy(feats), torch.from_numpy(featt)) == (None,) * 6
     finally:
         rputil.set_sift_detector(old)
+
+
+# ---- the batched, device-resident derivation (csrc/keypoints.hip; RelativePosePipeline(keypoints="reference")) -----------------------------
+@pytest.mark.parametrize("kind,cis", [("second", (0, 1)), ("kinect", (2, 3))])
+def test_batched_keypoints_equal_the_reference_goldens(golden_dir, kind, cis):
+    """relpose_keypoints_reference on a BATCH of two scan pairs (4 views) against the reference's own getKeypoint / getKeypoint_kinect
+    outputs (getkeypoint.npz: the reference run with a cv2 stub returning the fixture's detections, np.random seeded): keypoint
+    coordinates and weights of both views, exactly -- descriptors at the selected detections, the fused distance-map + NMS picks (the maps
+    are never materialised), validity filter, random fill, concatenation order.  The host half (rputil.keypoint_plan) draws the reference's
+    np.random stream from RandomState(seed).  Reference: rputil.py:141-237, :240-353, :355-371."""
+    import torch
+    from cases import GK_CASES
+    from relativepose_amd import rputil, synth
+    g = np.load(os.path.join(golden_dir, "getkeypoint.npz"))
+    dev = torch.device("cuda:0")
+    H, W, S = 160, 640, 15
+    off = 7 + S
+    f = torch.randn(4, off + 32, H, W, device=dev)                 # the other channels of a network output: ignored
+    plans = []
+    for b, ci in enumerate(cis):
+        k, seed = GK_CASES[ci]
+        assert k == kind
+        _, _, feats, featt, det_s, det_t, _, _ = synth.make_keypoint_case(seed, kind)
+        f[2 * b, off:] = torch.from_numpy(feats).to(dev)
+        f[2 * b + 1, off:] = torch.from_numpy(featt).to(dev)
+        plans.append(rputil.keypoint_plan(rputil.map_detections(det_s, kind, H), rputil.map_detections(det_t, kind, H), kind, H, W,
+                                          np.random.RandomState(seed)))
+    tab = rputil.upload_keypoint_tables(rputil.keypoint_tables(plans, H, W), dev)
+    pts, w, npts = rputil.keypoints_reference_dev(f, off, tab, kind)
+    pts, w, npts = pts.cpu().numpy(), w.cpu().numpy(), npts.cpu().numpy()
+    for b, ci in enumerate(cis):
+        for v, (pn, wn) in enumerate((("pts", "ptsW"), ("ptt", "pttW"))):
+            ref_p, ref_w = g[f"gk_{ci}_{pn}"], g[f"gk_{ci}_{wn}"]
+            n = int(npts[2 * b + v])
+            assert n == len(ref_p), (ci, pn, n, len(ref_p))
+            assert np.array_equal(pts[2 * b + v, :n], ref_p), (ci, pn)
+            assert np.array_equal(w[2 * b + v, :n], ref_w), (ci, wn)
+            assert not w[2 * b + v, n:].any()
+    log("batched_keypoints_vs_reference_golden", kind=kind, keypoints_per_view=npts.tolist(), queries=int(tab["nq"]))
+
+
+def _sift_like(rs_, kind, n, h=160):
+    if kind == "kinect":
+        return np.stack((rs_.uniform(2, 636, n), rs_.uniform(2, 476, n)), 1)
+    return np.stack((rs_.uniform(1, h - 3, n), rs_.uniform(1, h - 3, n)), 1)
+
+
+@pytest.mark.parametrize("ds,kind,S,tanh", [("suncg", "second", 15, 1), ("scannet", "kinect", 21, 1)])
+def test_pipeline_reference_keypoints_equal_per_pair_getkeypoint_at_every_level(ds, kind, S, tanh):
+    """RelativePosePipeline(keypoints="reference"): 4 scan pairs x 3 free-running levels -- at every level the batched device derivation gives
+    each pair exactly the keypoints (coordinates, weights, counts, order) that the per-pair shim rputil.getKeypoint / getKeypoint_kinect
+    (pinned to the reference by getkeypoint.npz) computes from THAT level's feature maps of THAT pair with the same np.random seed, and
+    the poses are those of a keypoints="given" pipeline fed the same per-level sets.  Reference call site: evaluation.py:278 ->
+    rpmodule.getMatchingPrimitive :511-533."""
+    import torch
+    from types import SimpleNamespace
+    from relativepose_amd import params, rputil, synth, weights
+    from relativepose_amd.model import SCNet
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    B, h = 4, 160
+    d = synth.make_pairs(B, 8100, ds)
+    net = SCNet(SimpleNamespace(batchnorm=1, useTanh=tanh, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+    net.load_state_dict(weights.make_state_dict(9, S))
+    rs_ = np.random.RandomState(55)
+    dets = [(_sift_like(rs_, kind, 60 + 7 * b), _sift_like(rs_, kind, 45 + 5 * b)) for b in range(B)]
+    sift = [(rputil.map_detections(a, kind, h), rputil.map_detections(c, kind, h)) for a, c in dets]
+    seeds = [[1000 * b + lvl + 17 for lvl in range(3)] for b in range(B)]
+    pipe = RelativePosePipeline(net, ds, kind, params.final_params(ds), keypoints="reference")
+    st = pipe.prepare(d["rgb"], d["norm"], d["depth"], None, None, dev, sift=sift, kp_seeds=seeds)
+    keep = []
+    pose, status, trace = pipe.run(st, keep=keep)
+    off = 7 + S
+    img = np.zeros((h, 4 * h, 3), np.uint8)
+    full = np.zeros((480, 640, 3), np.uint8)
+    worst = 0
+    for lvl in range(3):
+        f = keep[lvl]["f"]
+        P, ns, nt = keep[lvl]["pts"].cpu().numpy(), keep[lvl]["ns"].cpu().numpy(), keep[lvl]["nt"].cpu().numpy()
+        ws, wt = keep[lvl]["w_s"].cpu().numpy(), keep[lvl]["w_t"].cpu().numpy()
+        for b in range(B):
+            queue = [dets[b][0], dets[b][1]]
+            old = rputil.set_sift_detector(lambda gray: queue.pop(0))
+            try:
+                np.random.seed(seeds[b][lvl])
+                fs, ft = f[2 * b, off:off + 32].contiguous(), f[2 * b + 1, off:off + 32].contiguous()
+                res = rputil.getKeypoint_kinect(img, img, fs, ft, full, full) if kind == "kinect" else rputil.getKeypoint(img, img, fs, ft)
+            finally:
+                rputil.set_sift_detector(old)
+            pts, _, ptsW, ptt, _, pttW = res
+            assert ns[b] == len(pts) and nt[b] == len(ptt), (lvl, b, ns[b], len(pts), nt[b], len(ptt))
+            assert np.array_equal(P[b, 0, :ns[b]], pts) and np.array_equal(P[b, 1, :nt[b]], ptt), (lvl, b)
+            assert np.array_equal(ws[b, :ns[b]], ptsW) and np.array_equal(wt[b, :nt[b]], pttW), (lvl, b)
+            worst = max(worst, int(ns[b]), int(nt[b]))
+    # the poses: the matcher shim on each level's kept primitives at the pair's own (ragged) counts and weights reproduces the level's pose bitwise
+    from relativepose_amd import rpmodule
+    sig = params.final_params(ds)
+    for lvl in range(3):
+        k = keep[lvl]
+        for b in (0, B - 1):
+            n_s, n_t = int(k["ns"][b]), int(k["nt"][b])
+            S_ = {"pc": k["pc"][b, 0, :n_s].cpu().numpy(), "normal": k["nn"][b, 0, :n_s].cpu().numpy(), "feat": k["ft"][b, 0, :n_s].cpu().numpy(),
+                  "weight": k["w_s"][b, :n_s].cpu().numpy()}
+            T_ = {"pc": k["pc"][b, 1, :n_t].cpu().numpy(), "normal": k["nn"][b, 1, :n_t].cpu().numpy(), "feat": k["ft"][b, 1, :n_t].cpu().numpy(),
+                  "weight": k["w_t"][b, :n_t].cpu().numpy()}
+            helper = rpmodule.RelativePoseEstimation_helper(S_, T_, rpmodule.opts(*sig[lvl]))
+            assert np.array_equal(helper, trace[lvl][b].cpu().numpy()), (lvl, b)
+    log("pipeline_reference_keypoints", dataset=ds, mask=kind, pairs=B, levels=3, max_keypoints_per_view=worst, status=status.cpu().tolist())
+    assert torch.isfinite(pose).all()
