@@ -8,7 +8,7 @@
 //   affinity_rows_kernel   small batches: a lane owns up to 8 targets in registers, the row is broadcast through SGPRs
 //   affinity_tile_kernel   large batches: approximate distances on the matrix pipe (fp16 MFMA) find the few entries per row
 //                          that matter; only those get the exact numpy-order arithmetic; wij rows are written once
-//   affinity_lds_kernel    nt_max > 512: targets transposed in LDS (any size up to 4096)
+//   affinity_lds_kernel    nt_max > 512: targets transposed in LDS (up to RELPOSE_MAX_TARGETS = 1152 targets: 136 B each + 128 B < 160 KB of LDS)
 // The bound is HBM by SURVEY 8(d)'s definition: (Ns + Nt) * 33 * 4 + Ns * Nt * 4 algorithmic bytes per pair-step.
 //
 // Compiled with -ffp-contract=off: the float32 distance must round like numpy.

@@ -447,8 +447,9 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
         const double hr = (MODE == 1) ? f.hh[r] : 0.0, ur = (MODE == 2) ? f.vec[r] : 0.0;
         double acc = 0.0;
         int cc[RP_SEG_DEPTH][U]; double w[RP_SEG_DEPTH][U];
-        // per-lane predication throughout: lanes whose segment is shorter issue neither the loads nor the LDS gathers of the
-        // dead slots (gating whole batches with a ballot, or processing all 32 slots branch-free, measured 20-30 % slower)
+        // dead slots (beyond a shorter segment's length) load the segment's FIRST entry again (a clamped, valid address: no branch around the
+        // loads) and their LDS gathers are issued like everybody's; only the accumulation is predicated (see `consume`).  Gating whole
+        // batches with a ballot, or processing all 32 slots branch-free, measured 20-30 % slower.
         auto load = [&](int buf, int kb) {
 #pragma unroll
             for (int q = 0; q < U; ++q) {

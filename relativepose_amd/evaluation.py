@@ -82,17 +82,28 @@ def summarize(error_stats):
     return out
 
 
+def _prepare_batch(pipe, batch, device):
+    """pipe.prepare for a DataLoader-layout batch dict under either keypoint mode: keypoints="given" reads "pts" / "ptw" (injected
+    keypoints), keypoints="reference" reads "sift" = [(source detections [n,2], target detections [m,2])] * B in panorama coordinates
+    (rputil.map_detections of the SIFT detector's output, rputil.py:152-172) and optionally "kp_seeds" [B][levels]: every level then derives
+    its keypoints from its own feature maps, as evaluation.py:278 does through getMatchingPrimitive."""
+    if getattr(pipe, "keypoints", "given") == "reference":
+        return pipe.prepare(batch["rgb"], batch["norm"], batch["depth"], None, None, device, sift=batch["sift"], kp_seeds=batch.get("kp_seeds"))
+    return pipe.prepare(batch["rgb"], batch["norm"], batch["depth"], batch["pts"], batch["ptw"], device)
+
+
 def evaluate_pairs(pipe, batches, device, result_path=None, names=None):
     """The reference's evaluation loop (evaluation.py:203-320) over an iterable of batches
     ``{"rgb","norm","depth","R" [B,2,4,4], "pts" [B,2,N,2], "ptw" [B,2,N]}`` (the DataLoader dict layout, batched, with the
-    injected keypoints): R_gt = R_t inv(R_s) (:185), overlap statistics from the observed clouds (util.parse_data +
+    injected keypoints; with RelativePosePipeline(keypoints="reference") a batch carries "sift" detections instead, _prepare_batch):
+    R_gt = R_t inv(R_s) (:185), overlap statistics from the observed clouds (util.parse_data +
     point_cloud_overlap), the recurrent pipeline on the GPU, then one result record per pair."""
     from . import util
     stats = []
     k = 0
     for batch in batches:
         B = batch["rgb"].shape[0]
-        st = pipe.prepare(batch["rgb"], batch["norm"], batch["depth"], batch["pts"], batch["ptw"], device)
+        st = _prepare_batch(pipe, batch, device)
         pose, status, _ = pipe.run(st)
         pose = pose.cpu().numpy()
         pcs, valid = util.depth2pc_dev(st["depth"], pipe.dataset)
@@ -114,8 +125,9 @@ class SyntheticBatch:
     seed + b) that materialises only the pairs a rank asks for -- evaluate_pairs_sharded hands every rank the same batch list, and a rank
     should not render the other ranks' panoramas."""
 
-    def __init__(self, size, seed, dataset, mask_method, keypoints, h=160):
+    def __init__(self, size, seed, dataset, mask_method, keypoints, h=160, sift=0):
         self.size, self.seed, self.dataset, self.mask_method, self.keypoints, self.h = size, seed, dataset, mask_method, keypoints, h
+        self.sift = int(sift)           # > 0: also `sift` synthetic SIFT detections per view (for RelativePosePipeline(keypoints="reference"))
 
     def take(self, idx):
         from . import synth
@@ -125,6 +137,11 @@ class SyntheticBatch:
         kps = [synth.make_keypoints(1, self.keypoints, 7919 * (self.seed + int(b)) + 13, self.mask_method, h=self.h) for b in idx]
         out = {k: np.concatenate([p[k] for p in parts]) for k in ("rgb", "norm", "depth", "R")}
         out["pts"], out["ptw"] = np.concatenate([k[0] for k in kps]), np.concatenate([k[1] for k in kps])
+        if self.sift:
+            from . import rputil
+            dets = [synth.make_sift_detections(1, self.sift, 15485863 * (self.seed + int(b)) + 7, self.mask_method, self.h)[0] for b in idx]
+            out["sift"] = [(rputil.map_detections(a, self.mask_method, self.h), rputil.map_detections(c, self.mask_method, self.h)) for a, c in dets]
+            out["kp_seeds"] = [[31 * (self.seed + int(b)) + lvl for lvl in range(8)] for b in idx]
         return out
 
 
@@ -136,7 +153,11 @@ def _batch_take(batch, idx):
     """The pairs `idx` of a global batch as a dict of arrays (a dict batch is sliced, a lazy one renders them)."""
     if hasattr(batch, "take"):
         return batch.take(idx)
-    return {k: v[idx] for k, v in batch.items() if isinstance(v, np.ndarray)}
+    out = {k: v[idx] for k, v in batch.items() if isinstance(v, np.ndarray)}
+    for k in ("sift", "kp_seeds"):                        # per-pair lists (keypoints="reference")
+        if k in batch:
+            out[k] = [batch[k][int(i)] for i in idx]
+    return out
 
 
 def _default_record(pipe, sub, poses, device, names, ks):
@@ -209,7 +230,7 @@ def evaluate_pairs_sharded(pipe, batches, device, result_path=None, names=None, 
             i, first = chunk[mine[q]]
             b = _batch_take(batches[i], local[mine[q]])
             subs[q] = b
-            return pipe.prepare(b["rgb"], b["norm"], b["depth"], b["pts"], b["ptw"], device)
+            return _prepare_batch(pipe, b, device)
 
         def on_result(q, pose, st):
             # records of this rank's pairs of batch q, built as soon as the batch is complete (the other in-flight batch keeps the GPU busy)
@@ -302,6 +323,9 @@ def main(argv=None):
     ap.add_argument("--rm", action="store_true", help="ignore an existing result file (the reference's --rm)")
     ap.add_argument("--round-batches", type=int, default=None, help="global batches per gather + save round (default: all)")
     ap.add_argument("--seed", type=int, default=4000)
+    ap.add_argument("--keypoint-mode", choices=["given", "reference"], default="given",
+                    help="reference: every level derives its keypoints from its own feature maps like rputil.getKeypoint (synthetic SIFT detections)")
+    ap.add_argument("--sift", type=int, default=120, help="--keypoint-mode reference: synthetic SIFT detections per view")
     args = ap.parse_args(argv)
 
     def worker():
@@ -319,8 +343,9 @@ def main(argv=None):
         mm, S, tanh = ("kinect", 21, 0) if ds == "scannet" else ("second", 21 if ds == "matterport" else 15, 1)
         net = SCNet(SimpleNamespace(batchnorm=1, useTanh=tanh, skipLayer=1, outputType="rgbdnsf", snumclass=S))
         net.load_state_dict(weights.make_state_dict(7, S))
-        pipe = RelativePosePipeline(net, ds, mm, params.final_params(ds))
-        batches = [SyntheticBatch(min(args.batch, args.pairs - k), args.seed + k, ds, mm, args.keypoints) for k in range(0, args.pairs, args.batch)]
+        pipe = RelativePosePipeline(net, ds, mm, params.final_params(ds), keypoints=args.keypoint_mode)
+        batches = [SyntheticBatch(min(args.batch, args.pairs - k), args.seed + k, ds, mm, args.keypoints,
+                                  sift=args.sift if args.keypoint_mode == "reference" else 0) for k in range(0, args.pairs, args.batch)]
         path = None if args.exp is None else args.exp + ".result.npy"
         D.barrier(world)
         t0 = time.perf_counter()

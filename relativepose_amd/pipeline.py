@@ -237,8 +237,13 @@ class RelativePosePipeline:
         stream as soon as batch k is complete.  Returns the per-batch results in order."""
         import torch
         cur = torch.cuda.current_stream()
-        nst = len(states)
-        depth = nst if depth is None else max(1, min(depth, nst))
+        if provider is not None:
+            states = []
+            nst = max(1, steps)
+            depth = max(1, min(2 if depth is None else depth, nst))
+        else:
+            nst = len(states)
+            depth = nst if depth is None else max(1, min(depth, nst))
         self._chain_nets = depth > 1
         self._ensure_net_stream(states)
         # One HIP stream per IN-FLIGHT SLOT, not per prepared batch: the runtime multiplexes streams onto 4 hardware queues, and with
@@ -287,6 +292,10 @@ class RelativePosePipeline:
                             done = e.value
                     if done is not None:
                         del live[slot]
+                        # the batch's buffers are free again once this point of its stream is reached (a copy stream that refills them for a
+                        # later batch waits for THIS event, not for whatever else is queued on the slot stream: bench.py's upload look-ahead)
+                        st["done_ev"] = torch.cuda.Event()
+                        st["done_ev"].record(st["stream"])
                         pose, status = done[0], done[1]
                         if on_result is not None:
                             cur.wait_stream(st["stream"])

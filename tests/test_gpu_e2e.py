@@ -131,8 +131,10 @@ def test_free_running_well_conditioned_other_conventions_within_1e4(ci, golden_d
 #   f16    (one fp16 MFMA per product, SURVEY 8d config 5's literal "fp16 MFMA convs": an accuracy trade the caller opts into)
 #          -> asserted against F16_ROT_BOUND / F16_TRANS_BOUND, measured on the MI355X (profiles/r05_parity_full_suite.jsonl) with 3x slack;
 #          it does NOT meet the 1e-4 parity bar on every fixture and bench.py's `dtype` string says so.
-F16_ROT_BOUND = 5e-3
-F16_TRANS_BOUND = 5e-3
+# measured (MI355X, round 5): f16x3 <= 7.9e-8 rotation / 1.1e-7 translation on all seven fixtures and levels; plain f16 <= 8.7e-6 / 2.4e-5 after
+# level 0 but up to 3.9e-3 / 7.8e-3 after level 2 (the feedback loop amplifies the 2^-11 product error): the bounds below are 3x that
+F16_ROT_BOUND = 1.2e-2
+F16_TRANS_BOUND = 2.5e-2
 _WC_ALL = [("wc", i) for i in range(len(WC_CASES))] + [("wc2", i) for i in range(len(WC2_CASES))]
 
 
@@ -171,6 +173,8 @@ def test_free_running_well_conditioned_16bit_conv_arithmetic(kind, ci, prec, gol
     for s in range(3):
         assert errs[s] < rb, (prec, s, errs)
         assert terr[s] < tb, (prec, s, terr)
+    if prec == "f16":
+        assert errs[0] < 1e-4 and terr[0] < 1e-4, (errs, terr)       # level 0 (no feedback yet) still meets the bar
 
 
 def test_wc_teacher_forcing_changes_nothing_but_feedback_matters(golden_dir):
