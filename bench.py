@@ -73,7 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement")
     ap.add_argument("--h2d-mode", choices=["auto", "slot", "lookahead"], default="auto",
-                    help="PCIe-inclusive run: uploads on the batch's slot stream, or on a copy stream one in-flight depth ahead (auto: lookahead when a step uploads > 400 MB)")
+                    help="PCIe-inclusive run: uploads on the batch's slot stream, or on a copy stream one in-flight depth ahead (auto: lookahead whenever >= 2 x inflight batches rotate)")
     ap.add_argument("--no-aux", action="store_true", help="skip the roofline / affinity side measurements (profiling runs)")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3", "f16"], default=None,
                     help="conv arithmetic (default: the config's; f32 = exact fp32 MFMA = the parity configuration)")
@@ -275,7 +275,8 @@ def worker(args):
     #              used `batches - depth` steps ago -- the copy waits for that batch's done event only), so a 734 MB upload (13 ms at 320x1280)
     #              runs under the other batches' convolutions instead of in front of its own batch (round 4: -21 % at configs[4])
     per_step_h2d = 0 if args.no_h2d else sum(t.numel() * t.element_size() for t in batches[0]["host"].values())
-    h2d_mode = args.h2d_mode if args.h2d_mode != "auto" else ("lookahead" if per_step_h2d > 400e6 and nbatch >= 2 * depth else "slot")
+    # (measured, round 5: configs[4] 764 -> 925 pairs/s PCIe-inclusive = -4 % instead of -22 %; configs[1] 660 -> 663: look-ahead whenever the rotation allows it)
+    h2d_mode = args.h2d_mode if args.h2d_mode != "auto" else ("lookahead" if nbatch >= 2 * depth else "slot")
     if h2d_mode == "lookahead" and nbatch < 2 * depth:
         h2d_mode = "slot"
     copy_stream = torch.cuda.Stream() if (h2d_mode == "lookahead" and not args.no_h2d) else None

@@ -470,6 +470,7 @@ __global__ __launch_bounds__(1024) void nms_sampling_kernel(const float* __restr
         if (threadIdx.x == 0) {
             float b = bv[0]; int id = bi[0];
             for (int w = 1; w < (int)(blockDim.x >> 6); ++w) if (bv[w] > b || (bv[w] == b && bi[w] < id)) { b = bv[w]; id = bi[w]; }
+            if (!(b > 0.f)) id = 0;                // every remaining heat underflowed to 0 = the value of the suppressed pixels: np.argmax returns pixel 0
             const int y = id / W, x = id - y * W;
             pts[((size_t)map * K + k) * 2 + 0] = x;
             pts[((size_t)map * K + k) * 2 + 1] = y;

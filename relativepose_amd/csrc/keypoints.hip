@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256) void kp_pick_kernel(const float* __restrict__ 
         if (lane == 0) red[wave] = b;
         __syncthreads();
         b = kp_max(kp_max(red[0], red[1]), kp_max(red[2], red[3]));
-        const int idx = b ? kp_key_idx(b) : 0;                  // (a map with no pixel left: np.argmax of a constant map = index 0)
+        // A best heat of exactly 0 (every remaining pixel underflowed: |q - f|^2 > ~207, possible with unbounded descriptors, useTanh = 0) equals
+        // the map minimum the suppressed pixels were set to (rputil.py:370): the reference's argmax then returns the FIRST pixel of the whole map,
+        // suppressed or not.  (Also: a map with no pixel left.)
+        const int idx = (b >> 32) ? kp_key_idx(b) : 0;
         const int py = idx / W, px = idx - py * W;
         if (threadIdx.x == 0) {
             picks[((size_t)q * topk + k) * 2 + 0] = px;

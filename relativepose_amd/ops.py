@@ -25,6 +25,7 @@ Operator                    replaces (reference file:line)
   pano2pc                   util.Pano2PointCloud, util.py:751-811
   pose_inverse              np.linalg.inv, evaluation.py:235
   sample_primitives         evaluation.py:246-253 + rputil.getPixel / interpolate
+  keypoints_reference       rputil.getKeypoint / getKeypoint_kinect behind the SIFT detector, rputil.py:141-353 (batched, per level)
   affinity_topk             rpmodule.py:342-379
   match_pairs               RelativePoseEstimation_helper, rpmodule.py:317-508
 """
@@ -53,6 +54,8 @@ _lib.define("pano2pc(Tensor depth, int dataset) -> (Tensor, Tensor)")
 _lib.define("pose_inverse(Tensor pose) -> Tensor")
 _lib.define("sample_primitives(Tensor f, int feat_off, Tensor obs_norm, Tensor obs_depth, Tensor pts, Tensor npts, "
             "int mask_method, int compose, int dataset) -> (Tensor, Tensor, Tensor)")
+_lib.define("keypoints_reference(Tensor f, int feat_off, Tensor q_src, Tensor q_pt, Tensor q_map, Tensor q_off, int nq_view_max, int topk, int window, "
+            "Tensor slot_kind, Tensor slot_xy, int mask_method) -> (Tensor, Tensor, Tensor)")
 _lib.define("affinity_topk(Tensor feat_s, Tensor weight_s, Tensor feat_t, Tensor weight_t, Tensor ns, Tensor nt, "
             "float[] params, int topK, bool want_wij) -> (Tensor, Tensor, Tensor, Tensor)")
 _lib.define("match_pairs(Tensor pc_s, Tensor normal_s, Tensor feat_s, Tensor weight_s, Tensor pc_t, Tensor normal_t, "
@@ -121,6 +124,13 @@ def _sample_primitives(f, feat_off, obs_norm, obs_depth, pts, npts, mask_method,
                                        npts.contiguous(), _INV_MASK[int(mask_method)], _INV_DATASET[int(dataset)], int(compose))
 
 
+def _keypoints_reference(f, feat_off, q_src, q_pt, q_map, q_off, nq_view_max, topk, window, slot_kind, slot_xy, mask_method):
+    from . import rputil as _ru
+    tab = {"q_src": q_src.contiguous(), "q_pt": q_pt.contiguous(), "q_map": q_map.contiguous(), "q_off": q_off.contiguous(), "nq": int(q_src.shape[0]),
+           "nq_view_max": int(nq_view_max), "topk": int(topk), "slot_kind": slot_kind.contiguous(), "slot_xy": slot_xy.contiguous(), "L": int(slot_kind.shape[1])}
+    return _ru.keypoints_reference_dev(f.contiguous(), int(feat_off), tab, _INV_MASK[int(mask_method)], window=int(window))
+
+
 def _affinity_topk(feat_s, weight_s, feat_t, weight_t, ns, nt, params, topK, want_wij):
     wij, cj, cw, keff = _rp.affinity_topk(feat_s.contiguous(), weight_s.contiguous(), feat_t.contiguous(), weight_t.contiguous(),
                                           ns.contiguous(), nt.contiguous(), _para(params, topK), want_wij=bool(want_wij))
@@ -138,8 +148,8 @@ def _match_pairs(pc_s, normal_s, feat_s, weight_s, pc_t, normal_t, feat_t, weigh
 
 for _name, _fn in (("scnet_forward", _scnet_forward), ("scnet_forward_out", _scnet_forward_out), ("apply_mask", _apply_mask), ("build_view", _build_view), ("warp", _warp),
                    ("warp_pairs_", _warp_pairs_), ("pano2pc", _pano2pc), ("pose_inverse", _pose_inverse),
-                   ("sample_primitives", _sample_primitives), ("affinity_topk", _affinity_topk), ("match_pairs", _match_pairs)):
+                   ("sample_primitives", _sample_primitives), ("keypoints_reference", _keypoints_reference), ("affinity_topk", _affinity_topk), ("match_pairs", _match_pairs)):
     _lib.impl(_name, _fn, "CUDA")
 
 OPS = ("scnet_forward", "scnet_forward_out", "apply_mask", "build_view", "warp", "warp_pairs_", "pano2pc", "pose_inverse", "sample_primitives",
-       "affinity_topk", "match_pairs")
+       "keypoints_reference", "affinity_topk", "match_pairs")

@@ -108,6 +108,12 @@ def test_batched_keypoints_equal_the_reference_goldens(golden_dir, kind, cis):
                                           np.random.RandomState(seed)))
     tab = rputil.upload_keypoint_tables(rputil.keypoint_tables(plans, H, W), dev)
     pts, w, npts = rputil.keypoints_reference_dev(f, off, tab, kind)
+    # the same call through the custom-op surface
+    import relativepose_amd.ops  # noqa: F401
+    from relativepose_amd.util import MASKS
+    o = torch.ops.relpose.keypoints_reference(f, off, tab["q_src"], tab["q_pt"], tab["q_map"], tab["q_off"], tab["nq_view_max"], tab["topk"], 15,
+                                              tab["slot_kind"], tab["slot_xy"], MASKS[kind])
+    assert torch.equal(o[0], pts) and torch.equal(o[1], w) and torch.equal(o[2], npts)
     pts, w, npts = pts.cpu().numpy(), w.cpu().numpy(), npts.cpu().numpy()
     for b, ci in enumerate(cis):
         for v, (pn, wn) in enumerate((("pts", "ptsW"), ("ptt", "pttW"))):
