@@ -1600,7 +1600,7 @@ struct HeadsDesc {
 constexpr int HEADS_W = 4352;
 
 template <int S, bool POSE = false>      // POSE (RELPOSE_FWD_POSE_OUTPUTS): the n, d and f heads only; rgb and semantic channels are written as zeros
-__global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
+__global__ __launch_bounds__(256, 3) void heads_kernel(const HeadsDesc hd) {
     __shared__ __attribute__((aligned(16))) float wl[HEADS_W];
     __shared__ float2 ssl[320];                        // scale/shift of this block's BatchNorm group
     constexpr int cf = 7 + S + 32;
@@ -1615,17 +1615,18 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     const size_t pix = pix0 + threadIdx.x;
     const float* pd = hd.d2 + pix * 224;
     const float* pa = hd.a1 + pix * 192;
-    float a3[12], as_[24], af[32];                     // rgb 0:3 | n 4:7 | d 8:11 (padded quads), s, f
+    // Register footprint (round 5): the three accumulator sets live one after the other -- rgb / n / d (12), then s (24), then f (32), each
+    // stored as soon as its last line is done -- instead of all 68 plus a 55-float output row at once.  238-244 VGPRs -> <= 128: a wave of this
+    // kernel on a SIMD used to leave room for ONE wave of the fp32 tile kernels (168 VGPRs, three per SIMD when alone) while the forward's tail
+    // overlaps the other batch's convolutions (pipeline.run_pipelined); now it leaves room for two.  Same lines in the same order, same
+    // operations per accumulator: bitwise the same output.
+    float a3[12];                                      // rgb 0:3 | n 4:7 | d 8:11 (padded quads)
 #pragma unroll
     for (int o = 0; o < 12; ++o) a3[o] = 0.f;
-#pragma unroll
-    for (int o = 0; o < 24; ++o) as_[o] = 0.f;
-#pragma unroll
-    for (int o = 0; o < 32; ++o) af[o] = 0.f;
     // One 128-byte line (32 channels) of a pixel at a time: all 8 loads are issued back to back so the line is
     // fetched once (a wave touches 64 lines per load instruction; interleaving compute between the loads of a
     // line let other waves evict it from the 32 KB L1 first).  The NEXT line's loads are issued before this line's arithmetic
-    // (two register sets, alternating): at 234 VGPRs only 2 waves share a SIMD and nothing else hides the trip to HBM.
+    // (two register sets, alternating).
     // Then BN + LeakyReLU and acc[4j+t'] += v * w[row][4j+t'] over the row's NQ4 weight quads.
 #define RP_HEAD_LOAD(X8, PTR)                                                                             \
     { _Pragma("unroll") for (int q = 0; q < 8; ++q) X8[q] = reinterpret_cast<const float4*>(PTR)[q]; }
@@ -1651,8 +1652,8 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     }
     // line order: A1 skip lines of [rgb,] n, d (level-invariant: the snapshot point), then the D2 lines of [rgb,] n, d, [s: 2 lines,] f: 2 lines
     float4 xa[8], xb[8];
-    constexpr int M0 = POSE ? 1 : 0;
     float4* snp = reinterpret_cast<float4*>(hd.snap) + pix * 3;
+    float* o = hd.out + pix * cf;                      // a lane's cf floats are contiguous in the NHWC output
     // (two register sets, strictly alternating: a line's NEXT load goes to the set the line does not read)
 #define RP_HEAD_SKIP(X8, NEXT, M_) RP_HEAD_LINE(X8, NEXT, 224 + (M_) * 32, (96 + (M_) * 32) * 4, 4, 1, a3, (M_) * 4)
 #define RP_HEAD_D2(X8, NEXT, M_) RP_HEAD_LINE(X8, NEXT, (M_) * 32, ((M_) * 32) * 4, 4, 1, a3, (M_) * 4)
@@ -1689,26 +1690,59 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     }
 #undef RP_HEAD_SKIP
 #undef RP_HEAD_D2
+    {   // channels 0:7 = rgb | n | d (+ bias): out of the registers before the next accumulator set starts
+        const float r0 = POSE ? 0.f : a3[0] + hd.bias[0], r1 = POSE ? 0.f : a3[1] + hd.bias[1], r2 = POSE ? 0.f : a3[2] + hd.bias[2];
+        *reinterpret_cast<float2*>(o + 0) = make_float2(r0, r1);
+        *reinterpret_cast<float2*>(o + 2) = make_float2(r2, a3[4] + hd.bias[3]);
+        *reinterpret_cast<float2*>(o + 4) = make_float2(a3[5] + hd.bias[4], a3[6] + hd.bias[5]);
+        o[6] = a3[8] + hd.bias[6];
+    }
+    // channels [C0, C0 + N) of the pixel's row from VAL(k): 8-byte stores from the first even offset on
+#define RP_HEAD_STORE(C0, N, VAL)                                                                          \
+    {                                                                                                    \
+        constexpr int c0_ = (C0), n_ = (N), lead_ = c0_ & 1;                                             \
+        if (lead_) o[c0_] = VAL(0);                                                                      \
+        _Pragma("unroll") for (int k = lead_; k + 1 < n_; k += 2) *reinterpret_cast<float2*>(o + c0_ + k) = make_float2(VAL(k), VAL(k + 1)); \
+        if ((n_ - lead_) & 1) o[c0_ + n_ - 1] = VAL(n_ - 1);                                             \
+    }
     if (!POSE) {
+        float as_[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) as_[k] = 0.f;
         RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 128), 96, 768, 24, 6, as_, 0)                                                // s
         RP_HEAD_LINE(xb, RP_HEAD_LOAD(xa, pd + 160), 128, 768 + 32 * 24, 24, 6, as_, 0)
+#define RP_HEAD_SVAL(k) (as_[(k)] + hd.bias[7 + (k)])
+        RP_HEAD_STORE(7, S, RP_HEAD_SVAL)
+#undef RP_HEAD_SVAL
+    } else {
+#define RP_HEAD_ZVAL(k) 0.f
+        RP_HEAD_STORE(7, S, RP_HEAD_ZVAL)
+#undef RP_HEAD_ZVAL
     }
-    RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 192), 160, 2304, 32, 8, af, 0)                                                   // f
-    RP_HEAD_LINE(xb, , 192, 2304 + 32 * 32, 32, 8, af, 0)
+    {
+        float af[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) af[k] = 0.f;
+        RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 192), 160, 2304, 32, 8, af, 0)                                               // f
+        RP_HEAD_LINE(xb, , 192, 2304 + 32 * 32, 32, 8, af, 0)
+        if (hd.use_tanh) {
+            // (four at a time: left to itself the scheduler interleaves all 32 tanhf expansions and their temporaries set the kernel's register count)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                af[k] = tanhf(af[k] + hd.bias[7 + S + k]);
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) af[k] = af[k] + hd.bias[7 + S + k];
+        }
+#define RP_HEAD_FVAL(k) af[(k)]
+        RP_HEAD_STORE(7 + S, 32, RP_HEAD_FVAL)
+#undef RP_HEAD_FVAL
+    }
+#undef RP_HEAD_STORE
 #undef RP_HEAD_LINE
 #undef RP_HEAD_LOAD
-    // bias, tanh, store (cf is even: 8-byte stores; a lane's cf floats are contiguous in the NHWC output)
-    float r[cf + 1];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) { r[o] = POSE ? 0.f : a3[o] + hd.bias[o]; r[3 + o] = a3[4 + o] + hd.bias[3 + o]; }
-    r[6] = a3[8] + hd.bias[6];
-#pragma unroll
-    for (int o = 0; o < S; ++o) r[7 + o] = POSE ? 0.f : as_[o] + hd.bias[7 + o];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) { const float v = af[k] + hd.bias[7 + S + k]; r[7 + S + k] = hd.use_tanh ? tanhf(v) : v; }
-    float* o = hd.out + pix * cf;
-#pragma unroll
-    for (int k = 0; k < cf / 2; ++k) *reinterpret_cast<float2*>(o + 2 * k) = make_float2(r[2 * k], r[2 * k + 1]);
 }
 
 // Split-K reduce + BatchNorm partial sums in one pass (round 2): grid (chunk, group, member); a workgroup adds the K slices of a
