@@ -30,6 +30,8 @@
 #include <stdlib.h>
 #include <stddef.h>
 
+extern int32_t g_rp_tune[RELPOSE_TUNE_COUNT];      // relpose_set_tuning (matcher.hip)
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -1599,8 +1601,14 @@ struct HeadsDesc {
 };
 constexpr int HEADS_W = 4352;
 
+// Round-5 experiment, NOT kept: the three accumulator sets one after the other + 3 waves per SIMD (238 -> 132 VGPRs, no spills, bitwise the same
+// output).  Alone the kernel gets a third wave per SIMD; in the pipeline the headline DROPPED 668 -> 655 pairs/s: at 238 VGPRs a wave of this kernel
+// does not fit beside two waves of the fp32 tile kernels (168 VGPRs each), so a workgroup only enters a CU where TWO conv workgroups have left -- it
+// fills the drain of the conv launches and otherwise stays out; at 132 VGPRs it takes every single slot a conv workgroup frees and keeps it (the next
+// heads workgroup fits where a conv workgroup does not).  The big footprint is what keeps the forward's HBM-bound tail out of the other batch's
+// MFMA-bound middle.
 template <int S, bool POSE = false>      // POSE (RELPOSE_FWD_POSE_OUTPUTS): the n, d and f heads only; rgb and semantic channels are written as zeros
-__global__ __launch_bounds__(256, 3) void heads_kernel(const HeadsDesc hd) {
+__global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     __shared__ __attribute__((aligned(16))) float wl[HEADS_W];
     __shared__ float2 ssl[320];                        // scale/shift of this block's BatchNorm group
     constexpr int cf = 7 + S + 32;
@@ -1615,18 +1623,17 @@ __global__ __launch_bounds__(256, 3) void heads_kernel(const HeadsDesc hd) {
     const size_t pix = pix0 + threadIdx.x;
     const float* pd = hd.d2 + pix * 224;
     const float* pa = hd.a1 + pix * 192;
-    // Register footprint (round 5): the three accumulator sets live one after the other -- rgb / n / d (12), then s (24), then f (32), each
-    // stored as soon as its last line is done -- instead of all 68 plus a 55-float output row at once.  238-244 VGPRs -> <= 128: a wave of this
-    // kernel on a SIMD used to leave room for ONE wave of the fp32 tile kernels (168 VGPRs, three per SIMD when alone) while the forward's tail
-    // overlaps the other batch's convolutions (pipeline.run_pipelined); now it leaves room for two.  Same lines in the same order, same
-    // operations per accumulator: bitwise the same output.
-    float a3[12];                                      // rgb 0:3 | n 4:7 | d 8:11 (padded quads)
+    float a3[12], as_[24], af[32];                     // rgb 0:3 | n 4:7 | d 8:11 (padded quads), s, f
 #pragma unroll
     for (int o = 0; o < 12; ++o) a3[o] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 24; ++o) as_[o] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) af[o] = 0.f;
     // One 128-byte line (32 channels) of a pixel at a time: all 8 loads are issued back to back so the line is
     // fetched once (a wave touches 64 lines per load instruction; interleaving compute between the loads of a
     // line let other waves evict it from the 32 KB L1 first).  The NEXT line's loads are issued before this line's arithmetic
-    // (two register sets, alternating).
+    // (two register sets, alternating): at 234 VGPRs only 2 waves share a SIMD and nothing else hides the trip to HBM.
     // Then BN + LeakyReLU and acc[4j+t'] += v * w[row][4j+t'] over the row's NQ4 weight quads.
 #define RP_HEAD_LOAD(X8, PTR)                                                                             \
     { _Pragma("unroll") for (int q = 0; q < 8; ++q) X8[q] = reinterpret_cast<const float4*>(PTR)[q]; }
@@ -1652,8 +1659,8 @@ __global__ __launch_bounds__(256, 3) void heads_kernel(const HeadsDesc hd) {
     }
     // line order: A1 skip lines of [rgb,] n, d (level-invariant: the snapshot point), then the D2 lines of [rgb,] n, d, [s: 2 lines,] f: 2 lines
     float4 xa[8], xb[8];
+    constexpr int M0 = POSE ? 1 : 0;
     float4* snp = reinterpret_cast<float4*>(hd.snap) + pix * 3;
-    float* o = hd.out + pix * cf;                      // a lane's cf floats are contiguous in the NHWC output
     // (two register sets, strictly alternating: a line's NEXT load goes to the set the line does not read)
 #define RP_HEAD_SKIP(X8, NEXT, M_) RP_HEAD_LINE(X8, NEXT, 224 + (M_) * 32, (96 + (M_) * 32) * 4, 4, 1, a3, (M_) * 4)
 #define RP_HEAD_D2(X8, NEXT, M_) RP_HEAD_LINE(X8, NEXT, (M_) * 32, ((M_) * 32) * 4, 4, 1, a3, (M_) * 4)
@@ -1690,59 +1697,26 @@ __global__ __launch_bounds__(256, 3) void heads_kernel(const HeadsDesc hd) {
     }
 #undef RP_HEAD_SKIP
 #undef RP_HEAD_D2
-    {   // channels 0:7 = rgb | n | d (+ bias): out of the registers before the next accumulator set starts
-        const float r0 = POSE ? 0.f : a3[0] + hd.bias[0], r1 = POSE ? 0.f : a3[1] + hd.bias[1], r2 = POSE ? 0.f : a3[2] + hd.bias[2];
-        *reinterpret_cast<float2*>(o + 0) = make_float2(r0, r1);
-        *reinterpret_cast<float2*>(o + 2) = make_float2(r2, a3[4] + hd.bias[3]);
-        *reinterpret_cast<float2*>(o + 4) = make_float2(a3[5] + hd.bias[4], a3[6] + hd.bias[5]);
-        o[6] = a3[8] + hd.bias[6];
-    }
-    // channels [C0, C0 + N) of the pixel's row from VAL(k): 8-byte stores from the first even offset on
-#define RP_HEAD_STORE(C0, N, VAL)                                                                          \
-    {                                                                                                    \
-        constexpr int c0_ = (C0), n_ = (N), lead_ = c0_ & 1;                                             \
-        if (lead_) o[c0_] = VAL(0);                                                                      \
-        _Pragma("unroll") for (int k = lead_; k + 1 < n_; k += 2) *reinterpret_cast<float2*>(o + c0_ + k) = make_float2(VAL(k), VAL(k + 1)); \
-        if ((n_ - lead_) & 1) o[c0_ + n_ - 1] = VAL(n_ - 1);                                             \
-    }
     if (!POSE) {
-        float as_[24];
-#pragma unroll
-        for (int k = 0; k < 24; ++k) as_[k] = 0.f;
         RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 128), 96, 768, 24, 6, as_, 0)                                                // s
         RP_HEAD_LINE(xb, RP_HEAD_LOAD(xa, pd + 160), 128, 768 + 32 * 24, 24, 6, as_, 0)
-#define RP_HEAD_SVAL(k) (as_[(k)] + hd.bias[7 + (k)])
-        RP_HEAD_STORE(7, S, RP_HEAD_SVAL)
-#undef RP_HEAD_SVAL
-    } else {
-#define RP_HEAD_ZVAL(k) 0.f
-        RP_HEAD_STORE(7, S, RP_HEAD_ZVAL)
-#undef RP_HEAD_ZVAL
     }
-    {
-        float af[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) af[k] = 0.f;
-        RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 192), 160, 2304, 32, 8, af, 0)                                               // f
-        RP_HEAD_LINE(xb, , 192, 2304 + 32 * 32, 32, 8, af, 0)
-        if (hd.use_tanh) {
-            // (four at a time: left to itself the scheduler interleaves all 32 tanhf expansions and their temporaries set the kernel's register count)
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                af[k] = tanhf(af[k] + hd.bias[7 + S + k]);
-                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 32; ++k) af[k] = af[k] + hd.bias[7 + S + k];
-        }
-#define RP_HEAD_FVAL(k) af[(k)]
-        RP_HEAD_STORE(7 + S, 32, RP_HEAD_FVAL)
-#undef RP_HEAD_FVAL
-    }
-#undef RP_HEAD_STORE
+    RP_HEAD_LINE(xa, RP_HEAD_LOAD(xb, pd + 192), 160, 2304, 32, 8, af, 0)                                                   // f
+    RP_HEAD_LINE(xb, , 192, 2304 + 32 * 32, 32, 8, af, 0)
 #undef RP_HEAD_LINE
 #undef RP_HEAD_LOAD
+    // bias, tanh, store (cf is even: 8-byte stores; a lane's cf floats are contiguous in the NHWC output)
+    float r[cf + 1];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { r[o] = POSE ? 0.f : a3[o] + hd.bias[o]; r[3 + o] = a3[4 + o] + hd.bias[3 + o]; }
+    r[6] = a3[8] + hd.bias[6];
+#pragma unroll
+    for (int o = 0; o < S; ++o) r[7 + o] = POSE ? 0.f : as_[o] + hd.bias[7 + o];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) { const float v = af[k] + hd.bias[7 + S + k]; r[7 + S + k] = hd.use_tanh ? tanhf(v) : v; }
+    float* o = hd.out + pix * cf;
+#pragma unroll
+    for (int k = 0; k < cf / 2; ++k) *reinterpret_cast<float2*>(o + 2 * k) = make_float2(r[2 * k], r[2 * k + 1]);
 }
 
 // Split-K reduce + BatchNorm partial sums in one pass (round 2): grid (chunk, group, member); a workgroup adds the K slices of a
@@ -3071,13 +3045,16 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
     float* act = (float*)(ws + o.act);
     float2* ssp = (float2*)(ws + o.ss);
     double* partial = (double*)(ws + o.partial);
+    // scheduling knobs (relpose_set_tuning): unused LDS requested by the head / tail launches when they overlap another forward's convolutions
+    const size_t head_pad = (two && head_side) ? (size_t)std::max(0, g_rp_tune[RELPOSE_TUNE_HEAD_LDS_PAD_KB]) * 1024 : 0;
+    const size_t tail_pad = two ? (size_t)std::max(0, g_rp_tune[RELPOSE_TUNE_TAIL_LDS_PAD_KB]) * 1024 : 0;
     auto mark = [&](int kind) {
         if (!net->profiling) return;
         hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, s);
         net->ev.push_back(e); net->ev_kind.push_back(kind);
     };
     mark(3);
-    hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, s, x, act + net->bufs["X0"].off * n, n, H, W, plan->self_cached ? 8 : 0);
+    hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), head_pad, s, x, act + net->bufs["X0"].off * n, n, H, W, plan->self_cached ? 8 : 0);
     mark(-3);
     int op_index = -1;
     for (const Op& op : plan->ops) {
@@ -3188,7 +3165,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
                 hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                    act + net->bufs["A1"].off * n, partial, n);
             else
-                hipLaunchKernelGGL(conv1_mfma_kernel, dim3(196 * n), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
+                hipLaunchKernelGGL(conv1_mfma_kernel, dim3(196 * n), dim3(256), head_pad, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                    act + net->bufs["A1"].off * n, partial, n, (plan->zero_warp ? 1 : 0) | (plan->self_cached ? 2 : 0));
             mark(-1);
         } else if (op.type == OP_STATS_FUSED) {
@@ -3212,10 +3189,10 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
             mark(1);
             const dim3 hg((unsigned)((size_t)n * RS * RS / 256));
             if (plan->pose_only) {
-                if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, true>), hg, dim3(256), 0, s, hd);
-                else hipLaunchKernelGGL((heads_kernel<21, true>), hg, dim3(256), 0, s, hd);
-            } else if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, false>), hg, dim3(256), 0, s, hd);
-            else hipLaunchKernelGGL((heads_kernel<21, false>), hg, dim3(256), 0, s, hd);
+                if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, true>), hg, dim3(256), tail_pad, s, hd);
+                else hipLaunchKernelGGL((heads_kernel<21, true>), hg, dim3(256), tail_pad, s, hd);
+            } else if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, false>), hg, dim3(256), tail_pad, s, hd);
+            else hipLaunchKernelGGL((heads_kernel<21, false>), hg, dim3(256), tail_pad, s, hd);
             mark(-1);
         } else if (op.type == OP_REDUCE) {
             mark(4);
@@ -3259,7 +3236,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
         }
     }
     mark(3);
-    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), net->cf <= RO_MAXC ? (size_t)4 * 2 * RO_MAXW * net->cf * sizeof(float) : 0, s,
+    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), (net->cf <= RO_MAXC ? (size_t)4 * 2 * RO_MAXW * net->cf * sizeof(float) : 0) + tail_pad, s,
                        act + net->bufs["OUT"].off * n, out, n, net->cf, H, W);
     mark(-3);
     RP_CHECK_LAUNCH();
