@@ -85,8 +85,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-tail-overlap", action="store_true", help="A/B: the whole SCNet forward on the SCNet stream (no head / tail on the slot streams)")
     ap.add_argument("--net-priority", type=int, default=None, help="A/B: HIP stream priority of the SCNet stream (default: -1 = high when the tail overlaps)")
     ap.add_argument("--fit-cluster", type=int, default=1, help="A/B: workgroups per scan pair in the fit inside the loop (default 1: no helper workgroups)")
-    ap.add_argument("--head-lds-pad", type=int, default=None, help="A/B: KB of unused LDS requested by the forward's head launches on the slot streams (RELPOSE_TUNE_HEAD_LDS_PAD_KB)")
-    ap.add_argument("--tail-lds-pad", type=int, default=None, help="A/B: KB of unused LDS requested by the forward's tail launches on the slot streams (RELPOSE_TUNE_TAIL_LDS_PAD_KB)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
     ap.add_argument("--batches", type=int, default=4, help="distinct prepared batches rotated through the in-flight slots")
@@ -253,11 +251,6 @@ def worker(args):
                                 outputs="pose" if args.pose_outputs else "all", self_stream_cache=not args.no_self_cache,
                                 tail_overlap=not args.no_tail_overlap, net_priority=args.net_priority, loop_fit_cluster=args.fit_cluster,
                                 keypoints=args.keypoint_mode)
-    from relativepose_amd import _lib as RL
-    if args.head_lds_pad is not None:
-        RL.lib().relpose_set_tuning(RL.TUNE_KEYS["head_lds_pad_kb"], args.head_lds_pad)
-    if args.tail_lds_pad is not None:
-        RL.lib().relpose_set_tuning(RL.TUNE_KEYS["tail_lds_pad_kb"], args.tail_lds_pad)
     ref_kp = args.keypoint_mode == "reference"
     if ref_kp:
         from relativepose_amd import rputil

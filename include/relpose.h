@@ -82,15 +82,9 @@ void relpose_default_params(RelposeParams* p_host);
  *   RELPOSE_TUNE_FIT_FIXED_CHECKS   0 = the eigen-solve places its convergence tests where the residual estimate is predicted to
  *                                   reach the tolerance (default), 1 = a test every 8 products (the earlier rule; A/B switch).  The
  *                                   one knob whose settings agree to round-off only (both converge to 1e-13; the number of Lanczos
- *                                   steps differs)
- *   RELPOSE_TUNE_HEAD_LDS_PAD_KB    extra (unused) LDS, in KB, requested by the launches of a forward's head (input resize, conv1) ...
- *   RELPOSE_TUNE_TAIL_LDS_PAD_KB    ... and tail (the five 1x1 heads, final resize) when they run on a second stream (relpose_scnet_forward2):
- *                                   a scheduling knob -- a workgroup that needs more LDS than one conv workgroup frees only enters a CU in the
- *                                   drain of a conv launch instead of taking single freed slots from the other batch's convolutions.  0 = none.
- *                                   Results are unaffected (bitwise). */
+ *                                   steps differs) */
 enum { RELPOSE_TUNE_AFFINITY_KERNEL = 0, RELPOSE_TUNE_FIT_MAX_PRODUCTS = 1, RELPOSE_TUNE_FIT_CLUSTER = 2,
-       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_HEAD_LDS_PAD_KB = 5, RELPOSE_TUNE_TAIL_LDS_PAD_KB = 6,
-       RELPOSE_TUNE_COUNT = 8 };
+       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_COUNT = 8 };
 int relpose_set_tuning(int32_t key, int32_t value);
 const char* relpose_version(void);
 

@@ -30,8 +30,6 @@
 #include <stdlib.h>
 #include <stddef.h>
 
-extern int32_t g_rp_tune[RELPOSE_TUNE_COUNT];      // relpose_set_tuning (matcher.hip)
-
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -1605,8 +1603,9 @@ constexpr int HEADS_W = 4352;
 // output).  Alone the kernel gets a third wave per SIMD; in the pipeline the headline DROPPED 668 -> 655 pairs/s: at 238 VGPRs a wave of this kernel
 // does not fit beside two waves of the fp32 tile kernels (168 VGPRs each), so a workgroup only enters a CU where TWO conv workgroups have left -- it
 // fills the drain of the conv launches and otherwise stays out; at 132 VGPRs it takes every single slot a conv workgroup frees and keeps it (the next
-// heads workgroup fits where a conv workgroup does not).  The big footprint is what keeps the forward's HBM-bound tail out of the other batch's
-// MFMA-bound middle.
+// heads workgroup fits where a conv workgroup does not) -- the working hypothesis; the converse experiment, head / tail launches padded with unused
+// LDS so that they need more than one freed conv slot (conv1 +6 / +12 KB, heads and resize_out +8 KB), changed nothing at configs[1] (675.0 / 674.2
+// base, 673.6, 676.2, 676.3, 673.1) and cost 2.7 % at configs[2]: not kept either (tools/gpu_r5_pads.sh).
 template <int S, bool POSE = false>      // POSE (RELPOSE_FWD_POSE_OUTPUTS): the n, d and f heads only; rgb and semantic channels are written as zeros
 __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     __shared__ __attribute__((aligned(16))) float wl[HEADS_W];
@@ -3045,16 +3044,13 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
     float* act = (float*)(ws + o.act);
     float2* ssp = (float2*)(ws + o.ss);
     double* partial = (double*)(ws + o.partial);
-    // scheduling knobs (relpose_set_tuning): unused LDS requested by the head / tail launches when they overlap another forward's convolutions
-    const size_t head_pad = (two && head_side) ? (size_t)std::max(0, g_rp_tune[RELPOSE_TUNE_HEAD_LDS_PAD_KB]) * 1024 : 0;
-    const size_t tail_pad = two ? (size_t)std::max(0, g_rp_tune[RELPOSE_TUNE_TAIL_LDS_PAD_KB]) * 1024 : 0;
     auto mark = [&](int kind) {
         if (!net->profiling) return;
         hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, s);
         net->ev.push_back(e); net->ev_kind.push_back(kind);
     };
     mark(3);
-    hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), head_pad, s, x, act + net->bufs["X0"].off * n, n, H, W, plan->self_cached ? 8 : 0);
+    hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, s, x, act + net->bufs["X0"].off * n, n, H, W, plan->self_cached ? 8 : 0);
     mark(-3);
     int op_index = -1;
     for (const Op& op : plan->ops) {
@@ -3165,7 +3161,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
                 hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                    act + net->bufs["A1"].off * n, partial, n);
             else
-                hipLaunchKernelGGL(conv1_mfma_kernel, dim3(196 * n), dim3(256), head_pad, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
+                hipLaunchKernelGGL(conv1_mfma_kernel, dim3(196 * n), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                    act + net->bufs["A1"].off * n, partial, n, (plan->zero_warp ? 1 : 0) | (plan->self_cached ? 2 : 0));
             mark(-1);
         } else if (op.type == OP_STATS_FUSED) {
@@ -3189,10 +3185,10 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
             mark(1);
             const dim3 hg((unsigned)((size_t)n * RS * RS / 256));
             if (plan->pose_only) {
-                if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, true>), hg, dim3(256), tail_pad, s, hd);
-                else hipLaunchKernelGGL((heads_kernel<21, true>), hg, dim3(256), tail_pad, s, hd);
-            } else if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, false>), hg, dim3(256), tail_pad, s, hd);
-            else hipLaunchKernelGGL((heads_kernel<21, false>), hg, dim3(256), tail_pad, s, hd);
+                if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, true>), hg, dim3(256), 0, s, hd);
+                else hipLaunchKernelGGL((heads_kernel<21, true>), hg, dim3(256), 0, s, hd);
+            } else if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, false>), hg, dim3(256), 0, s, hd);
+            else hipLaunchKernelGGL((heads_kernel<21, false>), hg, dim3(256), 0, s, hd);
             mark(-1);
         } else if (op.type == OP_REDUCE) {
             mark(4);
@@ -3236,7 +3232,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
         }
     }
     mark(3);
-    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), (net->cf <= RO_MAXC ? (size_t)4 * 2 * RO_MAXW * net->cf * sizeof(float) : 0) + tail_pad, s,
+    hipLaunchKernelGGL(resize_out_kernel, dim3(4096), dim3(256), net->cf <= RO_MAXC ? (size_t)4 * 2 * RO_MAXW * net->cf * sizeof(float) : 0, s,
                        act + net->bufs["OUT"].off * n, out, n, net->cf, H, W);
     mark(-3);
     RP_CHECK_LAUNCH();
