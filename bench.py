@@ -411,6 +411,29 @@ def worker(args):
             f_next = (net.plan_macs(2 * nloc, FW & ~SCNet.FLAG_ZERO_WARP, self_cached=True) if not args.no_self_cache
                       else net.plan_macs(2 * nloc, FW & ~SCNet.FLAG_ZERO_WARP)) / m_full
             exec_gflop = flops / 1e9 * (f_lvl0 + 2 * f_next)
+            # the same three forwards ALONE on the GPU (level-0 plan, then two self-cached ones; nothing on any other stream): what the SCNet part
+            # of a step costs without the other batch's matcher / geometry / head / tail beside it
+            xa = torch.randn(2 * nloc, 16, h, 4 * h, device=dev)
+            xa[:, 8:] = 0
+            xb = xa.clone()
+            xb[:, 8:] = torch.randn(2 * nloc, 8, h, 4 * h, device=dev)
+            fo = torch.empty(2 * nloc, net.out_channels, h, 4 * h, device=dev)
+            outs_kw = "pose" if args.pose_outputs else "all"
+
+            def alone_step():
+                tag = net.new_self_tag() if not args.no_self_cache else 0
+                net.forward(xa, out=fo, zero_warp=True, outputs=outs_kw, self_tag=tag)
+                net.forward(xb, out=fo, outputs=outs_kw, self_tag=tag)
+                net.forward(xb, out=fo, outputs=outs_kw, self_tag=tag)
+            for _ in range(2):
+                alone_step()
+            ea0, ea1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea0.record()
+            for _ in range(6):
+                alone_step()
+            ea1.record(); ea1.synchronize()
+            alone_ms = ea0.elapsed_time(ea1) / 6
+            del xa, xb, fo
             res["roofline"] = {"kernel": "SCNet conv stack: conv_igemm_kernel + conv_s2_tile_kernel + conv_s2_strip_kernel + deconv_tile_kernel + conv1_mfma_kernel + heads_kernel (fp32 MFMA 32x32x2)"
                                          if f32 else (stack16 + " -- fp16 MFMA 32x32x16" if prec == "f16" else stack16 + f" -- 3 x {prec[:-2]} MFMA 32x32x16 per fp32 product"),
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
@@ -420,6 +443,10 @@ def worker(args):
                                "algorithmic_gflop_per_forward": flops / 1e9,
                                "in_loop": {"executed_gflop_per_step": exec_gflop, "achieved": exec_gflop / ms, "frac": exec_gflop / ms / peak,
                                            "executed_fraction_of_full_forward": {"level0_zero_warp_plan": f_lvl0, "levels_1_2": f_next},
+                                           "forwards_alone": {"ms_per_step": alone_ms, "achieved": exec_gflop / alone_ms, "frac": exec_gflop / alone_ms / peak,
+                                                              "pairs_per_s_if_nothing_else_ran": nloc * 1e3 / alone_ms,
+                                                              "note": "the step's three forwards with no other stream active (HIP events): in_loop.frac / this = what overlapping "
+                                                                      "the other batch's matcher, geometry, head and tail costs the convolutions"},
                                            "note": "plan-aware: multiply-accumulates the three forwards of a step really launch (relpose_scnet_plan_macs) "
                                                    "x 2 / ms_per_step / peak; the reference's algorithmic work per step is 3 x algorithmic_gflop_per_forward"}}
             # --- N x N affinity build at the bench batch and at a batch where the bytes are meaningful
