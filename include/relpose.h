@@ -87,6 +87,13 @@ enum { RELPOSE_TUNE_AFFINITY_KERNEL = 0, RELPOSE_TUNE_FIT_MAX_PRODUCTS = 1, RELP
        RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_COUNT = 8 };
 int relpose_set_tuning(int32_t key, int32_t value);
 const char* relpose_version(void);
+/* A HIP stream whose kernels may only use the first `n_cus` compute units of the device's CU-mask order (hipExtStreamCreateWithCUMask; on gfx950 the
+ * mask bits interleave over the 8 XCDs, so n_cus = 64 is 8 CUs of every XCD); n_cus <= 0 or >= the device's CU count = an ordinary stream.  For the
+ * serving loop (pipeline.run_pipelined): the HBM- / latency-bound work of the batches in flight (head, tail, geometry, matcher) is confined to a slice of
+ * the chip instead of taking wave slots from the other batch's convolutions on every CU.  No reference counterpart (the reference runs one pair at a
+ * time on the default stream, evaluation.py:203-284).  relpose_stream_destroy releases it. */
+int relpose_stream_create_cu_limited(void** stream_out, int32_t n_cus);
+int relpose_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------ matcher
  * Keypoint sets of B scan pairs, padded to ns_max / nt_max rows.
@@ -286,7 +293,14 @@ int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_
  * bitwise those of the full forward.  Opt-in for callers that only want poses; never the default. */
 /* RELPOSE_FWD_NEW_WORKSPACE (relpose_scnet_forward4): the caller (re)allocated the workspace since its last forward -- possibly at the
  * same address --: whatever self-stream cache the library associates with the pointer is dropped before this forward. */
-enum { RELPOSE_FWD_ZERO_WARP = 1, RELPOSE_FWD_POSE_OUTPUTS = 2, RELPOSE_FWD_NEW_WORKSPACE = 4 };
+/* RELPOSE_FWD_PART_FRONT / RELPOSE_FWD_PART_BACK (relpose_scnet_forward_ex, round 5): ONE forward enqueued by TWO calls with otherwise identical
+ * arguments.  FRONT enqueues the head, the encoder (conv1..conv4) and the bottleneck chain (conv4's split-K reduction .. deconv6 with their
+ * reductions and BatchNorm finalizes: ~30 dispatches of a few hundred workgroups at most, mymodel.py:293-304) -- the chain on `mid_stream`
+ * when one is given; BACK waits for the chain and enqueues the decoder (deconv5..deconv2) on `stream` and the tail on `tail_stream`.
+ * Between the two calls the caller may enqueue the FRONT of another forward (another workspace) on `stream`: that forward's large
+ * encoder grids then run while this forward's chain trickles through `mid_stream` (pipeline.run_pipelined(split_forward=True)).  A BACK
+ * without a pending FRONT on the workspace (or with another n / plan) returns RELPOSE_EINVAL; the output is bitwise that of the one-call forward. */
+enum { RELPOSE_FWD_ZERO_WARP = 1, RELPOSE_FWD_POSE_OUTPUTS = 2, RELPOSE_FWD_NEW_WORKSPACE = 4, RELPOSE_FWD_PART_FRONT = 8, RELPOSE_FWD_PART_BACK = 16 };
 int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
                            void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags);
 /* relpose_scnet_forward3 with a self-stream cache.  Inside one scan pair's recurrence (evaluation.py:217-242) the masked own views --
@@ -309,6 +323,8 @@ int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_
  *   x, out, n_images, H, W, workspace, workspace_bytes   as relpose_scnet_forward
  *   stream, tail_stream   as relpose_scnet_forward2 (tail_stream NULL = stream)
  *   self_tag              as relpose_scnet_forward4 (0 = always recompute the self-view streams)
+ *   mid_stream            (round 5) the bottleneck chain of the forward (see RELPOSE_FWD_PART_FRONT) runs on this stream, ordered by events behind the
+ *                         encoder and in front of the decoder; NULL = `stream`.  Honoured by one-call forwards as well.
  *   workspace_generation  the caller's name for THIS ALLOCATION of `workspace` (e.g. a counter bumped whenever the buffer is re-allocated),
  *                         sent with every call: the self-stream cache is used only when the previous forward on the pointer carried the
  *                         same generation -- a workspace re-created at a recycled address is never mistaken for the old one, whichever call
@@ -327,6 +343,7 @@ typedef struct RelposeForwardArgs {
     void* tail_stream;
     uint64_t self_tag;
     uint64_t workspace_generation;
+    void* mid_stream;
 } RelposeForwardArgs;
 int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args);
 

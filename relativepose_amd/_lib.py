@@ -35,13 +35,15 @@ class ForwardArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", c_int), ("x", c_void_p), ("out", c_void_p),
                 ("n_images", c_int), ("H", c_int), ("W", c_int), ("reserved0", c_int),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("stream", c_void_p), ("tail_stream", c_void_p),
-                ("self_tag", C.c_uint64), ("workspace_generation", C.c_uint64)]
+                ("self_tag", C.c_uint64), ("workspace_generation", C.c_uint64), ("mid_stream", c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/relpose.h
 SIGNATURES = {
     "relpose_default_params": (None, [C.POINTER(Params)]),
     "relpose_version": (c_char_p, []),
+    "relpose_stream_create_cu_limited": (c_int, [C.POINTER(c_void_p), c_int]),
+    "relpose_stream_destroy": (c_int, [c_void_p]),
     "relpose_set_tuning": (c_int, [c_int, c_int]),
     "relpose_match_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int64]),
     "relpose_match_pairs": (c_int, [C.POINTER(Params), C.POINTER(Keypoints), c_void_p, c_size_t, c_int64,

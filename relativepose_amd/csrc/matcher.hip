@@ -1319,6 +1319,33 @@ void relpose_default_params(RelposeParams* p) {
 
 const char* relpose_version(void) { return "relpose-hip 0.1 (gfx950)"; }
 
+int relpose_stream_create_cu_limited(void** stream_out, int32_t n_cus) {
+    if (!stream_out) return RELPOSE_EINVAL;
+    int dev = 0, ncu = 0;
+    RP_HIP(hipGetDevice(&dev));
+    RP_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    hipStream_t s = nullptr;
+    if (n_cus <= 0 || n_cus >= ncu) {
+        RP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    } else {
+        uint32_t mask[32];
+        const int words = std::min(32, (ncu + 31) / 32);
+        for (int w = 0; w < words; ++w) {
+            const int lo = 32 * w;
+            mask[w] = n_cus >= lo + 32 ? 0xffffffffu : (n_cus > lo ? ((1u << (n_cus - lo)) - 1u) : 0u);
+        }
+        RP_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+    }
+    *stream_out = (void*)s;
+    return 0;
+}
+
+int relpose_stream_destroy(void* stream) {
+    if (!stream) return RELPOSE_EINVAL;
+    RP_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
 size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, int32_t topK, int64_t max_edges) {
     if (nt_max > RELPOSE_MAX_TARGETS) return 0;
     if (B <= 0 || ns_max <= 0 || topK < 1 || topK > RP_MAXK || (int64_t)ns_max * topK > RP_MAX_CORRES) return 0;

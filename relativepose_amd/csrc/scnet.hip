@@ -2077,6 +2077,9 @@ struct RelposeSCNet {
     std::map<std::pair<void*, int>, void*> plans;   // (workspace, n) -> Plan* (each with its own device descriptor table)
     struct SelfState { uint64_t tag = 0, gen = 0; int n = 0, H = 0, W = 0; bool pose_only = false; };
     std::map<void*, SelfState> self_state;          // workspace -> whose self-view streams it holds (relpose_scnet_forward4)
+    // workspace -> the forward whose RELPOSE_FWD_PART_FRONT half has been enqueued and whose _BACK half has not
+    struct PendingFront { void* plan = nullptr; SelfState st; const float* x = nullptr; float* out = nullptr; int flags = 0; };
+    std::map<void*, PendingFront> pending;
     std::map<std::string, Layer> layers;
     std::map<std::string, Buf> bufs;
     size_t per_image_floats = 0, ss_float2_per_group = 0;
@@ -2328,6 +2331,10 @@ struct Plan {
     int tail_first = -1;         // first op of the forward's tail (the heads; resize_out follows): relpose_scnet_forward2 moves it to a second stream
     int head_count = 0;          // ops of the forward's head (conv1 + its BatchNorm finalize; resize_in precedes): second stream as well
     hipEvent_t tail_ev = nullptr, head_ev = nullptr;
+    // the bottleneck chain (conv4's split-K reduction .. deconv6's BatchNorm finalize): ops [mid_first, mid_end) may run on a third stream, and a
+    // forward may be enqueued in two calls cut at mid_end (RELPOSE_FWD_PART_FRONT / _BACK)
+    int mid_first = -1, mid_end = -1;
+    hipEvent_t mid_ev0 = nullptr, mid_ev1 = nullptr;
 };
 
 struct Builder {
@@ -2709,7 +2716,10 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     R.force_ksplit = 6; R.shared_slices = R.zero_warp ? 0x2a : 0;      // slice ks = stream block ks of A3 (odd = warped view)
     R.skip_slices = R.self_cached ? 0x15 : 0;
     const size_t conv4_desc = R.plan->descs.size();
-    one("conv4", R.src("A3", 0, 768), nullptr, 56, "A4", 0); R.stats("A4");
+    one("conv4", R.src("A3", 0, 768), nullptr, 56, "A4", 0);
+    // the bottleneck chain starts with conv4's split-K reduction (when it has one) and ends in front of deconv5
+    R.plan->mid_first = (int)R.plan->ops.size() - ((!R.plan->ops.empty() && R.plan->ops.back().type == OP_REDUCE) ? 1 : 0);
+    R.stats("A4");
     R.force_ksplit = 0; R.shared_slices = 0; R.skip_slices = 0;
     // (the strip kernel took the shared slices: nothing reads the warped blocks of A3 beyond the first image pair, no copies needed)
     if (R.zero_warp && !R.rc && R.plan->descs[conv4_desc].shared_slices)
@@ -2725,6 +2735,7 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     sk = R.src("A8", 0, 512); one("deconv8", R.src("D9", 0, 512), &sk, 3, "D8", 0); R.stats("D8");
     sk = R.src("A7", 0, 512); one("deconv7", R.src("D8", 0, 512), &sk, 3, "D7", 0); R.stats("D7");
     sk = R.src("A6", 0, 512); one("deconv6", R.src("D7", 0, 512), &sk, 7, "D6", 0); R.stats("D6");
+    R.plan->mid_end = (int)R.plan->ops.size();
     sk = R.src("A5", 0, 512); one("deconv5", R.src("D6", 0, 512), &sk, 14, "D5", 0); R.stats("D5");
     sk = R.src("A4", 0, 256); one("deconv4", R.src("D5", 0, 256), &sk, 28, "D4", 0); R.stats("D4");
     // heads (mymodel.py:309-376): rgb/n/d with skips from the self stream, s/f without
@@ -2775,10 +2786,13 @@ void free_plan(RelposeSCNet* net) {
         if (p->d_descs) (void)hipFree(p->d_descs);
         if (p->tail_ev) (void)hipEventDestroy(p->tail_ev);
         if (p->head_ev) (void)hipEventDestroy(p->head_ev);
+        if (p->mid_ev0) (void)hipEventDestroy(p->mid_ev0);
+        if (p->mid_ev1) (void)hipEventDestroy(p->mid_ev1);
         delete p;
     }
     net->plans.clear();
     net->self_state.clear();       // (new weights / precision: nothing cached is valid)
+    net->pending.clear();          // (a half-enqueued forward loses its plan: its BACK call returns RELPOSE_EINVAL)
 }
 
 struct WsOffsets { size_t act, ss, partial, splitk, statp, persist, snap, total; };
@@ -2982,11 +2996,29 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
     const uint64_t self_tag = args->struct_size >= offsetof(RelposeForwardArgs, self_tag) + sizeof(uint64_t) ? args->self_tag : 0;
     const uint64_t ws_gen = args->struct_size >= offsetof(RelposeForwardArgs, workspace_generation) + sizeof(uint64_t) ? args->workspace_generation : 0;
     if (!net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0 || n >= (1 << 24)) return RELPOSE_EINVAL;
-    if (flags & ~(RELPOSE_FWD_ZERO_WARP | RELPOSE_FWD_POSE_OUTPUTS | RELPOSE_FWD_NEW_WORKSPACE)) return RELPOSE_EINVAL;
+    if (flags & ~(RELPOSE_FWD_ZERO_WARP | RELPOSE_FWD_POSE_OUTPUTS | RELPOSE_FWD_NEW_WORKSPACE | RELPOSE_FWD_PART_FRONT | RELPOSE_FWD_PART_BACK)) return RELPOSE_EINVAL;
+    const int part = flags & (RELPOSE_FWD_PART_FRONT | RELPOSE_FWD_PART_BACK);
+    if (part == (RELPOSE_FWD_PART_FRONT | RELPOSE_FWD_PART_BACK)) return RELPOSE_EINVAL;
+    void* mid_stream = (args->struct_size >= offsetof(RelposeForwardArgs, mid_stream) + sizeof(void*) && args->mid_stream) ? args->mid_stream : args->stream;
     const int G = n / 2;
     // (nothing to share with one BatchNorm group; the tile kernels' patch pairing wants the 2-image members' patch count even as well)
     const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2;
     const bool pose_only = (flags & RELPOSE_FWD_POSE_OUTPUTS) != 0;
+    Plan* plan = nullptr;
+    RelposeSCNet::SelfState commit;          // what the workspace holds once this forward is through
+    commit.tag = self_tag; commit.n = n; commit.H = H; commit.W = W; commit.pose_only = pose_only; commit.gen = ws_gen;
+    if (part == RELPOSE_FWD_PART_BACK) {
+        // the second half of a forward whose FRONT call chose the plan (and invalidated the self-stream record): same arguments, or nothing runs
+        auto it = net->pending.find(workspace);
+        if (it == net->pending.end()) return RELPOSE_EINVAL;
+        const RelposeSCNet::PendingFront pf = it->second;
+        net->pending.erase(it);
+        if (pf.x != x || pf.out != out || pf.flags != (flags & ~(RELPOSE_FWD_PART_BACK | RELPOSE_FWD_NEW_WORKSPACE)) || pf.st.n != n || pf.st.H != H || pf.st.W != W ||
+            pf.st.tag != self_tag || pf.st.gen != ws_gen)
+            return RELPOSE_EINVAL;
+        plan = (Plan*)pf.plan;
+    } else {
+    net->pending.erase(workspace);           // (a FRONT that is never followed by its BACK: dropped by whatever forward comes next)
     if (flags & RELPOSE_FWD_NEW_WORKSPACE) net->self_state.erase(workspace);      // the memory behind this pointer is not what the last forward left
     // Self-stream cache: the previous forward on this workspace carried the same non-zero tag (and shape, and -- when the caller names its
     // allocations -- the same workspace generation) -> the self-view encoder streams it left in the workspace are what this forward would
@@ -2997,7 +3029,6 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
     // (the accumulator snapshots are laid out per plan family: a pose-outputs forward has fewer decoder heads)
     bool self_cached = self_tag != 0 && prev.tag == self_tag && prev.n == n && prev.H == H && prev.W == W && prev.pose_only == pose_only && !zero_warp &&
                        prev.gen == ws_gen;
-    Plan* plan = nullptr;
     int snap_mode = 0;
     for (int attempt = 0; attempt < 2 && !plan; ++attempt) {
         // a tagged forward that computes the self streams also leaves the accumulator snapshots of the skip-connection halves
@@ -3007,7 +3038,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
         if (it != net->plans.end()) { plan = (Plan*)it->second; break; }
         const WsOffsets o = ws_offsets(net, n);
         if (workspace_bytes < o.total) return RELPOSE_ENOMEM;
-        if (net->plans.size() >= 16) {       // callers keep a few long-lived workspaces; bound the cache
+        if (net->plans.size() >= 32 && net->pending.empty()) {       // callers keep a few long-lived workspaces; bound the cache
             free_plan(net);
             self_cached = false;             // (free_plan drops every workspace's self-stream record with the plans)
             snap_mode = self_tag != 0 ? 1 : 0;
@@ -3033,6 +3064,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
         net->plans[std::make_pair(workspace, key2)] = p;
         plan = p;
     }
+    }   // (part != BACK)
     if (!plan) return RELPOSE_EINVAL;
     net->last_n = n;
     // two-stream mode: the HBM-bound head (resize_in, conv1) and tail (heads, resize_out) run on tail_stream, the MFMA-bound middle on `stream`
@@ -3049,12 +3081,45 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
         hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, s);
         net->ev.push_back(e); net->ev_kind.push_back(kind);
     };
-    mark(3);
-    hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, s, x, act + net->bufs["X0"].off * n, n, H, W, plan->self_cached ? 8 : 0);
-    mark(-3);
+    const bool mid_split = plan->mid_first >= 0 && plan->mid_end > plan->mid_first && plan->mid_first >= plan->head_count && plan->mid_end <= plan->tail_first;
+    if (part && !mid_split) return RELPOSE_EINVAL;
+    if (part != RELPOSE_FWD_PART_BACK) {
+        mark(3);
+        hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, s, x, act + net->bufs["X0"].off * n, n, H, W, plan->self_cached ? 8 : 0);
+        mark(-3);
+    } else {
+        // the decoder continues on `stream` behind the chain (wherever FRONT enqueued it)
+        s = (hipStream_t)stream;
+        RP_HIP(hipStreamWaitEvent(s, plan->mid_ev1, 0));
+    }
     int op_index = -1;
     for (const Op& op : plan->ops) {
         ++op_index;
+        if (part == RELPOSE_FWD_PART_BACK && op_index < plan->mid_end) continue;
+        if (mid_split && op_index == plan->mid_first && part != RELPOSE_FWD_PART_BACK && (hipStream_t)mid_stream != s) {
+            if (!plan->mid_ev0) RP_HIP(hipEventCreateWithFlags(&plan->mid_ev0, hipEventDisableTiming));
+            RP_HIP(hipEventRecord(plan->mid_ev0, s));
+            s = (hipStream_t)mid_stream;
+            RP_HIP(hipStreamWaitEvent(s, plan->mid_ev0, 0));
+        }
+        if (mid_split && op_index == plan->mid_end && part != RELPOSE_FWD_PART_BACK) {
+            if (part == RELPOSE_FWD_PART_FRONT) {
+                // the first half ends here: BACK (the next call on this workspace) orders the decoder behind this event
+                if (!plan->mid_ev1) RP_HIP(hipEventCreateWithFlags(&plan->mid_ev1, hipEventDisableTiming));
+                RP_HIP(hipEventRecord(plan->mid_ev1, s));
+                RP_CHECK_LAUNCH();
+                RelposeSCNet::PendingFront pf;
+                pf.plan = plan; pf.st = commit; pf.x = x; pf.out = out; pf.flags = flags & ~(RELPOSE_FWD_PART_FRONT | RELPOSE_FWD_NEW_WORKSPACE);
+                net->pending[workspace] = pf;
+                return 0;
+            }
+            if (s != (hipStream_t)stream) {
+                if (!plan->mid_ev1) RP_HIP(hipEventCreateWithFlags(&plan->mid_ev1, hipEventDisableTiming));
+                RP_HIP(hipEventRecord(plan->mid_ev1, s));
+                s = (hipStream_t)stream;
+                RP_HIP(hipStreamWaitEvent(s, plan->mid_ev1, 0));
+            }
+        }
         if (op.type == OP_NOP) continue;
         if (op_index == plan->head_count && s != (hipStream_t)stream) {      // head done: the convolutions continue on `stream`
             if (!plan->head_ev) RP_HIP(hipEventCreateWithFlags(&plan->head_ev, hipEventDisableTiming));
@@ -3237,8 +3302,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
     mark(-3);
     RP_CHECK_LAUNCH();
     {   // everything is enqueued: the workspace now holds (stream-ordered) the self-view streams of `self_tag`
-        RelposeSCNet::SelfState& st = net->self_state[workspace];
-        st.tag = self_tag; st.n = n; st.H = H; st.W = W; st.pose_only = pose_only; st.gen = ws_gen;
+        net->self_state[workspace] = commit;
     }
     return 0;
 }

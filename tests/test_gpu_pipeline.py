@@ -257,3 +257,31 @@ def test_pipeline_self_stream_cache_gives_the_same_poses():
     torch.cuda.synchronize()
     for k, (pose, status) in enumerate(res):
         assert torch.equal(pose, want[k][0]) and torch.equal(status, want[k][1]), k
+
+
+@pytest.mark.parametrize("slot_cus", [0, 64])
+def test_pipeline_split_forward_three_in_flight_equal_sequential_runs(slot_cus):
+    """The round-5 serving loop: three batches in flight, every SCNet forward enqueued in two halves with the bottleneck chain on a third
+    stream (A.enc B.enc C.enc A.dec B.dec C.dec on the SCNet stream), optionally with CU-masked slot streams -- the poses are bitwise
+    those of `run` batch by batch (same kernels, same data; only the enqueue order and the streams differ)."""
+    import torch
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, mm, S, tanh = "suncg", "second", 15, 1
+    net = _gpu_net(S, tanh, E2E_WEIGHT_SEED)
+    plain = RelativePosePipeline(net, ds, mm)
+    split = RelativePosePipeline(net, ds, mm, split_forward=True, slot_cus=slot_cus)
+    states, want = [], []
+    for j in range(4):
+        d = synth.make_pairs(2, 1900 + 10 * j, ds)
+        pts, ptw = synth.make_keypoints(2, 60, 1900 + 10 * j, mm)
+        st = plain.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
+        pose, status, _ = plain.run(st)
+        states.append(st); want.append((pose.clone(), status.clone()))
+    torch.cuda.synchronize()
+    for depth in (3, 2):
+        res = split.run_pipelined(states, 9, None, depth=depth)
+        torch.cuda.synchronize()
+        for k, (pose, status) in enumerate(res):
+            assert torch.equal(pose, want[k % 4][0]) and torch.equal(status, want[k % 4][1]), (depth, k)
+    log("pipeline_split_forward", slot_cus=slot_cus, bitwise=True)
