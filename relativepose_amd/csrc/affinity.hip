@@ -15,6 +15,9 @@
 #include "matcher_internal.h"
 #include <limits.h>
 #include <string.h>
+#include <algorithm>
+#include <map>
+#include <mutex>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -928,6 +931,458 @@ __global__ __launch_bounds__(AT_WAVES * 64, 4) void affinity_tile_kernel(Relpose
     }
 }
 
+// ---- pool variant (round 5): the tile kernel's stages as SEPARATE dense launches ----------------------------------------------------------
+// The tile kernel runs five dependent stages per workgroup (staging | P1 | selection + pooled exact distances | ranking | exp + row
+// stores) at 77 KB of LDS and 118 VGPRs: 2 workgroups per CU, every stage a latency chain (profiles/r04_affinity_pmc.txt).  Here each stage
+// is a launch of its own, shaped for what it does:
+//   aff3_screen_kernel  the SAME approximate screen (fp16 MFMA, the same error bound and thresholds as affinity_tile_kernel) with the targets
+//                       staged as fp16 only (20 KB of LDS); the candidates of every half row go into a global pool as ONE contiguous
+//                       segment per lane (wave-level reservation with one atomic), the scaled float32 descriptors are written out once,
+//                       and -- for a materialised wij -- the wave zero-fills its rows with streaming stores while the matrix pipe works;
+//   aff3_exact_kernel   one lane per pooled candidate: numpy-order float32 distance, Markstein exponent (dense, no queues or ballots);
+//   aff3_rank_kernel    one lane per source ROW (64 different rows per wave): rank, exp of the K winners, float64 norm over the norm
+//                       window, outputs, and the window values of the row scattered over the zeros;
+// rows the bound does not cover / that do not fit the pool are marked RP_AFF_REDO and redone by affinity_rows_kernel<FIXUP> as before.
+// Results: corres_j identical, corres_w / wij to round-off of the tile kernel's (the norm window is taken from the exact row maximum).
+struct A3Scratch {
+    unsigned* ctl;             // (unused)
+    uint2* hdr;                // [waves] {pool base, candidates} of every screen wave
+    unsigned short* seg;       // [waves][64] exclusive prefix of the lanes' candidate counts
+    float* fs_sc;              // [B * ns_max * 32] feat_s / 100 (float32 division like numpy)
+    float* ft_sc;              // [B * nt_max * 32]
+    unsigned* item_row;        // [waves][cap] global source row of candidate g
+    unsigned* item_tgt;        // [waves][cap] (global target row << 1) | denominator class
+    double* item_e;            // [waves][cap] exact exponent
+    unsigned cap;              // pool slots per screen wave (a multiple of 64)
+    unsigned nwaves;
+};
+#define A3_LDB 80              // LDS row stride of the fp16 target descriptors (bytes): conflict-free b128 reads
+
+// exclusive prefix over the lanes of a per-lane count < 512 + the wave total (ballots of the bit planes)
+__device__ __forceinline__ int a3_lane_prefix(int c, int& total) {
+    int ex = 0; total = 0;
+#pragma unroll
+    for (int bpl = 0; bpl < 9; ++bpl) {
+        const unsigned long long bm = __ballot((c >> bpl) & 1);
+        if (bm) {
+            ex += (__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0))) << bpl;
+            total += __popcll(bm) << bpl;
+        }
+    }
+    return ex;
+}
+
+template <bool WRITE_WIJ, int KL, int TPM>      // TPM: tile pairs of 64 targets (ntp <= 128 * TPM... ntp = 64 * tile pairs <= 64 * TPM)
+__global__ __launch_bounds__(AT_WAVES * 64, 4) void aff3_screen_kernel(RelposeKeypoints kp, AffConsts ac, int topK, int ntp, int rows_per_block, int rpw,
+                                                                         float* __restrict__ wij, int32_t* __restrict__ corres_j,
+                                                                         int32_t* __restrict__ keff_out, A3Scratch sc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NT = blockDim.x;
+    const int b = blockIdx.y;
+    const int ns = kp.ns[b], nt = kp.nt[b];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, n = lane & 31;
+    const int wv = (blockIdx.y * gridDim.x + blockIdx.x) * (NT >> 6) + wave;       // this wave's header
+    const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) keff_out[b] = keff;
+    if (keff == 0 || blockIdx.x * rows_per_block >= ns) {
+        if (lane == 0) sc.hdr[wv] = make_uint2(0u, 0u);
+        return;
+    }
+    char* th = smem;                                             // [ntp][A3_LDB] fp16 target descriptors, class-sorted
+    unsigned* tpack = (unsigned*)(th + (size_t)ntp * A3_LDB);    // [ntp] fp16 {hi, lo * 1024} of -|t|^2 / 2
+    unsigned short* perm = (unsigned short*)(tpack + ntp);       // [ntp] sorted position -> target index
+    unsigned short* posof = perm + ntp;                          // [ntp] target index -> sorted position
+    int* misc = (int*)(posof + ntp);                             // [0] max |t|^2, [1] pair not covered by the bound, [2] class-1 targets
+    const int i0w = blockIdx.x * rows_per_block + wave * rpw;
+    const int nrows = max(0, min(min(rpw, rows_per_block - wave * rpw), ns - i0w));
+    const int i = i0w + n;
+    const bool rowok = n < nrows;
+    const size_t si = (size_t)b * kp.ns_max + (rowok ? i : 0);
+    float4 fsraw[RP_FEAT / 4];
+#pragma unroll
+    for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) fsraw[c4] = rowok ? rp_ldg4(kp.feat_s + si * RP_FEAT + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const double wsi = rowok ? rp_ldg(kp.weight_s + si) : 0.0;
+    if (WRITE_WIJ && nrows > 0) {
+        // the wave's rows of wij: zeros now (streaming stores that drain under the sweeps), the window values over them later (aff3_rank_kernel)
+        float* wbase = wij + ((size_t)b * kp.ns_max + i0w) * kp.nt_max;
+        const int nfl = nrows * kp.nt_max;
+        if ((kp.nt_max & 3) == 0) for (int q4 = lane; q4 < (nfl >> 2); q4 += 64) rp_stg4(wbase + 4 * q4, make_float4(0.f, 0.f, 0.f, 0.f));
+        else for (int q1 = lane; q1 < nfl; q1 += 64) rp_stg(wbase + q1, 0.f);
+    }
+    {   // ---- stage the pair's targets, sorted by weight class, as fp16 (rounded toward zero like the tile kernel's operands)
+        if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+        if (wave == 0) {
+            double wt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int j = lane + 64 * k; wt[k] = (j < nt) ? rp_ldg(kp.weight_t + (size_t)b * kp.nt_max + j) : 0.0; }
+            int n1 = 0;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = lane + 64 * k;
+                n1 += __popcll(__ballot(j < nt && wt[k] == 1.0));
+                if (j < nt && !(wt[k] >= 0.0 && wt[k] <= 1.0)) bad = true;
+            }
+            int r1 = 0, r0 = n1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = lane + 64 * k;
+                const bool v = j < nt, c1 = v && wt[k] == 1.0, c0 = v && !c1;
+                const unsigned long long b1 = __ballot(c1), b0 = __ballot(c0);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int p = c1 ? r1 + __popcll(b1 & below) : r0 + __popcll(b0 & below);
+                if (v) { posof[j] = (unsigned short)p; perm[p] = (unsigned short)j; }
+                r1 += __popcll(b1); r0 += __popcll(b0);
+            }
+            for (int j = nt + lane; j < ntp; j += 64) perm[j] = (unsigned short)j;
+            if (lane == 0) misc[2] = n1;
+            if (bad) misc[1] = 1;
+        }
+        __syncthreads();
+        const float* ftg = kp.feat_t + (size_t)b * kp.nt_max * RP_FEAT;
+        float* fto = sc.ft_sc + (size_t)b * kp.nt_max * RP_FEAT;
+        float mx = 0.f;
+        bool bad = false;
+        for (int idx0 = 0; idx0 < ntp * (RP_FEAT / 4); idx0 += NT) {       // (uniform trip count: the lanes of a target reduce through DPP)
+            const int idx = idx0 + tid;
+            const int j = idx >> 3, c4 = idx & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int row = min(j, ntp - 1);
+            const bool ok = j < nt;
+            if (ok) { v = rp_ldg4(ftg + (size_t)j * RP_FEAT + 4 * c4); row = posof[j]; }
+            v = rp_div100(v);
+            if (ok && blockIdx.x == 0) rp_stg4(fto + (size_t)j * RP_FEAT + 4 * c4, v);      // the scaled descriptors, once per pair
+            if (j < ntp) *reinterpret_cast<uint2*>(th + (size_t)row * A3_LDB + 8 * c4) = make_uint2(rp_pkrtz(v.x, v.y), rp_pkrtz(v.z, v.w));
+            // |t|^2 over the 8 lanes that hold the target's 32 features (a fixed tree; the bound below covers the summation order)
+            float a = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            if (c4 == 0 && j < ntp) {
+                if (ok && !(a < 1e8f)) bad = true;
+                const float g0 = ok ? -0.5f * a : AT2_PADG;
+                const _Float16 hi = (_Float16)g0;
+                const _Float16 lo = ok ? (_Float16)((g0 - (float)hi) * 1024.0f) : (_Float16)0.0f;
+                tpack[row] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                if (ok) mx = fmaxf(mx, a);
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0) atomicMax(&misc[0], __float_as_int(mx));
+        if (bad) misc[1] = 1;
+        __syncthreads();
+    }
+    const float ntmax = __int_as_float(misc[0]);
+    const bool pair_bad = misc[1] != 0;
+    const int n1 = misc[2];
+    if (nrows <= 0) {
+        if (lane == 0) sc.hdr[wv] = make_uint2(0u, 0u);
+        return;
+    }
+    float nsq = 0.f;
+    f16x8 bf0, bf1, bfx;
+    {
+        float fs[RP_FEAT];
+#pragma unroll
+        for (int c4 = 0; c4 < RP_FEAT / 4; ++c4) {
+            const float4 v = rp_div100(fsraw[c4]);
+            fs[4 * c4] = v.x; fs[4 * c4 + 1] = v.y; fs[4 * c4 + 2] = v.z; fs[4 * c4 + 3] = v.w;
+            if (rowok && h == 0) rp_stg4(sc.fs_sc + si * RP_FEAT + 4 * c4, v);
+        }
+#pragma unroll
+        for (int c = 0; c < RP_FEAT; ++c) nsq += fs[c] * fs[c];
+        unsigned P[16], p[8];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) P[q] = rp_pkrtz(fs[2 * q], fs[2 * q + 1]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { p[q] = h ? P[4 + q] : P[q]; p[4 + q] = h ? P[12 + q] : P[8 + q]; }
+        const u32x4 lo = {p[0], p[1], p[2], p[3]}, hi = {p[4], p[5], p[6], p[7]};
+        bf0 = __builtin_bit_cast(f16x8, lo);
+        bf1 = __builtin_bit_cast(f16x8, hi);
+        const u32x4 one = {h ? 0u : rp_pkrtz(1.0f, 0.0009765625f), 0u, 0u, 0u};
+        bfx = __builtin_bit_cast(f16x8, one);
+    }
+    const bool rowone = wsi == 1.0;
+    const bool row_bad = pair_bad || !(wsi >= 0.0 && wsi <= 1.0) || !(nsq < 1e8f);
+    const float nrd0 = -(float)ac.rden[0], nrd1 = -(float)ac.rden[1];
+    const float B1 = rowone ? nrd1 : nrd0, B0 = nrd0;
+    const float al1 = -2.0f * B1, be1 = B1 * nsq, al0 = -2.0f * B0, be0 = B0 * nsq;
+    const int ntiles = ntp / 32;
+    const int tmix = (n1 & 31) ? (n1 >> 5) : -1;
+
+    auto tile_g = [&](int T) {
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const char* row = th + (size_t)(32 * T + n) * A3_LDB + 16 * h;
+        const u32x4 k0 = *reinterpret_cast<const u32x4*>(row), k1 = *reinterpret_cast<const u32x4*>(row + 32);
+        const u32x4 k2 = {h ? 0u : tpack[32 * T + n], 0u, 0u, 0u};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, k0), bf0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, k1), bf1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, k2), bfx, acc, 0, 0, 0);
+        return acc;
+    };
+    auto pos_of = [&](int T, int r) { return 32 * T + 8 * (r >> 2) + 4 * h + (r & 3); };
+
+    // ---- P1 (as affinity_tile_kernel): row maximum and the KL largest group-of-8 maxima, as exponents
+    float te[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) te[k] = -INFINITY;
+    for (int T = 0; T < ntiles; ++T) {
+        const floatx16 g = tile_g(T);
+        float gm[2];
+        if (T != tmix) {
+            const bool c1 = 32 * T < n1;
+            const float al = c1 ? al1 : al0, be = c1 ? be1 : be0;
+#pragma unroll
+            for (int g8 = 0; g8 < 2; ++g8) {
+                const float q0 = rp_max_nc(rp_max_nc(g[8 * g8], g[8 * g8 + 1]), rp_max_nc(g[8 * g8 + 2], g[8 * g8 + 3]));
+                const float q1 = rp_max_nc(rp_max_nc(g[8 * g8 + 4], g[8 * g8 + 5]), rp_max_nc(g[8 * g8 + 6], g[8 * g8 + 7]));
+                gm[g8] = __builtin_fmaf(al, rp_max_nc(q0, q1), be);
+            }
+        } else {
+#pragma unroll
+            for (int g8 = 0; g8 < 2; ++g8) {
+                float m8 = -INFINITY;
+#pragma unroll
+                for (int r = 8 * g8; r < 8 * g8 + 8; ++r) {
+                    const bool c1 = pos_of(T, r) < n1;
+                    m8 = fmaxf(m8, __builtin_fmaf(c1 ? al1 : al0, g[r], c1 ? be1 : be0));
+                }
+                gm[g8] = m8;
+            }
+        }
+        rp_list_push<KL>(te, gm[0]);
+        rp_list_push<KL>(te, gm[1]);
+    }
+    {
+        float ot[KL];
+#pragma unroll
+        for (int k = 0; k < KL; ++k) ot[k] = __shfl_xor(te[k], 32, 64);
+#pragma unroll
+        for (int kk = 0; kk < KL; ++kk) rp_list_push<KL>(te, ot[kk]);
+    }
+    float kth = te[0];
+#pragma unroll
+    for (int k = 1; k < KL; ++k) if (k == keff - 1) kth = te[k];
+    const float emax_a = te[0];
+    const float rdmax = fmaxf(-nrd0, -nrd1);
+    const float errd = 2.2e-3f * (nsq + ntmax) + 3.5e-7f * (sqrtf(nsq) + sqrtf(ntmax));
+    const float err = errd * rdmax + 4e-6f * (fmaxf(fabsf(kth), fabsf(emax_a)) + rdmax * nsq) + 1e-30f;
+    // one threshold: possible winners, the norm window and (materialised wij) the value window are nested sets
+    const float thr_imp = fminf(kth, emax_a - (float)RP_AFF_NORM_WINDOW) - 2.0f * err;
+    const float thr = WRITE_WIJ ? fminf(thr_imp, emax_a - (float)RP_AFF_WINDOW - 2.0f * err) : thr_imp;
+    const bool sel_row = rowok && !row_bad;
+    const float tg1 = sel_row ? (thr - be1) / al1 - 1e-6f * fabsf((thr - be1) / al1) : INFINITY;
+    const float tg0 = sel_row ? (thr - be0) / al0 - 1e-6f * fabsf((thr - be0) / al0) : INFINITY;
+
+    // ---- P2: the candidate masks of the half row, one word per pair of tiles: bit 31 - (16 u + r) <-> sorted position pos_of(T + u, r)
+    unsigned m[TPM];
+    int cnt = 0;
+#pragma unroll
+    for (int tp = 0; tp < TPM; ++tp) {
+        m[tp] = 0;
+        if (2 * tp < ntiles) {
+            const int T = 2 * tp;
+            unsigned mm = 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const floatx16 g = tile_g(T + u);
+                if (T + u != tmix) {
+                    const bool c1 = 32 * (T + u) < n1;
+                    const float tg = c1 ? tg1 : tg0;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const rp_v2f d = (rp_v2f){g[r], g[r + 1]} - (rp_v2f){tg, tg};
+                        mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.x), 31);
+                        mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(d.y), 31);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool c1 = pos_of(T + u, r) < n1;
+                        mm = (mm << 1) | (g[r] >= (c1 ? tg1 : tg0) ? 0u : 1u);
+                    }
+                }
+            }
+            mm = ~mm;
+            if (32 * (T + 2) > nt) {       // padding positions
+                unsigned vm = 0;
+#pragma unroll
+                for (int idx = 0; idx < 32; ++idx) vm = (vm << 1) | (pos_of(T + (idx >> 4), idx & 15) < nt ? 1u : 0u);
+                mm &= vm;
+            }
+            if (!sel_row) mm = 0;
+            m[tp] = mm;
+            cnt += __popc(mm);
+        }
+    }
+    // ---- one contiguous pool segment per lane: wave total, one reservation, every lane writes its own candidates
+    int total;
+    const int ex = a3_lane_prefix(cnt, total);
+    // (a fixed slice of the pool per screen wave: one global fill counter bumped by 8192 waves from 8 XCDs cost ~100 us of line migrations)
+    const unsigned base = (unsigned)wv * sc.cap;
+    const bool over = (unsigned)total > sc.cap;                                 // the slice is full: the wave's rows go to the exact redo
+    if (lane == 0) sc.hdr[wv] = make_uint2(base, over ? 0u : (unsigned)total);
+    sc.seg[(size_t)wv * 64 + lane] = (unsigned short)ex;
+    if (rowok && h == 0) corres_j[si * topK] = (row_bad || over) ? RP_AFF_REDO : 0;
+    if (over || total == 0) return;
+    unsigned pslot = base + (unsigned)ex;
+    const unsigned grow = (unsigned)si;
+    const unsigned tbase = (unsigned)((size_t)b * kp.nt_max);
+#pragma unroll
+    for (int tp = 0; tp < TPM; ++tp) {
+        unsigned mm = m[tp];
+        while (mm) {
+            const int bit = __builtin_ctz(mm);
+            mm &= mm - 1;
+            const int idx = 31 - bit;
+            const int pos = pos_of(2 * tp + (idx >> 4), idx & 15);
+            const unsigned j = perm[pos];
+            const unsigned cls = (rowone && pos < n1) ? 1u : 0u;
+            sc.item_row[pslot] = grow;
+            sc.item_tgt[pslot] = ((tbase + j) << 1) | cls;
+            ++pslot;
+        }
+    }
+}
+
+// one lane per pooled candidate: the numpy-order float32 distance of its (source row, target row) and the exponent
+__global__ __launch_bounds__(256) void aff3_exact_kernel(A3Scratch sc, AffConsts ac) {
+    // a wave <-> 64 consecutive slots of one screen wave's slice
+    const unsigned chunks = sc.cap >> 6;
+    const unsigned gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const unsigned wv = gw / chunks, chunk = gw - wv * chunks;
+    if (wv >= sc.nwaves) return;
+    const unsigned cnt_w = sc.hdr[wv].y;
+    if (chunk * 64u >= cnt_w) return;
+    {
+        const unsigned slot = chunk * 64u + (threadIdx.x & 63u);
+        const unsigned g = wv * sc.cap + slot;
+        const bool act = slot < cnt_w;
+        const unsigned row = act ? sc.item_row[g] : 0u, tg = act ? sc.item_tgt[g] : 0u;
+        const float* ps = sc.fs_sc + (size_t)row * RP_FEAT;
+        const float* pt = sc.ft_sc + (size_t)(tg >> 1) * RP_FEAT;
+        float r8[8];
+#pragma unroll
+        for (int c8 = 0; c8 < RP_FEAT / 8; ++c8) {
+            const float4 sa = rp_ldg4(ps + 8 * c8), sb = rp_ldg4(ps + 8 * c8 + 4);
+            const float4 ta = rp_ldg4(pt + 8 * c8), tb = rp_ldg4(pt + 8 * c8 + 4);
+            const float ss[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            const float tt[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float df = ss[k] - tt[k];
+                const float sq = df * df;
+                if (c8 == 0) r8[k] = sq; else r8[k] = r8[k] + sq;
+            }
+        }
+        const float d = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+        const bool cls = (tg & 1u) != 0;
+        if (act) sc.item_e[g] = rp_exponent(d, cls ? ac.den[1] : ac.den[0], cls ? ac.rden[1] : ac.rden[0]);
+    }
+}
+
+// one lane per source row: rank the row's candidates (e descending, target index ascending), exp of the K winners, the float64 norm over
+// the norm window (winners in rank order, then the other candidates inside it in pool order), the outputs, the row's window values
+template <bool WRITE_WIJ, int KL>
+__global__ __launch_bounds__(256) void aff3_rank_kernel(RelposeKeypoints kp, int topK, int rows_per_block, int rpw, int nblk, int atw,
+                                                         float* __restrict__ wij, int32_t* __restrict__ corres_j, double* __restrict__ corres_w,
+                                                         A3Scratch sc) {
+    const long long grow = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nrow_all = (long long)kp.B * kp.ns_max;
+    const bool inb = grow < nrow_all;
+    const int b = inb ? (int)(grow / kp.ns_max) : 0;
+    const int r = inb ? (int)(grow - (long long)b * kp.ns_max) : 0;
+    const int ns = kp.ns[b], nt = kp.nt[b];
+    const int keff = (ns >= 3 && nt >= 3) ? min(topK, nt - 1) : 0;
+    bool live = inb && keff > 0 && r < ns;
+    if (live && corres_j[(size_t)grow * topK] == RP_AFF_REDO) live = false;
+    // the screen wave that owns this row, and the row's two pool segments (its half-row lanes n and n + 32)
+    const int blk = r / rows_per_block, rin = r - blk * rows_per_block;
+    const int w = rin / rpw, n = rin - w * rpw;
+    const size_t wv = ((size_t)b * nblk + blk) * atw + w;
+    uint2 hd = make_uint2(0u, 0u);
+    unsigned o0 = 0, c0 = 0, o1 = 0, c1 = 0;
+    if (live) {
+        hd = sc.hdr[wv];
+        const unsigned short* sg = sc.seg + wv * 64;
+        o0 = sg[n]; c0 = sg[n + 1] - o0;
+        o1 = sg[n + 32]; c1 = (n + 32 == 63 ? hd.y : sg[n + 33]) - o1;
+        if (hd.y == 0) { c0 = 0; c1 = 0; }
+    }
+    const unsigned ctot = c0 + c1;
+    const unsigned tbase = (unsigned)((size_t)b * kp.nt_max);
+    auto slot_of = [&](unsigned c) { return hd.x + (c < c0 ? o0 + c : o1 + (c - c0)); };
+    double le[KL];
+    int lj[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) { le[k] = -INFINITY; lj[k] = INT_MAX; }
+    for (unsigned c = 0; __ballot(c < ctot); ++c) {
+        const bool v = c < ctot;
+        const unsigned slot = v ? slot_of(c) : 0u;
+        double e = v ? sc.item_e[slot] : -INFINITY;
+        int jj = v ? (int)((sc.item_tgt[slot] >> 1) - tbase) : INT_MAX;
+#pragma unroll
+        for (int k = 0; k < KL; ++k) {
+            const bool better = (e > le[k]) || (e == le[k] && jj < lj[k]);
+            const double te_ = le[k]; const int tj_ = lj[k];
+            le[k] = better ? e : te_; lj[k] = better ? jj : tj_;
+            e = better ? te_ : e; jj = better ? tj_ : jj;
+        }
+    }
+    double lw[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) lw[k] = exp(le[k]);                            // (exp(-inf) = 0 for an empty entry)
+    const double emx = le[0];
+    const double need_norm = emx - RP_AFF_NORM_WINDOW;
+    double sumsq = 0.0;
+#pragma unroll
+    for (int k = 0; k < KL; ++k) if (le[k] >= need_norm) sumsq += lw[k] * lw[k];
+    {   // candidates inside the norm window that are not among the KL best, in pool order
+        const double elast = le[KL - 1]; const int jlast = lj[KL - 1];
+        if (__ballot(live && elast >= need_norm && ctot > (unsigned)KL)) {
+            for (unsigned c = 0; __ballot(c < ctot); ++c) {
+                const bool v = c < ctot;
+                const unsigned slot = v ? slot_of(c) : 0u;
+                const double e = v ? sc.item_e[slot] : -INFINITY;
+                const int jj = v ? (int)((sc.item_tgt[slot] >> 1) - tbase) : INT_MAX;
+                const bool want = v && e >= need_norm && ((e < elast) || (e == elast && jj > jlast));
+                if (__ballot(want)) { const double wv_ = exp(e); if (want) sumsq += wv_ * wv_; }
+            }
+        }
+    }
+    const double nm = sqrt(sumsq);
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < KL; ++k) {
+            if (k < keff) {
+                const bool ok = lj[k] >= 0 && lj[k] < nt;
+                corres_j[(size_t)grow * topK + k] = ok ? lj[k] : 0;
+                corres_w[(size_t)grow * topK + k] = (ok && nm != 0.0) ? lw[k] / nm : 0.0;
+            }
+        }
+    }
+    if (!WRITE_WIJ) return;
+    // window values: wij = exp(e - e_max) * (exp(e_max) / norm), exact zeros below the window (the zeros the screen wrote stay)
+    const float rsf = (!live || !(nm > 0.0)) ? 0.f : (float)(lw[0] / nm);
+    float* wrow = wij + (size_t)grow * kp.nt_max;
+    for (unsigned c = 0; __ballot(c < ctot); ++c) {
+        const bool v = live && c < ctot;
+        const unsigned slot = v ? slot_of(c) : 0u;
+        const double e = v ? sc.item_e[slot] : -INFINITY;
+        const int jj = v ? (int)((sc.item_tgt[slot] >> 1) - tbase) : 0;
+        const double x = e - emx;
+        const double tl = x * 1.4426950408889634;
+        const double nr = __builtin_rint(tl);
+        const float p2 = __builtin_amdgcn_exp2f((float)(tl - nr));
+        float val = ldexpf(p2 * rsf, (int)fmax(nr, -300.0));
+        if (!(x >= -RP_AFF_WINDOW && x <= 0.0)) val = 0.f;
+        if (v && val != 0.f) rp_stg(wrow + jj, val);
+    }
+}
+
 template <int TP>
 int launch_affinity_rows(const RelposeKeypoints& kp, const AffConsts& ac, int topK, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
     // ~2 waves per SIMD over the whole chip, between 2 and 32 rows per wave (the per-wave target staging costs ~2 rows' worth)
@@ -941,10 +1396,99 @@ int launch_affinity_rows(const RelposeKeypoints& kp, const AffConsts& ac, int to
     return 0;
 }
 
+// scratch of the pool variant: one grow-only block per stream (calls on one stream are ordered; calls on different streams get different blocks)
+struct A3Block { void* ptr = nullptr; size_t bytes = 0; };
+static std::mutex g_a3_mu;
+static std::map<std::pair<int, hipStream_t>, A3Block> g_a3_blocks;
+
+static int a3_scratch(size_t bytes, hipStream_t s, void** out) {
+    int dev = 0;
+    RP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_a3_mu);
+    A3Block& blk = g_a3_blocks[std::make_pair(dev, s)];
+    if (blk.bytes < bytes) {
+        if (blk.ptr) { RP_HIP(hipStreamSynchronize(s)); RP_HIP(hipFree(blk.ptr)); blk.ptr = nullptr; blk.bytes = 0; }
+        RP_HIP(hipMalloc(&blk.ptr, bytes));
+        blk.bytes = bytes;
+    }
+    *out = blk.ptr;
+    return 0;
+}
+
+template <int TP>
+static int a3_launch_fixup(const RelposeKeypoints& kp, const AffConsts& ac, int topK, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
+    const int rpw2 = 32;
+    dim3 grid2((kp.ns_max + 4 * rpw2 - 1) / (4 * rpw2), kp.B);
+    if (wij) hipLaunchKernelGGL((affinity_rows_kernel<TP, true, true>), grid2, dim3(256), 0, s, kp, ac, topK, rpw2, wij, cj, cw, keff);
+    else hipLaunchKernelGGL((affinity_rows_kernel<TP, false, true>), grid2, dim3(256), 0, s, kp, ac, topK, rpw2, wij, cj, cw, keff);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+// screen -> exact -> rank (+ the exact redo of marked rows): see aff3_screen_kernel
+static int launch_affinity_pool(const RelposeParams& p, const RelposeKeypoints& kp, const AffConsts& ac, float* wij, int32_t* cj, double* cw, int32_t* keff,
+                                hipStream_t s) {
+    const long long tiles32 = (long long)kp.B * ((kp.ns_max + 31) / 32);
+    const int ntp = (kp.nt_max + 63) & ~63;
+    const int atw = tiles32 >= 4096 ? AT_WAVES : (tiles32 >= 1024 ? 4 : 2);
+    const int nblk = (kp.ns_max + atw * 32 - 1) / (atw * 32);
+    const int rb = (kp.ns_max + nblk - 1) / nblk, rpw = (rb + atw - 1) / atw;
+    const size_t rows = (size_t)kp.B * kp.ns_max, tgts = (size_t)kp.B * kp.nt_max;
+    if (rows >= (1ull << 31) || tgts >= (1ull << 30)) return RELPOSE_EINVAL;
+    const size_t nwaves = (size_t)kp.B * nblk * atw;
+    // pool slots per screen wave: 32 candidates per row on average (the bench distributions have ~11; a dense window overflows into the exact redo)
+    const size_t capw = (((size_t)rpw * std::min(kp.nt_max, 32)) + 63) & ~(size_t)63;
+    const size_t cap = nwaves * capw;
+    if (cap >= (1ull << 32)) return RELPOSE_EINVAL;
+    size_t off = 0;
+    const size_t o_ctl = off; off += 256;
+    const size_t o_hdr = off; off += rp_align(nwaves * sizeof(uint2));
+    const size_t o_seg = off; off += rp_align(nwaves * 64 * sizeof(unsigned short));
+    const size_t o_fs = off; off += rp_align(rows * RP_FEAT * sizeof(float));
+    const size_t o_ft = off; off += rp_align(tgts * RP_FEAT * sizeof(float));
+    const size_t o_ir = off; off += rp_align(cap * sizeof(unsigned));
+    const size_t o_it = off; off += rp_align(cap * sizeof(unsigned));
+    const size_t o_ie = off; off += rp_align(cap * sizeof(double));
+    void* blk = nullptr;
+    const int rc = a3_scratch(off, s, &blk);
+    if (rc) return rc;
+    char* base = (char*)blk;
+    A3Scratch sc;
+    sc.ctl = (unsigned*)(base + o_ctl); sc.hdr = (uint2*)(base + o_hdr); sc.seg = (unsigned short*)(base + o_seg);
+    sc.fs_sc = (float*)(base + o_fs); sc.ft_sc = (float*)(base + o_ft);
+    sc.item_row = (unsigned*)(base + o_ir); sc.item_tgt = (unsigned*)(base + o_it); sc.item_e = (double*)(base + o_ie);
+    sc.cap = (unsigned)capw; sc.nwaves = (unsigned)nwaves;
+    const size_t lds = (size_t)ntp * (A3_LDB + 4 + 4) + 16;
+    dim3 grid(nblk, kp.B);
+#define RP_A3_SCREEN(W_, KL_, TPM_) \
+    hipLaunchKernelGGL((aff3_screen_kernel<W_, KL_, TPM_>), grid, dim3(atw * 64), lds, s, kp, ac, p.topK, ntp, rb, rpw, wij, cj, keff, sc)
+#define RP_A3_SCREEN_T(W_, KL_) { if (ntp <= 256) RP_A3_SCREEN(W_, KL_, 4); else RP_A3_SCREEN(W_, KL_, 8); }
+    if (wij) { if (p.topK <= 5) RP_A3_SCREEN_T(true, 5) else RP_A3_SCREEN_T(true, RP_MAXK) }
+    else { if (p.topK <= 5) RP_A3_SCREEN_T(false, 5) else RP_A3_SCREEN_T(false, RP_MAXK) }
+#undef RP_A3_SCREEN_T
+#undef RP_A3_SCREEN
+    RP_CHECK_LAUNCH();
+    const unsigned eg = (unsigned)((nwaves * (capw >> 6) + 3) / 4);
+    hipLaunchKernelGGL(aff3_exact_kernel, dim3(eg), dim3(256), 0, s, sc, ac);
+    RP_CHECK_LAUNCH();
+    const dim3 rg((unsigned)((rows + 255) / 256));
+#define RP_A3_RANK(W_, KL_) hipLaunchKernelGGL((aff3_rank_kernel<W_, KL_>), rg, dim3(256), 0, s, kp, p.topK, rb, rpw, nblk, atw, wij, cj, cw, sc)
+    if (wij) { if (p.topK <= 5) RP_A3_RANK(true, 5); else RP_A3_RANK(true, RP_MAXK); }
+    else { if (p.topK <= 5) RP_A3_RANK(false, 5); else RP_A3_RANK(false, RP_MAXK); }
+#undef RP_A3_RANK
+    RP_CHECK_LAUNCH();
+    switch ((kp.nt_max + 127) / 128) {
+        case 1: return a3_launch_fixup<1>(kp, ac, p.topK, wij, cj, cw, keff, s);
+        case 2: return a3_launch_fixup<2>(kp, ac, p.topK, wij, cj, cw, keff, s);
+        case 3: return a3_launch_fixup<3>(kp, ac, p.topK, wij, cj, cw, keff, s);
+        default: return a3_launch_fixup<4>(kp, ac, p.topK, wij, cj, cw, keff, s);
+    }
+}
+
 }  // namespace
 
 int rp_launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
-    const int sel = g_rp_tune[RELPOSE_TUNE_AFFINITY_KERNEL];      // 0: by size, 1: row kernel, 2: tile kernel, 3: LDS kernel
+    const int sel = g_rp_tune[RELPOSE_TUNE_AFFINITY_KERNEL];      // 0: by size, 1: row kernel, 2: tile kernel, 3: LDS kernel, 4: pool variant
     const RpPairConsts kc = rp_make_consts(p);
     AffConsts ac;
     ac.den[0] = kc.den_other; ac.den[1] = kc.den_both;
@@ -960,6 +1504,9 @@ int rp_launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float
         // small batches: the row kernel (one wave per few rows) has the lower latency; the tile kernel pays from ~256 row tiles on
         const long long tiles32 = (long long)kp.B * ((kp.ns_max + 31) / 32);
         const bool use_tile = sel == 2 || (sel == 0 && tiles32 >= RP_AFF_TILE_MIN_TILES);
+        // the pool variant: forced, or by itself where it measured faster than the tile kernel -- the fused form (no wij copy) beyond 256 targets
+        // (B = 1024, N = 400: 254 vs 342 us; at N = 200 the tile kernel wins 95 vs 117 us, and with a materialised wij everywhere: profiles/r05_affinity_pool.txt)
+        if (sel == 4 || (sel == 0 && !wij && kp.nt_max > 256 && tiles32 >= RP_AFF_TILE_MIN_TILES)) return launch_affinity_pool(p, kp, ac, wij, cj, cw, keff, s);
         if (use_tile) {
             // second-generation tile kernel + (normally idle) exact redo of the rows it marked
             const int ntp = (kp.nt_max + 63) & ~63;

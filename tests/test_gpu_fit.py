@@ -233,7 +233,7 @@ def test_row_and_tile_affinity_kernels_equal_lds_kernel():
     with _lib.tuning(affinity_kernel="lds"):
         old = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
     # the current kernels: batch-size default, row kernel forced, tile kernel forced
-    for sel in ("auto", "rows", "tile"):
+    for sel in ("auto", "rows", "tile", "pool"):
         with _lib.tuning(affinity_kernel=sel):
             new = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
         assert torch.equal(new[1], old[1]) and torch.equal(new[3], old[3]), sel             # corres_j, k_eff
@@ -292,6 +292,15 @@ def test_tile_affinity_kernel_at_production_batch_vs_oracle():
     _check_affinity_vs_oracle(cases, para, auto, rows={0, 1, 2, 100, 255})
     fused = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para, want_wij=False)
     assert torch.equal(fused[1], auto[1]) and torch.equal(fused[2], auto[2])        # the fused variant: same indices, same weights, bitwise
+    # the pool variant (round 5: screen / exact / rank as separate dense launches): same indices, weights and wij to round-off, its fused form bitwise its own
+    with _lib.tuning(affinity_kernel="pool"):
+        pool = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+        pool_f = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para, want_wij=False)
+    assert torch.equal(pool[1], rows[1]) and torch.equal(pool[3], rows[3])
+    assert torch.allclose(pool[2], rows[2], rtol=1e-13, atol=0)
+    assert torch.allclose(pool[0], rows[0], rtol=1e-6, atol=1e-30)
+    assert torch.equal(pool_f[1], pool[1]) and torch.equal(pool_f[2], pool[2])
+    _check_affinity_vs_oracle(cases, para, pool, rows={0, 1, 2, 100, 255})
 
 
 def test_tile_affinity_overflow_rows_are_redone_exactly():
@@ -310,11 +319,12 @@ def test_tile_affinity_overflow_rows_are_redone_exactly():
     cases = [(S, T), (S2, T2), (S3, T3)]
     para = rpmodule.opts(0.3, 0.3, 0.04, 0.0087)
     kp = rpmodule.pack_keypoints(cases, dev)
-    with _lib.tuning(affinity_kernel="tile"):
-        out = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
-    _check_affinity_vs_oracle(cases, para, out)
     with _lib.tuning(affinity_kernel="rows"):
         ref = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
-    assert torch.equal(out[1], ref[1])                                     # ties resolved like the row kernel (smaller index)
-    assert torch.allclose(out[2], ref[2], rtol=1e-13, atol=0)              # (the two kernels add the row norm up in different orders)
-    assert torch.allclose(out[0], ref[0], rtol=1e-6, atol=1e-30)
+    for sel in ("tile", "pool"):          # (pool variant: 150 tied entries per row overflow nothing -- its pool is dynamic -- but the bound's redo rows are marked the same way)
+        with _lib.tuning(affinity_kernel=sel):
+            out = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)
+        _check_affinity_vs_oracle(cases, para, out)
+        assert torch.equal(out[1], ref[1]), sel                                # ties resolved like the row kernel (smaller index)
+        assert torch.allclose(out[2], ref[2], rtol=1e-13, atol=0), sel         # (the kernels add the row norm up in different orders)
+        assert torch.allclose(out[0], ref[0], rtol=1e-6, atol=1e-30), sel

@@ -43,7 +43,7 @@ def _params(gm, ds, row, method="irls+sm"):
 
 
 @pytest.mark.parametrize("ci", range(len(MATCH_CASES)))
-@pytest.mark.parametrize("aff_kernel", ["rows", "tile"])
+@pytest.mark.parametrize("aff_kernel", ["rows", "tile", "pool"])
 def test_matcher_stages_vs_oracle(gm, dev, ci, aff_kernel):
     """aff_kernel: the register-resident affinity kernel (small batches) / the tile kernel (fp16-MFMA candidates + exact
     arithmetic on them; large batches), forced through relpose_set_tuning."""
@@ -110,7 +110,7 @@ def _stage_cases():
     return [(str(ci), c + (0.005,)) for ci, c in enumerate(MATCH_CASES)] + [("big", MATCH_BIG)]
 
 
-@pytest.mark.parametrize("aff_kernel", ["rows", "tile"])
+@pytest.mark.parametrize("aff_kernel", ["rows", "tile", "pool"])
 @pytest.mark.parametrize("tag,case", _stage_cases())
 def test_matcher_stages_vs_reference_stage_goldens(gm, dev, golden_dir, tag, case, aff_kernel):
     """Every stage of the HIP matcher against what the REFERENCE RUN ITSELF produced (tests/golden/matcher_stages.npz, captured by
@@ -122,8 +122,8 @@ def test_matcher_stages_vs_reference_stage_goldens(gm, dev, golden_dir, tag, cas
     from test_oracle_golden import check_corres_sets
     gs = np.load(os.path.join(golden_dir, "matcher_stages.npz"))
     N, Nt, seed, ds, row, inl, noise = case
-    if aff_kernel == "tile" and N > 512:
-        pytest.skip("the tile kernel takes up to 512 targets")
+    if aff_kernel in ("tile", "pool") and N > 512:
+        pytest.skip("the tile / pool kernels take up to 512 targets")
     S, T, _ = synth.make_match_case(N, seed, inlier=inl, noise=noise, Nt=Nt)
     para, _ = _params(gm, ds, row)
     with _lib.tuning(affinity_kernel=aff_kernel):
