@@ -73,7 +73,9 @@ void relpose_default_params(RelposeParams* p_host);
  * through the same checks); they exist for those tests and for tuning, not for the data path.  Returns the previous
  * value, RELPOSE_EINVAL for an unknown key.  Not synchronised with calls in flight on other threads.
  *   RELPOSE_TUNE_AFFINITY_KERNEL    0 = by batch size (default), 1 = row kernel (targets in registers), 2 = tile kernel
- *                                   (fp16-MFMA candidates + exact arithmetic on them), 3 = LDS kernel (the nt_max > 512 path)
+ *                                   (fp16-MFMA candidates + exact arithmetic on them), 3 = LDS kernel (the nt_max > 512 path),
+ *                                   4 = pool variant (round 5: the tile kernel's stages as separate dense launches; auto-selected for the
+ *                                   fused form beyond 256 targets at large batches, where it measured faster)
  *   RELPOSE_TUNE_FIT_MAX_PRODUCTS   0 = default budget (192) of matrix-vector products per eigen-solve; a tiny budget
  *                                   forces RELPOSE_NOT_CONVERGED
  *   RELPOSE_TUNE_FIT_CLUSTER        0 = by problem size (default), n = workgroups per scan pair in the fit (1, 2, 4, 8)
@@ -82,9 +84,13 @@ void relpose_default_params(RelposeParams* p_host);
  *   RELPOSE_TUNE_FIT_FIXED_CHECKS   0 = the eigen-solve places its convergence tests where the residual estimate is predicted to
  *                                   reach the tolerance (default), 1 = a test every 8 products (the earlier rule; A/B switch).  The
  *                                   one knob whose settings agree to round-off only (both converge to 1e-13; the number of Lanczos
- *                                   steps differs) */
+ *                                   steps differs)
+ *   RELPOSE_TUNE_HEADS_GRID / RELPOSE_TUNE_CONV1_GRID   (round 5) workgroups of the SCNet forward's tail (heads) / head (conv1) launches: 0 = one per tile
+ *                                   (default); n > 0 = at most n workgroups walking over the tiles -- caps how much of the chip these HBM-bound kernels
+ *                                   hold beside the other batch's convolutions in the serving loop (same results; A/B switch) */
 enum { RELPOSE_TUNE_AFFINITY_KERNEL = 0, RELPOSE_TUNE_FIT_MAX_PRODUCTS = 1, RELPOSE_TUNE_FIT_CLUSTER = 2,
-       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_COUNT = 8 };
+       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_HEADS_GRID = 5, RELPOSE_TUNE_CONV1_GRID = 6,
+       RELPOSE_TUNE_COUNT = 8 };
 int relpose_set_tuning(int32_t key, int32_t value);
 const char* relpose_version(void);
 /* A HIP stream whose kernels may only use the first `n_cus` compute units of the device's CU-mask order (hipExtStreamCreateWithCUMask; on gfx950 the

@@ -328,3 +328,26 @@ def test_tile_affinity_overflow_rows_are_redone_exactly():
         assert torch.equal(out[1], ref[1]), sel                                # ties resolved like the row kernel (smaller index)
         assert torch.allclose(out[2], ref[2], rtol=1e-13, atol=0), sel         # (the kernels add the row norm up in different orders)
         assert torch.allclose(out[0], ref[0], rtol=1e-6, atol=1e-30), sel
+
+
+def test_pool_affinity_variant_where_the_launcher_picks_it_by_itself():
+    """The pool variant (round 5) is auto-selected for the fused form (no wij copy) beyond 256 targets at >= 1024 row tiles -- the one case it measured
+    faster than the tile kernel (profiles/r05_affinity_pool.txt).  128 pairs x 300 keypoints (ragged): indices equal the row kernel's, weights to round-off,
+    sampled pairs against the numpy oracle; the materialised call of the same batch (tile kernel) gives bitwise the same indices."""
+    import torch
+    from relativepose_amd import _lib, rpmodule
+    dev = torch.device("cuda:0")
+    cases = [synth.make_match_case(300 - (b % 4), 7000 + b, inlier=(0.6, 0.3, 0.0)[b % 3], Nt=300 - (b % 7))[:2] for b in range(128)]
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.0087)
+    kp = rpmodule.pack_keypoints(cases, dev)
+    fused = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para, want_wij=False)             # auto -> pool
+    with _lib.tuning(affinity_kernel="pool"):
+        forced = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para, want_wij=False)
+    assert torch.equal(fused[1], forced[1]) and torch.equal(fused[2], forced[2])                               # (it IS the pool variant)
+    with _lib.tuning(affinity_kernel="rows"):
+        rows = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para, want_wij=False)
+    assert torch.equal(fused[1], rows[1]) and torch.equal(fused[3], rows[3])
+    assert torch.allclose(fused[2], rows[2], rtol=1e-13, atol=0)
+    full = rpmodule.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], para)                               # materialised: the tile kernel
+    assert torch.equal(full[1], fused[1]) and torch.allclose(full[2], fused[2], rtol=1e-13, atol=0)
+    _check_affinity_vs_oracle(cases, para, (None,) + tuple(fused[1:]), rows={0, 5, 127})
