@@ -93,8 +93,6 @@ def parse_args(argv=None):
                          "a batch's chain runs under the next batch's encoder")
     ap.add_argument("--mid-priority", type=int, default=-1, help="--split-forward: HIP stream priority of the chain's stream")
     ap.add_argument("--slot-cus", type=int, default=0, help="A/B: CU-mask the slot streams (head, tail, geometry, matcher) to this many compute units; 0 = no mask")
-    ap.add_argument("--heads-grid", type=int, default=0, help="A/B: workgroup cap of the heads launch (RELPOSE_TUNE_HEADS_GRID; 0 = one per 256-pixel block)")
-    ap.add_argument("--conv1-grid", type=int, default=0, help="A/B: workgroup cap of the conv1 launch (RELPOSE_TUNE_CONV1_GRID; 0 = one per tile)")
     ap.add_argument("--hw-queues", type=int, default=0,
                     help="A/B: GPU_MAX_HW_QUEUES for this process (the HIP runtime multiplexes streams onto 4 hardware queues by default); 0 = leave the environment alone")
     ap.add_argument("--keypoint-mode", choices=["given", "reference"], default="given",
@@ -231,10 +229,6 @@ def worker(args):
     from relativepose_amd.pipeline import RelativePosePipeline
 
     rank, world, local = D.init_from_env()
-    if args.heads_grid or args.conv1_grid:
-        from relativepose_amd import _lib
-        _lib.lib().relpose_set_tuning(_lib.TUNE_KEYS["heads_grid"], args.heads_grid)
-        _lib.lib().relpose_set_tuning(_lib.TUNE_KEYS["conv1_grid"], args.conv1_grid)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher provides WORLD_SIZE={world}")
     torch.cuda.set_device(local)

@@ -84,13 +84,9 @@ void relpose_default_params(RelposeParams* p_host);
  *   RELPOSE_TUNE_FIT_FIXED_CHECKS   0 = the eigen-solve places its convergence tests where the residual estimate is predicted to
  *                                   reach the tolerance (default), 1 = a test every 8 products (the earlier rule; A/B switch).  The
  *                                   one knob whose settings agree to round-off only (both converge to 1e-13; the number of Lanczos
- *                                   steps differs)
- *   RELPOSE_TUNE_HEADS_GRID / RELPOSE_TUNE_CONV1_GRID   (round 5) workgroups of the SCNet forward's tail (heads) / head (conv1) launches: 0 = one per tile
- *                                   (default); n > 0 = at most n workgroups walking over the tiles -- caps how much of the chip these HBM-bound kernels
- *                                   hold beside the other batch's convolutions in the serving loop (same results; A/B switch) */
+ *                                   steps differs) */
 enum { RELPOSE_TUNE_AFFINITY_KERNEL = 0, RELPOSE_TUNE_FIT_MAX_PRODUCTS = 1, RELPOSE_TUNE_FIT_CLUSTER = 2,
-       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_HEADS_GRID = 5, RELPOSE_TUNE_CONV1_GRID = 6,
-       RELPOSE_TUNE_COUNT = 8 };
+       RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_COUNT = 8 };
 int relpose_set_tuning(int32_t key, int32_t value);
 const char* relpose_version(void);
 /* A HIP stream whose kernels may only use the first `n_cus` compute units of the device's CU-mask order (hipExtStreamCreateWithCUMask; on gfx950 the

@@ -130,7 +130,7 @@ def _build_locked():
 
 
 # relpose_set_tuning keys (include/relpose.h RELPOSE_TUNE_*)
-TUNE_KEYS = {"affinity_kernel": 0, "fit_max_products": 1, "fit_cluster": 2, "fit_global_vectors": 3, "fit_fixed_checks": 4, "heads_grid": 5, "conv1_grid": 6}
+TUNE_KEYS = {"affinity_kernel": 0, "fit_max_products": 1, "fit_cluster": 2, "fit_global_vectors": 3, "fit_fixed_checks": 4}
 AFFINITY_KERNELS = {"auto": 0, "rows": 1, "tile": 2, "lds": 3, "pool": 4}
 
 

@@ -30,8 +30,6 @@
 #include <stdlib.h>
 #include <stddef.h>
 
-extern int32_t g_rp_tune[RELPOSE_TUNE_COUNT];      // relpose_set_tuning (matcher.hip owns the table)
-
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -1508,11 +1506,9 @@ __global__ __launch_bounds__(256, 3) void conv1_mfma_kernel(const float* __restr
     __shared__ __attribute__((aligned(16))) float xin[C1T_XIN];      // later reused for the per-wave statistics [4][192][2] f64
     static_assert(C1T_XIN * 4 >= 4 * 192 * 2 * 8, "statistics scratch aliases the input tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-    for (int i = tid; i < 6 * 9 * 4 * 32 / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(w1)[i];
-    for (unsigned blk = blockIdx.x; blk < 196u * (unsigned)n; blk += gridDim.x) {      // (fewer workgroups than tiles: RELPOSE_TUNE_CONV1_GRID)
-    if (blk != blockIdx.x) __syncthreads();                            // the statistics scratch of the previous tile aliases the input tile
-    const int tile = blk % 196, img = blk / 196;
+    const int tile = blockIdx.x % 196, img = blockIdx.x / 196;
     const int ty0 = (tile / 7) * 8, tx0 = (tile % 7) * 32;
+    for (int i = tid; i < 6 * 9 * 4 * 32 / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(w1)[i];
     for (int i = tid; i < 340 * 4; i += 256) {
         const int p = i >> 2, q4 = i & 3;
         const int py = p / 34, px = p - py * 34;
@@ -1582,7 +1578,6 @@ __global__ __launch_bounds__(256, 3) void conv1_mfma_kernel(const float* __restr
         double* o = stat + (pass * 192 + tid) * 2;
         o[0] = ssum; o[1] = ssq;
     }
-    }   // blk
 }
 
 // ---- the five 1x1 heads deconv1{rgb,n,d,s,f} (mymodel.py:188,196,204,220,228 / :312-376) in one pass ---------
@@ -1601,7 +1596,6 @@ struct HeadsDesc {
     // in every plan; snap_mode 1 stores the three heads' accumulators after it (12 floats per pixel), snap_mode 2 starts from them and
     // does not read A1 at all (384 of the 1280 bytes a pixel reads)
     int snap_mode; float* snap;
-    unsigned nblk;             // 256-pixel blocks in all (the launch may have fewer workgroups: RELPOSE_TUNE_HEADS_GRID)
 };
 constexpr int HEADS_W = 4352;
 
@@ -1617,13 +1611,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     __shared__ __attribute__((aligned(16))) float wl[HEADS_W];
     __shared__ float2 ssl[320];                        // scale/shift of this block's BatchNorm group
     constexpr int cf = 7 + S + 32;
-    for (int i = threadIdx.x; i < HEADS_W; i += 256) wl[i] = hd.w[i];
-    // (a launch with fewer workgroups than blocks walks over them: the A/B switch that caps how many CUs' worth of registers this HBM-bound kernel
-    // holds while the other batch's convolutions run)
-    for (unsigned blk = blockIdx.x; blk < hd.nblk; blk += gridDim.x) {
-    if (blk != blockIdx.x) __syncthreads();            // the previous block's lanes are done with ssl
-    const size_t pix0 = (size_t)blk * 256;             // 256 consecutive pixels: one image, one BatchNorm group
+    const size_t pix0 = (size_t)blockIdx.x * 256;      // 256 consecutive pixels: one image, one BatchNorm group
     const int g = (int)(pix0 / ((size_t)RS * RS)) >> 1;
+    for (int i = threadIdx.x; i < HEADS_W; i += 256) wl[i] = hd.w[i];
     for (int i = threadIdx.x; i < 320; i += 256) {
         // A1 skip blocks: channels [0:32] (rgb self), [64:96] (n self), [128:160] (d self) of the 192-channel buffer
         ssl[i] = i < 224 ? hd.ss_d2[(size_t)g * 224 + i] : hd.ss_a1[(size_t)g * 192 + ((i - 224) >> 5) * 64 + ((i - 224) & 31)];
@@ -1726,7 +1716,6 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     float* o = hd.out + pix * cf;
 #pragma unroll
     for (int k = 0; k < cf / 2; ++k) *reinterpret_cast<float2*>(o + 2 * k) = make_float2(r[2 * k], r[2 * k + 1]);
-    }   // blk
 }
 
 // Split-K reduce + BatchNorm partial sums in one pass (round 2): grid (chunk, group, member); a workgroup adds the K slices of a
@@ -3237,7 +3226,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
                 hipLaunchKernelGGL(conv1_direct_kernel, dim3(1024), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                    act + net->bufs["A1"].off * n, partial, n);
             else
-                hipLaunchKernelGGL(conv1_mfma_kernel, dim3(g_rp_tune[RELPOSE_TUNE_CONV1_GRID] > 0 ? std::min(196 * n, (int)g_rp_tune[RELPOSE_TUNE_CONV1_GRID]) : 196 * n), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
+                hipLaunchKernelGGL(conv1_mfma_kernel, dim3(196 * n), dim3(256), 0, s, act + net->bufs["X0"].off * n, net->d_w + net->w1_off,
                                    act + net->bufs["A1"].off * n, partial, n, (plan->zero_warp ? 1 : 0) | (plan->self_cached ? 2 : 0));
             mark(-1);
         } else if (op.type == OP_STATS_FUSED) {
@@ -3259,9 +3248,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
             hd.n = n; hd.S = net->S; hd.cf = net->cf; hd.use_tanh = net->use_tanh;
             hd.snap_mode = plan->snap_mode; hd.snap = (float*)(ws + o.snap) + plan->heads_snap_off;
             mark(1);
-            hd.nblk = (unsigned)((size_t)n * RS * RS / 256);
-            const int hcap = g_rp_tune[RELPOSE_TUNE_HEADS_GRID];
-            const dim3 hg(hcap > 0 ? std::min<unsigned>(hd.nblk, (unsigned)hcap) : hd.nblk);
+            const dim3 hg((unsigned)((size_t)n * RS * RS / 256));
             if (plan->pose_only) {
                 if (net->S == 15) hipLaunchKernelGGL((heads_kernel<15, true>), hg, dim3(256), 0, s, hd);
                 else hipLaunchKernelGGL((heads_kernel<21, true>), hg, dim3(256), 0, s, hd);
