@@ -11,8 +11,10 @@ configurations (Matterport N=400; ScanNet/kinect 32 pairs per GPU = 256 over 8;
 SUNCG 320x1280 with the fp16-MFMA conv path).  Pairs shard across ranks with no
 data-path collective and one RCCL all_gather of the 4x4 poses per step
 (``--scaling weak``: pairs per GPU fixed; ``--scaling strong``: ``--total-pairs``
-fixed).  Two steps are in flight (--inflight 2) over 4 rotating prepared batches:
-the launch-bound matcher phase of step k runs under the SCNet forward of step k+1.
+fixed).  Three steps are in flight (--inflight 3) over 6 rotating prepared batches:
+the launch-bound matcher phase of step k runs under the SCNet forwards of steps k+1, k+2
+(round 5: a third slot is free on configs[1] / [3] and worth +2 % / +7 % on configs[2] / [4],
+whose tail -> matcher -> warp -> head chain is longer than one forward).
 
     python bench.py                                   # 1 GPU, configs[1]
     python bench.py --gpus 8                          # spawns 8 ranks itself (one per GPU, RCCL)
@@ -85,9 +87,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-tail-overlap", action="store_true", help="A/B: the whole SCNet forward on the SCNet stream (no head / tail on the slot streams)")
     ap.add_argument("--net-priority", type=int, default=None, help="A/B: HIP stream priority of the SCNet stream (default: -1 = high when the tail overlaps)")
     ap.add_argument("--fit-cluster", type=int, default=1, help="A/B: workgroups per scan pair in the fit inside the loop (default 1: no helper workgroups)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="batches (steps) in flight per GPU: the matcher phase of step k overlaps the SCNet forward of step k+1")
-    ap.add_argument("--batches", type=int, default=4, help="distinct prepared batches rotated through the in-flight slots")
+    ap.add_argument("--batches", type=int, default=6, help="distinct prepared batches rotated through the in-flight slots")
+    ap.add_argument("--h2d-inflight", type=int, default=2,
+                    help="batches in flight during the PCIe-inclusive run (0 = --inflight): with the copy stream beside them two in flight measured better than "
+                         "three (configs[4]: 937 vs 769-876 pairs/s PCIe-inclusive), while three are better with resident inputs")
     ap.add_argument("--split-forward", type=int, default=0, choices=[0, 1],
                     help="A/B: every SCNet forward enqueued in two halves with the bottleneck chain on a third stream (RELPOSE_FWD_PART_FRONT / _BACK): "
                          "a batch's chain runs under the next batch's encoder")
@@ -285,8 +290,9 @@ def worker(args):
     #              runs under the other batches' convolutions instead of in front of its own batch (round 4: -21 % at configs[4])
     per_step_h2d = 0 if args.no_h2d else sum(t.numel() * t.element_size() for t in batches[0]["host"].values())
     # (measured, round 5: configs[4] 764 -> 925 pairs/s PCIe-inclusive = -4 % instead of -22 %; configs[1] 660 -> 663: look-ahead whenever the rotation allows it)
-    h2d_mode = args.h2d_mode if args.h2d_mode != "auto" else ("lookahead" if nbatch >= 2 * depth else "slot")
-    if h2d_mode == "lookahead" and nbatch < 2 * depth:
+    depth_h2d = max(1, min(args.h2d_inflight, depth)) if args.h2d_inflight > 0 else depth      # batches in flight while the inputs stream in
+    h2d_mode = args.h2d_mode if args.h2d_mode != "auto" else ("lookahead" if nbatch >= 2 * depth_h2d else "slot")
+    if h2d_mode == "lookahead" and nbatch < 2 * depth_h2d:
         h2d_mode = "slot"
     copy_stream = torch.cuda.Stream() if (h2d_mode == "lookahead" and not args.no_h2d) else None
 
@@ -302,6 +308,7 @@ def worker(args):
 
     def run_steps(k, h2d=False):
         """k steps = k batches of nloc pairs on this GPU, each followed by the pose gather; returns the last result."""
+        dp = depth_h2d if h2d else depth
         if h2d and h2d_mode == "lookahead":
             for st in batches:
                 st.pop("upload_ev", None)
@@ -310,18 +317,18 @@ def worker(args):
                 if "upload_ev" not in st:
                     issue_upload(st)                                   # the first `depth` batches of a run: nothing was sent ahead
                 torch.cuda.current_stream().wait_event(st.pop("upload_ev"))
-                j = i + depth
+                j = i + dp
                 if j < k and "upload_ev" not in batches[j % nbatch]:
                     issue_upload(batches[j % nbatch])
         else:
             before = (lambda i, st: pipe.upload_inputs(st, None)) if h2d else None
         if world == 1 or args.gather == "step" or total % world:        # (ragged shards: the per-step gather pads every block)
-            return pipe.run_pipelined(batches, k, lambda i, pose, status: D.gather_poses(pose, status, total, world), depth=depth,
+            return pipe.run_pipelined(batches, k, lambda i, pose, status: D.gather_poses(pose, status, total, world), depth=dp,
                                       before_batch=before)[-1]
         # --gather run (default): ONE collective for the whole run (north_star: "a single RCCL gather of the poses") -- the k steps'
         # poses of this rank are stacked and gathered once, inside the timed region; no RCCL kernel shares a hardware queue with
         # the SCNet / slot streams in steady state
-        res = pipe.run_pipelined(batches, k, None, depth=depth, before_batch=before)
+        res = pipe.run_pipelined(batches, k, None, depth=dp, before_batch=before)
         pose = torch.stack([r[0] for r in res], 1).reshape(nloc * k, 4, 4)          # [pair, step] order: a rank's block stays contiguous
         status = torch.stack([r[1] for r in res], 1).reshape(nloc * k)
         gp, gs = D.gather_poses(pose, status, total * k, world)
@@ -394,10 +401,10 @@ def worker(args):
                "status_ok_fraction": float((status == 0).double().mean().item())}
         if dt_h2d is not None:
             res["pcie_inclusive"] = {"value": total * args.steps / dt_h2d, "unit": "pairs/s", "ms_per_step": dt_h2d / args.steps * 1e3,
-                                     "h2d_bytes_per_step_per_gpu": per_step_h2d, "mode": h2d_mode,
+                                     "h2d_bytes_per_step_per_gpu": per_step_h2d, "mode": h2d_mode, "batches_in_flight": depth_h2d,
                                      "note": ("every step's panoramas + keypoints uploaded from pinned host memory on the batch's own stream (under the other "
                                               "in-flight batch's forward)" if h2d_mode == "slot" else
-                                              f"every step's panoramas + keypoints uploaded from pinned host memory on a copy stream {depth} steps ahead of their batch "
+                                              f"every step's panoramas + keypoints uploaded from pinned host memory on a copy stream {depth_h2d} steps ahead of their batch "
                                               "(under the in-flight batches' convolutions)") + "; never the headline value"}
         if not args.no_aux:
             # --- roofline of the dominant kernel: implicit-GEMM conv, HIP events on the launch stream

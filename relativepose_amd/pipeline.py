@@ -300,7 +300,13 @@ class RelativePosePipeline:
                         else:
                             st = states[nxt % nst]
                         if st.get("stream") is not None and st["stream"] is not ss:
-                            ss.wait_stream(st["stream"])         # the buffers' previous use (another slot / run_interleaved)
+                            # the buffers' previous use (another slot / run_interleaved): the batch that used them recorded its completion -- wait for
+                            # THAT, not for whatever else has been queued on its slot stream since (with 4 rotating batches and 3 in flight a state
+                            # changes slot every time: waiting for the whole stream serialised the slots, 592 vs 634 pairs/s at configs[2])
+                            if st.get("done_ev") is not None:
+                                ss.wait_event(st["done_ev"])
+                            else:
+                                ss.wait_stream(st["stream"])
                         st["stream"] = ss
                         if before_batch is not None:
                             with torch.cuda.stream(st["stream"]):

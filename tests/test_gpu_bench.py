@@ -79,7 +79,7 @@ def test_bench_eight_rank_plumbing_ragged_and_even():
     env.update(RELPOSE_DIST_BACKEND="gloo", RELPOSE_FORCE_DEVICE="0")
     for total, steps, want_gathers in ((256, 2, 1), (250, 2, 2)):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "3", "--scaling", "strong", "--total-pairs", str(total),
-                              "--steps", str(steps), "--warmup", "0", "--keypoints", "40", "--batches", "2", "--no-aux", "--no-h2d"],
+                              "--steps", str(steps), "--warmup", "0", "--keypoints", "40", "--batches", "2", "--inflight", "2", "--no-aux", "--no-h2d"],      # (8 ranks on ONE device: 2 workspaces of 11.5 GB each)
                              capture_output=True, text=True, timeout=2400, cwd=ROOT, env=env)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
