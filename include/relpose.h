@@ -75,7 +75,8 @@ void relpose_default_params(RelposeParams* p_host);
  *   RELPOSE_TUNE_AFFINITY_KERNEL    0 = by batch size (default), 1 = row kernel (targets in registers), 2 = tile kernel
  *                                   (fp16-MFMA candidates + exact arithmetic on them), 3 = LDS kernel (the nt_max > 512 path),
  *                                   4 = pool variant (round 5: the tile kernel's stages as separate dense launches; auto-selected for the
- *                                   fused form beyond 256 targets at large batches, where it measured faster)
+ *                                   fused form beyond 256 targets at large batches, where it measured faster; it keeps one grow-only scratch
+ *                                   block per (device, stream) it was called on for the life of the process: ~0.3 KB per source row)
  *   RELPOSE_TUNE_FIT_MAX_PRODUCTS   0 = default budget (192) of matrix-vector products per eigen-solve; a tiny budget
  *                                   forces RELPOSE_NOT_CONVERGED
  *   RELPOSE_TUNE_FIT_CLUSTER        0 = by problem size (default), n = workgroups per scan pair in the fit (1, 2, 4, 8)

@@ -205,6 +205,15 @@ def test_pipeline_rotating_states_with_reupload_equal_sequential_runs():
         assert torch.equal(pose, want[k % 4][0]) and torch.equal(status, want[k % 4][1]), k
     stacked = torch.stack([r[0] for r in res], 1).reshape(2 * 7, 4, 4).reshape(2, 7, 4, 4)
     assert torch.equal(stacked[:, -1], want[6 % 4][0])
+    # three in flight over the same 4 states (the bench default since round 5): a state changes slot EVERY time it comes round, its re-use is ordered behind
+    # the completion event of the batch that last used its buffers (not behind whatever its previous slot stream has queued since)
+    for st in states:
+        for k in st["host"]:
+            st[k].zero_()
+    res = pipe.run_pipelined(states, 11, None, depth=3, before_batch=lambda i, st: pipe.upload_inputs(st, None))
+    torch.cuda.synchronize()
+    for k, (pose, status) in enumerate(res):
+        assert torch.equal(pose, want[k % 4][0]) and torch.equal(status, want[k % 4][1]), ("depth 3", k)
 
 
 def test_pipeline_pose_outputs_option_gives_the_same_poses():
