@@ -2543,8 +2543,12 @@ void Builder::end_group() {
     // split along K until the launch has >= ~3000 tiles (>= 4 waves of resident blocks), keeping >= 8 k-tiles per slice
     int ksplit = 1;
     // (64 x 64 tiles: ~2 workgroups per CU are enough -- these launches are latency-bound chains, not throughput -- with >= 16 k-tiles each)
-    const long want_tiles = cfg == 7 ? 2048 : 3000;
-    const int min_slice = 8;
+    // (experiments build: RELPOSE_WANT_TILES / RELPOSE_WANT_TILES64 / RELPOSE_MIN_SLICE override the split-K rule below)
+    static const long wt_env = RP_ENV("RELPOSE_WANT_TILES") ? atol(RP_ENV("RELPOSE_WANT_TILES")) : 0;
+    static const long wt64_env = RP_ENV("RELPOSE_WANT_TILES64") ? atol(RP_ENV("RELPOSE_WANT_TILES64")) : 0;
+    static const int ms_env = RP_ENV("RELPOSE_MIN_SLICE") ? atoi(RP_ENV("RELPOSE_MIN_SLICE")) : 0;
+    const long want_tiles = cfg == 7 ? (wt64_env > 0 ? wt64_env : 2048) : (wt_env > 0 ? wt_env : 3000);
+    const int min_slice = ms_env > 0 ? ms_env : 8;
     while (!dtile && s2_cfg < 0 && tiles * ksplit < want_tiles && ksplit < 64 && min_kt / (ksplit * 2) >= min_slice) ksplit *= 2;
     if (force_ksplit && !dtile && s2_cfg < 0) ksplit = force_ksplit;
     size_t pf = 0;
