@@ -48,5 +48,12 @@ for vi, (name, tune) in enumerate((("fit, default", {}), ("fit, 1 workgroup per 
         e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
     c = res.counts.cpu().numpy(); it = res.eig_iters.cpu().numpy()
+    if os.environ.get("RELPOSE_POSE_DUMP"):          # (A/B of experiment builds: poses of this variant for a later comparison)
+        pth = os.environ["RELPOSE_POSE_DUMP"]
+        if os.path.exists(pth):
+            ref = np.load(pth)
+            print(f"   max |pose - {pth}| = {np.abs(res.pose.cpu().numpy() - ref).max():.3e}")
+        else:
+            np.save(pth, res.pose.cpu().numpy())
     print(f"{name}: {ms:.3f} ms per relpose_match_pairs (B={B}, N={N}, {ds}); status {np.bincount(res.status.cpu().numpy(), minlength=7).tolist()}; "
           f"edges/pair mean {2 * c[:, 1].mean():.0f} max {2 * c[:, 1].max()}; matrix-vector products per round mean {it.mean(0).round(1).tolist()} max {it.max(0).tolist()}")
