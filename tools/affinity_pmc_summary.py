@@ -15,7 +15,7 @@ def agg_pass(name):
         return {}
     out = {}
     for (did, kn, st, en), v in sorted(pmc(db).items(), key=lambda kv: kv[0][2]):
-        if "affinity" not in kn:
+        if "affinity" not in kn and "aff3" not in kn:
             continue
         k = short(kn)[:90]
         a = out.setdefault(k, {"n": 0, "us": 0.0})
