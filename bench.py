@@ -43,6 +43,13 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE = 36.14            # SCNet conv+convT MACs x2 per 224x224 sample
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16 / bf16
+MFMA_TERMS = {"bf16x3": 3, "f16x3": 3, "bf16x9": 9, "bf16x6": 6}      # 16-bit MFMA products issued per fp32 product
+DTYPE_EXACT = {
+    "bf16x9": "f32 (exact fp32 products on the bf16 matrix pipe: both operands cut into three bf16 pieces = all 24 significand bits, all nine partial "
+              "products issued as v_mfma_f32_32x32x16_bf16, each exact in the fp32 accumulator; fp32 accumulation, activations, BatchNorm statistics, conv1, heads)",
+    "bf16x6": "f32 (fp32 products on the bf16 matrix pipe: both operands cut into three bf16 pieces = all 24 significand bits, the six partial products "
+              ">= 2^-16 |a b| issued as v_mfma_f32_32x32x16_bf16, the three <= 2^-24 |a b| dropped; fp32 accumulation, activations, BatchNorm statistics, conv1, heads)",
+}
 PEAK_HBM_GBS = 8000.0
 
 # BASELINE.json configs[i] -> concrete single-GPU workload
@@ -77,7 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--h2d-mode", choices=["auto", "slot", "lookahead"], default="auto",
                     help="PCIe-inclusive run: uploads on the batch's slot stream, or on a copy stream one in-flight depth ahead (auto: lookahead whenever >= 2 x inflight batches rotate)")
     ap.add_argument("--no-aux", action="store_true", help="skip the roofline / affinity side measurements (profiling runs)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3", "f16"], default=None,
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x3", "f16", "bf16x9", "bf16x6"], default=None,
                     help="conv arithmetic (default: the config's; f32 = exact fp32 MFMA = the parity configuration)")
     ap.add_argument("--pose-outputs", action="store_true",
                     help="opt-in: SCNet computes only the heads the pose loop reads (normal, depth, features; RELPOSE_FWD_POSE_OUTPUTS) -- "
@@ -371,7 +378,7 @@ def worker(args):
                          f"scan-pairs/sec end-to-end (completion+feat+spectral-match), {h}x{4 * h} RGB-D (BASELINE configs[{args.config}]; the headline metric is quoted at 160x640)",
                "value": total * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-               "dtype": "f32" if f32 else ("f16 (plain fp16 MFMA conv products, fp32 accumulate and fp32 BatchNorm statistics; NOT a parity configuration: on the reference-pinned "
+               "dtype": "f32" if f32 else DTYPE_EXACT[prec] if prec in DTYPE_EXACT else ("f16 (plain fp16 MFMA conv products, fp32 accumulate and fp32 BatchNorm statistics; NOT a parity configuration: on the reference-pinned "
                                           "fixtures the free-running rotation is within 1e-5 of the reference after level 0 but only within 4e-3 after level 2 -- "
                                           "it breaks the 1e-4 bar, tests/test_gpu_e2e.py; f16x3 meets it with 1e-7)"
                                           if prec == "f16" else
@@ -415,7 +422,8 @@ def worker(args):
             flops = GFLOP_PER_IMAGE * 1e9 * 2 * nloc
             ach = flops / (g_ms * 1e-3) / 1e12
             # split-16-bit modes: every fp32 product costs three dense 16-bit MFMA products -> algorithmic peak = 2500 / 3
-            peak = PEAK_F32_MFMA_TFLOPS if f32 else (PEAK_F16_MFMA_TFLOPS if prec == "f16" else PEAK_F16_MFMA_TFLOPS / 3)
+            # bf16x9 / bf16x6 (exact-product emulation): nine / six dense bf16 MFMA products per fp32 product -> 2500 / 9, 2500 / 6
+            peak = PEAK_F32_MFMA_TFLOPS if f32 else (PEAK_F16_MFMA_TFLOPS if prec == "f16" else PEAK_F16_MFMA_TFLOPS / MFMA_TERMS[prec])
             tr = _traffic(f"config{args.config}_{prec}_pairs{nloc}")
             stack16 = ("SCNet conv stack: conv_s2_tile_kernel + conv_s2_strip_kernel + deconv_tile_kernel (SPLIT instantiations) + conv_igemm_kernel (conv6-9, deconv4-9) "
                        "+ conv1_mfma_kernel + heads_kernel (fp32)" if prec != "bf16x3" else "SCNet conv stack: conv_igemm_kernel (every layer) + conv1_mfma_kernel + heads_kernel (fp32)")
@@ -451,7 +459,7 @@ def worker(args):
             alone_ms = ea0.elapsed_time(ea1) / 6
             del xa, xb, fo
             res["roofline"] = {"kernel": "SCNet conv stack: conv_igemm_kernel + conv_s2_tile_kernel + conv_s2_strip_kernel + deconv_tile_kernel + conv1_mfma_kernel + heads_kernel (fp32 MFMA 32x32x2)"
-                                         if f32 else (stack16 + " -- fp16 MFMA 32x32x16" if prec == "f16" else stack16 + f" -- 3 x {prec[:-2]} MFMA 32x32x16 per fp32 product"),
+                                         if f32 else (stack16 + " -- fp16 MFMA 32x32x16" if prec == "f16" else stack16 + f" -- {MFMA_TERMS[prec]} x {prec[:-2]} MFMA 32x32x16 per fp32 product"),
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": tr["bytes"] if tr else None, "traffic_unit": "HBM bytes per forward (all conv launches; rocprofv3 PMC)",
                                "traffic_profile": tr["profile"] if tr else None,

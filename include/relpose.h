@@ -267,8 +267,14 @@ int64_t relpose_scnet_num_params(const RelposeSCNet* net);
  * stay fp32).  RELPOSE_PREC_F16X3 (opt-in): the same with float16 halves (11 + 11 mantissa bits: products exact to
  * ~2^-21 for O(1) operands; float16 range, so inputs must stay below 65504).  RELPOSE_PREC_F16 (opt-in): plain float16 products
  * (the hi halves only, one v_mfma_f32_32x32x16_f16 per product, fp32 accumulation and fp32 BatchNorm statistics: SURVEY 8d
- * config 5's "fp16 MFMA convs"; products exact to 2^-11).  May be switched at any time after finalize. */
-enum { RELPOSE_PREC_F32 = 0, RELPOSE_PREC_BF16X3 = 1, RELPOSE_PREC_F16X3 = 2, RELPOSE_PREC_F16 = 3 };
+ * config 5's "fp16 MFMA convs"; products exact to 2^-11).
+ * RELPOSE_PREC_BF16X9 (round 6): EXACT fp32 products on the bf16 matrix pipe -- every fp32 operand is cut into three bfloat16
+ * pieces (8 + 8 + 8 = 24 significand bits: a = a1 + a2 + a3 exactly, fp32 exponent range), all nine partial products
+ * ai * bj (each exact in the fp32 accumulator) are issued as v_mfma_f32_32x32x16_bf16, smallest first, fp32 accumulation:
+ * the arithmetic of the fp32 MFMA path (exact products, fp32 sums in another order) at 9/16 of its matrix-pipe cycles.
+ * RELPOSE_PREC_BF16X6: the same without the three partial products below 2^-24 |a b| (a2 b3, a3 b2, a3 b3).
+ * May be switched at any time after finalize. */
+enum { RELPOSE_PREC_F32 = 0, RELPOSE_PREC_BF16X3 = 1, RELPOSE_PREC_F16X3 = 2, RELPOSE_PREC_F16 = 3, RELPOSE_PREC_BF16X9 = 4, RELPOSE_PREC_BF16X6 = 5 };
 int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode);
 
 size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n_images, int32_t H, int32_t W);

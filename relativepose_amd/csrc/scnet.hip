@@ -40,6 +40,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int SPLIT> struct SplitT { typedef bf16x8 v8; typedef bf16x4 v4; };
 template <> struct SplitT<2> { typedef f16x8 v8; typedef f16x4 v4; };
 template <> struct SplitT<3> { typedef f16x8 v8; typedef f16x4 v4; };     // plain fp16 products (hi halves only), fp32 accumulate
+// SPLIT 4 / 5 (primary template: bf16): EXACT-product emulation of the fp32 contraction on the bf16 matrix pipe.  Every fp32 operand is
+// cut into three bfloat16 pieces a = a1 + a2 + a3 (8 + 8 + 8 = 24 significand bits: the sum is exact, bf16 has the fp32 exponent range),
+// every partial product ai * bj is exact in the fp32 accumulator (16 significand bits), and a * b = sum of the 9 partial products.
+// SPLIT 4 ("bf16x9") issues all nine v_mfma_f32_32x32x16_bf16 terms, smallest first; SPLIT 5 ("bf16x6") drops a2 b3, a3 b2, a3 b3
+// (<= 2^-24 |a b| each: below the rounding of the fp32 accumulation itself).
 typedef float rp_f4v __attribute__((ext_vector_type(4)));
 
 #ifndef RP_ABLATE
@@ -63,6 +68,9 @@ typedef float rp_f4v __attribute__((ext_vector_type(4)));
 constexpr int BK = RP_BK;       // K-tile (floats): 16 (double-buffered LDS) or 32 (whole 128-B lines per row, single LDS buffer)
 constexpr int LDK = BK + 4;     // LDS row stride in floats (80 / 144 B: 16-B aligned, conflict-free b128 reads)
 constexpr int KQ = BK / 4;      // float4 slots per tile row
+constexpr int LDK3 = 52;        // LDS row stride (floats) of the three-piece bf16 rows [32 hi | 32 mid | 32 lo | pad]: 208 B, an odd multiple of 16 B
+template <int SPLIT> struct RowLd { static constexpr int v = SPLIT >= 4 ? LDK3 : LDK; };
+constexpr bool rp_split3(int split) { return split >= 4; }
 constexpr int NBUF = (BK == 16) ? 2 : 1;
 constexpr float LRELU = 0.1f;
 constexpr double BN_EPS = 1e-5;
@@ -118,6 +126,27 @@ __device__ __forceinline__ float4 rp_bufld4(__amdgpu_buffer_rsrc_t r, int voff, 
     const rp_f32x4g f = (rp_f32x4g)__builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(f[0], f[1], f[2], f[3]);
 }
+typedef float rp_f32x2g __attribute__((__vector_size__(8)));
+__device__ __forceinline__ float2 rp_bufld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const rp_f32x2g f = (rp_f32x2g)__builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(f[0], f[1]);
+}
+
+// the partial products of one 16-channel step of the three-piece modes on ONE accumulator, smallest magnitude first
+template <int SPLIT>
+__device__ __forceinline__ void rp_mma3(floatx16& acc, const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+    if constexpr (SPLIT == 4) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bl, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
 
 // Tile: WM x WN waves (WM*WN = 4), each wave MI x NI MFMA 32x32 blocks.
 // Both tiles are register-staged: the global loads of tile kt+1 (A values, their BatchNorm
@@ -125,8 +154,10 @@ __device__ __forceinline__ float4 rp_bufld4(__amdgpu_buffer_rsrc_t r, int voff, 
 // latency hides under 64 MFMAs; the loader is branch-free (clamped addresses + selects) so hipcc
 // keeps the loads in flight across the MFMA block.
 template <int WM, int WN, int MI, int NI, bool SSLDS, bool UNI = false, int SPLIT = 0>
-__global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI == 1) ? 4 : (SSLDS ? 3 : 2))) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
+__global__ __launch_bounds__(WM * WN * 64, (NI == 4 || SPLIT >= 4) ? 2 : ((WM * WN == 8 || MI == 1) ? 4 : (SSLDS ? 3 : 2))) void conv_igemm_kernel(const ConvDesc* __restrict__ descs, int ninner, int mt_max) {
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    constexpr int LD = RowLd<SPLIT>::v;                 // LDS row stride (floats); three-piece bf16 rows: [32 hi | 32 mid | 32 lo | pad]
+    constexpr bool S3 = SPLIT >= 4;
     // Block order.  ninner == 1: member-major (each member's weights stay L2-resident while it runs).
     // ninner == 4 (the sub-pixel phases of one transposed conv, which gather from the SAME input tile):
     // the 4 phases of a spatial tile run back to back on the SAME XCD (blocks are dealt round-robin to the
@@ -146,8 +177,8 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
     constexpr int A_IT = BM / RPI;                      // float4 slots per thread for the A tile
     constexpr int B_IT = (BN + RPI - 1) / RPI;
     constexpr int SS_CAP = (WN == 2) ? 2048 : 512;      // float2 entries of the LDS scale/shift table (16 / 4 KB: still 3 blocks per CU)
-    __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDK];
+    __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LD];
     __shared__ __attribute__((aligned(16))) float sstab[SSLDS ? 2 * SS_CAP : 8];   // per 4 channels: 4 scales, then 4 shifts
     __shared__ __attribute__((aligned(16))) int rowpix[BM];
     __shared__ signed char rowslot[BM];        // BatchNorm group of the row relative to the tile's first group
@@ -221,12 +252,13 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int row = min(lrow + it * RPI, BN - 1);
-        b_src[it] = d.w + (size_t)(n0 + row) * d.K + kq * 4;
+        b_src[it] = d.w + (size_t)(n0 + row) * d.K * (S3 ? 3 : 2) / 2 + kq * 4;      // (S3: 6 bytes per weight; the row's lo piece at + 32 - 2 kq)
     }
 
     int r_base[A_IT], r_mg[UNI ? (A_IT + 1) / 2 : A_IT];     // UNI: no group field, two 16-bit tap masks per register
     float4 ra[A_IT], q0[SSLDS ? 1 : A_IT], q1[SSLDS ? 1 : A_IT];
     float4 rb[B_IT];
+    float2 rbl[S3 ? B_IT : 1];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     static_assert(B_IT <= 8 && (B_IT <= 2 || BN % RPI == 0), "B loader layout");
@@ -276,8 +308,11 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
             const float* q = reinterpret_cast<const float*>(sss_ + (size_t)g0 * sst_ + cc_);                      \
             qu0 = rp_ldg4(q); qu1 = rp_ldg4(q + 4);                                                               \
         }                                                                                                         \
-        const int kof_ = tap * d.Cin + c0;                                                                        \
-        _Pragma("unroll") for (int it = 0; it < B_IT; ++it) rb[it] = rp_ldg4(b_src[it] + kof_);                    \
+        const int kof_ = (tap * d.Cin + c0) * (S3 ? 3 : 2) / 2;                                                   \
+        _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                                     \
+            rb[it] = rp_ldg4(b_src[it] + kof_);                                                                   \
+            if (S3) { const float2 l_ = rp_ldg2(b_src[it] + kof_ + 32 - kq * 2); rbl[S3 ? it : 0] = l_; }          \
+        }                                                                                                         \
         if (d.tap_inner) { ++tap; if (tap == d.ntaps) { tap = 0; c0 += BK; } }                                    \
         else { c0 += BK; if (c0 == d.Cin) { c0 = 0; ++tap; } }                                                    \
     }
@@ -310,20 +345,27 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
             const rp_v2f mk_ = {okf_, okf_};                                                                      \
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                       \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                       \
-            if (!SPLIT) *reinterpret_cast<float4*>(&As[BUF][(lrow + it * RPI) * LDK + kq * 4]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
-            else {   /* row = [32 x 16-bit hi | 32 x 16-bit lo]: v = hi + lo to 2^-16 (bf16) / ~2^-22 (f16) */    \
+            if (!SPLIT) *reinterpret_cast<float4*>(&As[BUF][(lrow + it * RPI) * LD + kq * 4]) = make_float4(v01.x, v01.y, v23.x, v23.y); \
+            else {   /* row = [32 x 16-bit hi | 32 x 16-bit lo]: v = hi + lo to 2^-16 (bf16) / ~2^-22 (f16); S3: [hi | mid | lo], exact */ \
                 typedef typename SplitT<SPLIT>::v4 h4_;                                                           \
                 const rp_f4v vf_ = {v01.x, v01.y, v23.x, v23.y};                                                  \
                 const h4_ hi_ = __builtin_convertvector(vf_, h4_);                                                \
-                const h4_ lo_ = __builtin_convertvector(vf_ - __builtin_convertvector(hi_, rp_f4v), h4_);         \
-                h4_* ar_ = reinterpret_cast<h4_*>(&As[BUF][(lrow + it * RPI) * LDK]);                             \
+                const rp_f4v r1_ = vf_ - __builtin_convertvector(hi_, rp_f4v);                                    \
+                const h4_ lo_ = __builtin_convertvector(r1_, h4_);                                                \
+                h4_* ar_ = reinterpret_cast<h4_*>(&As[BUF][(lrow + it * RPI) * LD]);                              \
                 ar_[kq] = hi_;                                                                                    \
                 if (SPLIT != 3) ar_[8 + kq] = lo_;                                                                \
+                if (S3) ar_[16 + kq] = __builtin_convertvector(r1_ - __builtin_convertvector(lo_, rp_f4v), h4_);  \
             }                                                                                                     \
         }                                                                                                         \
-        if (BN >= RPI || lrow < BN) *reinterpret_cast<float4*>(&Bs[BUF][lrow * LDK + kq * 4]) = rb[0];            \
-        _Pragma("unroll") for (int it = 1; it < B_IT; ++it)                                                       \
-            *reinterpret_cast<float4*>(&Bs[BUF][(lrow + it * RPI) * LDK + kq * 4]) = rb[it];                        \
+        if (BN >= RPI || lrow < BN) {                                                                             \
+            *reinterpret_cast<float4*>(&Bs[BUF][lrow * LD + kq * 4]) = rb[0];                                     \
+            if (S3) *reinterpret_cast<float2*>(&Bs[BUF][lrow * LD + 32 + kq * 2]) = rbl[0];                       \
+        }                                                                                                         \
+        _Pragma("unroll") for (int it = 1; it < B_IT; ++it) {                                                     \
+            *reinterpret_cast<float4*>(&Bs[BUF][(lrow + it * RPI) * LD + kq * 4]) = rb[it];                       \
+            if (S3) *reinterpret_cast<float2*>(&Bs[BUF][(lrow + it * RPI) * LD + 32 + kq * 2]) = rbl[S3 ? it : 0]; \
+        }                                                                                                         \
     }
 
     // UNI (chosen by the host when the rows of a BatchNorm group are a multiple of BM, i.e. no tile of the
@@ -333,14 +375,36 @@ __global__ __launch_bounds__(WM * WN * 64, NI == 4 ? 2 : ((WM * WN == 8 || MI ==
     __syncthreads();       // every thread has its rtab rows in registers: the A buffer may be overwritten
     RP_STORE_TILE(0)
     __syncthreads();
-    const int arow = (wm * MI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
-    const int brow = (wn * NI * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const int arow = (wm * MI * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
+    const int brow = (wn * NI * 32 + (lane & 31)) * LD + (lane >> 5) * 4;
     for (int kt = kt_begin; kt < nkt; ++kt) {
         const int buf = (NBUF == 2) ? ((kt - kt_begin) & 1) : 0;
 #if RP_ABLATE != 2 && RP_ABLATE != 5
         if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
 #endif
-        if constexpr (SPLIT != 0) {
+        if constexpr (SPLIT >= 4) {
+            // exact-product emulation: nine (six) bf16 MFMA terms per 16-channel step, smallest first
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LD + st * 8]);
+                    am[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LD + 16 + st * 8]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LD + 32 + st * 8]);
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LD + st * 8]);
+                    bm[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LD + 16 + st * 8]);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LD + 32 + st * 8]);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) rp_mma3<SPLIT>(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
+            }
+        } else if constexpr (SPLIT != 0) {
             // x3 split: a*b ~= hi*hi + hi*lo + lo*hi on the 16-bit MFMA (fp32 accumulate), 2 steps of 16 k per tile
             typedef typename SplitT<SPLIT>::v8 h8;
 #pragma unroll
@@ -559,7 +623,12 @@ __device__ __forceinline__ void rp_tile_store_a(float* row, int kq, rp_v2f v01, 
         const h4_ hi_ = __builtin_convertvector(vf_, h4_);
         h4_* ar_ = reinterpret_cast<h4_*>(row);
         ar_[kq] = hi_;
-        if (SPLIT != 3) ar_[8 + kq] = __builtin_convertvector(vf_ - __builtin_convertvector(hi_, rp_f4v), h4_);
+        if constexpr (SPLIT >= 4) {       // three bf16 pieces: both remainders are exact fp32 differences, the third piece is exact
+            const rp_f4v r1_ = vf_ - __builtin_convertvector(hi_, rp_f4v);
+            const h4_ mid_ = __builtin_convertvector(r1_, h4_);
+            ar_[8 + kq] = mid_;
+            ar_[16 + kq] = __builtin_convertvector(r1_ - __builtin_convertvector(mid_, rp_f4v), h4_);
+        } else if (SPLIT != 3) ar_[8 + kq] = __builtin_convertvector(vf_ - __builtin_convertvector(hi_, rp_f4v), h4_);
     }
 }
 // one 32-channel chunk of one tap for MI x NI accumulators: a_rows[i] / b_rows[j] are LDS float indices of the lane's fragment rows
@@ -582,6 +651,27 @@ __device__ __forceinline__ void rp_tile_mma(floatx16 (&acc)[MI][NI], const float
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
+        }
+    } else if constexpr (SPLIT >= 4) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(&At[a_rows[i] + st * 8]);
+                am[i] = *reinterpret_cast<const bf16x8*>(&At[a_rows[i] + 16 + st * 8]);
+                al[i] = *reinterpret_cast<const bf16x8*>(&At[a_rows[i] + 32 + st * 8]);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_rows[j] + st * 8]);
+                bm[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_rows[j] + 16 + st * 8]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_rows[j] + 32 + st * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) rp_mma3<SPLIT>(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
         }
     } else {
         typedef typename SplitT<SPLIT>::v8 h8;
@@ -636,10 +726,13 @@ __device__ __forceinline__ void rp_tile_mma(floatx16 (&acc)[MI][NI], const float
 #define RP_DT_SPLIT_OCC 2
 #endif
 // (16-bit modes of the paired 8 x 8 variant -- deconv3 -- spill 44 registers at the 168 of 3 workgroups per CU: 2 per CU there, -9 %)
-#define RP_DT_OCC(MI_, NI_, NW_, SP_, PAIR_) ((MI_) * (NI_) == 1 ? ((NW_) == 4 ? (((SP_) && (PAIR_)) ? RP_DT_SPLIT_OCC : 3) : 2) : 2)
+#define RP_DT_OCC(MI_, NI_, NW_, SP_, PAIR_) ((SP_) >= 4 ? 2 : ((MI_) * (NI_) == 1 ? ((NW_) == 4 ? (((SP_) && (PAIR_)) ? RP_DT_SPLIT_OCC : 3) : 2) : 2))   /* three-piece rows: 68 KB of LDS */
 template <int MI, int NI, int NW, int TC, bool PAIR = false, int SPLIT = 0>
 __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void deconv_tile_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int NT = NW * 64, TR = 32 / TC;
+    constexpr int LD = RowLd<SPLIT>::v;                               // LDS row stride (floats)
+    constexpr bool S3 = SPLIT >= 4;                                   // three-piece bf16 operands: 6 bytes per weight, rows [hi | mid | lo]
+    constexpr int WB = S3 ? 6 : 4;
     constexpr int PR = PAIR ? 8 : (TC == 16 ? TR * MI * NW : TR), PW = PAIR ? 8 : (TC == 16 ? 16 : TC * NW), HW2 = PW + 2;
     constexpr int SUBPIX = (PR + 2) * HW2, NPIX = (PAIR ? 2 : 1) * SUBPIX;
     static_assert(TC == 16 || MI == 1, "strip layout: one tile per wave");
@@ -649,8 +742,8 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
     constexpr int B_ROWS = 4 * NI * 32;                               // rows [tap][col] of a phase's weight tiles
     constexpr int B_SLOTS = (B_ROWS + PSTEP - 1) / PSTEP;
     static_assert(BK == 32, "one 128-byte line per pixel and chunk");
-    __shared__ __attribute__((aligned(16))) float At[NPIX * LDK];
-    __shared__ __attribute__((aligned(16))) float Bt[4 * NI * 32 * LDK];
+    __shared__ __attribute__((aligned(16))) float At[NPIX * LD];
+    __shared__ __attribute__((aligned(16))) float Bt[4 * NI * 32 * LD];
     __shared__ __attribute__((aligned(16))) float sstab[2 * 512];   // per 4 channels: 4 scales, then 4 shifts
     const ConvDesc* dh = descs + blockIdx.y * 4;
     const ConvDesc d = dh[0];
@@ -674,9 +767,9 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
         sstab[(c & ~3) * 2 + (c & 3)] = e.x; sstab[(c & ~3) * 2 + 4 + (c & 3)] = e.y;
     }
     // halo slots of this thread: pixel offset in the image (or -1: zero padding) and LDS position
-    // slot it of this thread = halo pixel tid / 8 + PSTEP it, chunk column kqa (NT % KQ == 0); LDS position = a_lds0 + it * PSTEP * LDK
+    // slot it of this thread = halo pixel tid / 8 + PSTEP it, chunk column kqa (NT % KQ == 0); LDS position = a_lds0 + it * PSTEP * LD
     const int kqa = tid % KQ;
-    const int a_lds0 = (tid / KQ) * LDK + kqa * 4;
+    const int a_lds0 = (tid / KQ) * LD + kqa * 4;
     // Buffer loads (SGPR descriptor + 32-bit lane offset + SGPR chunk offset): one index register per slot instead of a 64-bit
     // address pair -- with 128 accumulator and 44 + 16 prefetch registers the flat-address version spilled.
     int a_px[A_SLOTS];                                                // pixel index inside the image, or -1 (zero padding)
@@ -697,16 +790,16 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
                                                                                        a_bytes * d.src[1].cstride, 0x00020000) : rs_a0;
     __amdgpu_buffer_rsrc_t rs_b[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) rs_b[p] = __builtin_amdgcn_make_buffer_rsrc((void*)dh[p].w, 0, d.cout_pad * d.K * 4, 0x00020000);
-    // weight slot it: row r = tid / 8 + PSTEP it of [tap][col] (r = tap * NI * 32 + col), chunk column kqa; LDS position r * LDK + kqa * 4
+    for (int p = 0; p < 4; ++p) rs_b[p] = __builtin_amdgcn_make_buffer_rsrc((void*)dh[p].w, 0, d.cout_pad * d.K * WB, 0x00020000);
+    // weight slot it: row r = tid / 8 + PSTEP it of [tap][col] (r = tap * NI * 32 + col), chunk column kqa; LDS position r * LD + kqa * 4
     int b_off[B_SLOTS];                                               // byte offset of the row in the phase's weights (chunk 0), or -1
 #pragma unroll
     for (int it = 0; it < B_SLOTS; ++it) {
         const int r = tid / KQ + it * PSTEP;
         const int tap = r / (NI * 32), col = r - tap * (NI * 32);
-        b_off[it] = r < B_ROWS ? ((n0 + col) * d.K + tap * d.Cin + kqa * 4) * 4 : -1;
+        b_off[it] = r < B_ROWS ? ((n0 + col) * d.K + tap * d.Cin) * WB + kqa * 16 : -1;     // (S3: the row's lo piece at + 128 - 8 kqa)
     }
-    const int b_lds0 = (tid / KQ) * LDK + kqa * 4;
+    const int b_lds0 = (tid / KQ) * LD + kqa * 4;
     floatx16 acc[4][MI][NI];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
@@ -721,15 +814,16 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
     const int wsp = PAIR ? (wave >> 1) : 0;                           // sub-patch of this wave
     int arow[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) arow[i] = (wsp * SUBPIX + (try0 + TR * i + l31 / TC + 1) * HW2 + tcx0 + (l31 % TC) + 1) * LDK + h * 4;
-    const int brow = l31 * LDK + h * 4;
+    for (int i = 0; i < MI; ++i) arow[i] = (wsp * SUBPIX + (try0 + TR * i + l31 / TC + 1) * HW2 + tcx0 + (l31 % TC) + 1) * LD + h * 4;
+    const int brow = l31 * LD + h * 4;
     const float slope = d.src[0].slope;
     int aoffs[4][4];                                                  // block-uniform: LDS offset of (phase, tap) relative to the output pixel
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) aoffs[p][t] = ((int)dh[p].offy[t] * HW2 + (int)dh[p].offx[t]) * LDK;
+        for (int t = 0; t < 4; ++t) aoffs[p][t] = ((int)dh[p].offy[t] * HW2 + (int)dh[p].offx[t]) * LD;
     float4 ra[A_SLOTS], rb[B_SLOTS];
+    float2 rbl[S3 ? B_SLOTS : 1];                                     // (S3) the lo pieces of the weight rows
     const int nchunk = d.Cin / BK;
     // chunk order: the skip source's channels (src[1]) first, then src[0]'s -- the k-th chunk processed starts at channel c0_of(k)
     const int nch0 = d.src[0].C / BK, nch1 = nchunk - nch0;
@@ -799,29 +893,26 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
             if ((it + 1) * PSTEP <= NPIX || tid / KQ + it * PSTEP < NPIX)                                     \
-                rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LDK], kqa, v01, v23);              \
+                rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LD], kqa, v01, v23);              \
         }                                                                                                     \
     }
-#define RP_DT_LOAD_B(P, C0)                                                                                    \
-    {                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
-            rb[it] = rp_bufld4(rs_b[P], max(b_off[it], 0), (C0) * 4);                                          \
-    }
-#define RP_DT_STORE_B()                                                                                        \
-    {                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
-            if ((it + 1) * PSTEP <= B_ROWS || b_off[it] >= 0) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = rb[it]; \
-    }
+#define RP_DT_LOAD_B(P, C0) RP_DT_LOAD_B2(rb, rbl, P, C0)
+#define RP_DT_STORE_B() RP_DT_STORE_B2(rb, rbl)
 
-#define RP_DT_LOAD_B2(RB, P, C0)                                                                               \
+#define RP_DT_LOAD_B2(RB, RBL, P, C0)                                                                          \
     {                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
-            RB[it] = rp_bufld4(rs_b[P], max(b_off[it], 0), (C0) * 4);                                          \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) {                                              \
+            RB[it] = rp_bufld4(rs_b[P], max(b_off[it], 0), (C0) * WB);                                         \
+            if (S3) RBL[S3 ? it : 0] = rp_bufld2(rs_b[P], max(b_off[it], 0) + 128 - kqa * 8, (C0) * WB);       \
+        }                                                                                                     \
     }
-#define RP_DT_STORE_B2(RB)                                                                                     \
+#define RP_DT_STORE_B2(RB, RBL)                                                                                \
     {                                                                                                         \
         _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it)                                                \
-            if ((it + 1) * PSTEP <= B_ROWS || b_off[it] >= 0) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = RB[it]; \
+            if ((it + 1) * PSTEP <= B_ROWS || b_off[it] >= 0) {                                               \
+                *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LD]) = RB[it];                           \
+                if (S3) *reinterpret_cast<float2*>(&Bt[b_lds0 + 32 - kqa * 2 + it * PSTEP * LD]) = RBL[S3 ? it : 0]; \
+            }                                                                                                 \
     }
     if constexpr (SPLIT != 0 && PAIR) {       // (deconv3's variant, which has the registers for it at 2 workgroups per CU; <1, 1> 8 x 16: no gain,
                                               // <1, 2>: two weight sets + 128 accumulators spill, 896 -> 1415 us)
@@ -829,13 +920,14 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
         // deeper: the weights of phase q + 2 are requested at the top of phase q (two register sets, alternating by phase parity) and
         // the next chunk's halo tile at the top of phase 1 (fp32: one phase ahead for both)
         float4 rb2[B_SLOTS];
+        float2 rbl2[S3 ? B_SLOTS : 1];
         if (snap_mode == 2) snap_load();
         RP_DT_LOAD_A(c0_of(k_first))
-        RP_DT_LOAD_B2(rb, 0, c0_of(k_first))
-        RP_DT_LOAD_B2(rb2, 1, c0_of(k_first))
+        RP_DT_LOAD_B2(rb, rbl, 0, c0_of(k_first))
+        RP_DT_LOAD_B2(rb2, rbl2, 1, c0_of(k_first))
         __syncthreads();                                              // sstab
         RP_DT_STORE_A(c0_of(k_first))
-        RP_DT_STORE_B2(rb)
+        RP_DT_STORE_B2(rb, rbl)
         __syncthreads();
         for (int ch = k_first; ch < nchunk; ++ch) {
             const int c0 = c0_of(ch), c0n = c0_of(ch + 1 < nchunk ? ch + 1 : ch);
@@ -843,8 +935,8 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 // the set that was stored to LDS for THIS phase is free: phase p + 2's weights go there
-                if (p < 2) { if (p == 0) RP_DT_LOAD_B2(rb, 2, c0) else RP_DT_LOAD_B2(rb2, 3, c0) }
-                else if (!last) { if (p == 2) RP_DT_LOAD_B2(rb, 0, c0n) else RP_DT_LOAD_B2(rb2, 1, c0n) }
+                if (p < 2) { if (p == 0) RP_DT_LOAD_B2(rb, rbl, 2, c0) else RP_DT_LOAD_B2(rb2, rbl2, 3, c0) }
+                else if (!last) { if (p == 2) RP_DT_LOAD_B2(rb, rbl, 0, c0n) else RP_DT_LOAD_B2(rb2, rbl2, 1, c0n) }
                 if (p == 1 && !last) RP_DT_LOAD_A(c0n)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -853,11 +945,11 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
 #pragma unroll
                     for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LDK;
+                    for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LD;
                     rp_tile_mma<SPLIT, MI, NI>(acc[p], At, ar_, Bt, br_);
                 }
                 __syncthreads();                                      // every wave is done with this phase's weights (and, p == 3, the halo tile)
-                if (p < 3 || !last) { if (p & 1) RP_DT_STORE_B2(rb) else RP_DT_STORE_B2(rb2) }      // phase p + 1's weights
+                if (p < 3 || !last) { if (p & 1) RP_DT_STORE_B2(rb, rbl) else RP_DT_STORE_B2(rb2, rbl2) }      // phase p + 1's weights
                 if (p == 3 && !last) RP_DT_STORE_A(c0n)
                 __syncthreads();
             }
@@ -886,7 +978,7 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
 #pragma unroll
                     for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LDK;
+                    for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LD;
                     rp_tile_mma<SPLIT, MI, NI>(acc[p], At, ar_, Bt, br_);
                 }
                 __syncthreads();                                          // every wave is done with this phase's weights (and, p == 3, the halo tile)
@@ -963,8 +1055,11 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
 // of every one of the 16 taps: 3.3-3.5x the global loads and transforms).  The weight tile of one tap is staged per k-step as before.
 // Geometry as in deconv_tile_kernel: TC == 16: patch 2 MI NW x 16 outputs, tiles stacked; PAIR: two 8 x 8 patches (56-wide grids).
 template <int MI, int NI, int TC, bool PAIR, int SPLIT = 0>
-__global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel(const ConvDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256, SPLIT >= 4 ? 2 : (MI * NI <= 2 ? 4 : 3)) void conv_s2_tile_kernel(const ConvDesc* __restrict__ descs) {
     constexpr int NW = 4, NT = 256, TR = 32 / TC;
+    constexpr int LD = RowLd<SPLIT>::v;                               // LDS row stride (floats)
+    constexpr bool S3 = SPLIT >= 4;                                   // three-piece bf16 operands: 6 bytes per weight, rows [hi | mid | lo]
+    constexpr int WB = S3 ? 6 : 4;
     constexpr int PR = PAIR ? 8 : TR * MI * NW, PW = PAIR ? 8 : 16, HW1 = PW + 1;
     constexpr int SUBPIX = (PR + 1) * HW1, NPIX = (PAIR ? 2 : 1) * SUBPIX;
     static_assert(!PAIR || (TC == 8 && MI == 1), "paired 8 x 8 patches: 4 waves of one 4 x 8 tile");
@@ -973,8 +1068,8 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
     constexpr int B_ROWS = NI * 32;
     constexpr int B_SLOTS = (B_ROWS + PSTEP - 1) / PSTEP;
     static_assert(BK == 32 && B_ROWS % PSTEP == 0, "weight tile layout");
-    __shared__ __attribute__((aligned(16))) float At[NPIX * LDK];
-    __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LDK];
+    __shared__ __attribute__((aligned(16))) float At[NPIX * LD];
+    __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LD];
     __shared__ __attribute__((aligned(16))) float sstab[2 * 128];
     const ConvDesc d = descs[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
@@ -994,7 +1089,7 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
         sstab[(c & ~3) * 2 + (c & 3)] = e.x; sstab[(c & ~3) * 2 + 4 + (c & 3)] = e.y;
     }
     const int kqa = tid % KQ;
-    const int a_lds0 = (tid / KQ) * LDK + kqa * 4;
+    const int a_lds0 = (tid / KQ) * LD + kqa * 4;
     // halo slot it = plane-tile pixel tid / 8 + PSTEP it: input pixel (2 (Y0 + r) - p, 2 (X0 + c) - q) of plane (p, q); a_in[it] is the
     // (p, q) = (0, 0) pixel index relative to image img_base, a_edge[it] flags the slots that leave the image for p = 1 / p = 0 / q = 1 / q = 0
     int a_in[A_SLOTS], a_edge = 0;
@@ -1023,11 +1118,11 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(d.src[0].x + img_px * d.src[0].cstride), 0,
                                                                          (PAIR ? 2 : 1) * d.Hin * d.Win * 4 * d.src[0].cstride, 0x00020000);
     const int n0 = blockIdx.z * NI * 32;
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.cout_pad * d.K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.cout_pad * d.K * WB, 0x00020000);
     int b_off[B_SLOTS];
 #pragma unroll
-    for (int it = 0; it < B_SLOTS; ++it) b_off[it] = ((n0 + tid / KQ + it * PSTEP) * d.K + kqa * 4) * 4;
-    const int b_lds0 = (tid / KQ) * LDK + kqa * 4;
+    for (int it = 0; it < B_SLOTS; ++it) b_off[it] = (n0 + tid / KQ + it * PSTEP) * d.K * WB + kqa * 16;
+    const int b_lds0 = (tid / KQ) * LD + kqa * 4;
     floatx16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -1039,11 +1134,12 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
     const int wsp = PAIR ? (wave >> 1) : 0;
     int arow[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) arow[i] = (wsp * SUBPIX + (try0 + TR * i + l31 / TC) * HW1 + (l31 % TC)) * LDK + h * 4;
-    const int brow = l31 * LDK + h * 4;
+    for (int i = 0; i < MI; ++i) arow[i] = (wsp * SUBPIX + (try0 + TR * i + l31 / TC) * HW1 + (l31 % TC)) * LD + h * 4;
+    const int brow = l31 * LD + h * 4;
     const float slope = d.src[0].slope;
     const int scs4 = d.src[0].cstride * 4;
     float4 ra[A_SLOTS], rb[B_SLOTS];
+    float2 rbl[S3 ? B_SLOTS : 1];                                     // (S3) the lo pieces of the weight rows
     const int nchunk = d.Cin / BK;
     const int nstep = nchunk * 16;                                    // (chunk, plane, tap) steps: s = (chunk * 4 + plane) * 4 + tap
 
@@ -1078,19 +1174,25 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
             if ((it + 1) * PSTEP <= NPIX || tid / KQ + it * PSTEP < NPIX)                                     \
-                rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LDK], kqa, v01, v23);              \
+                rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LD], kqa, v01, v23);              \
         }                                                                                                     \
     }
 #define RP_S2_LOAD_B(S)                                                                                        \
     {                                                                                                         \
         const int ch_ = (S) >> 4, pl_ = ((S) >> 2) & 3, tt_ = (S) & 3;                                        \
         const int ky_ = (pl_ >> 1) ? 2 * (tt_ >> 1) : 1 + 2 * (tt_ >> 1), kx_ = (pl_ & 1) ? 2 * (tt_ & 1) : 1 + 2 * (tt_ & 1); \
-        const int so_ = ((ky_ * 4 + kx_) * d.Cin + ch_ * BK) * 4;                                             \
-        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) rb[it] = rp_bufld4(rs_b, b_off[it], so_);       \
+        const int so_ = ((ky_ * 4 + kx_) * d.Cin + ch_ * BK) * WB;                                            \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) {                                              \
+            rb[it] = rp_bufld4(rs_b, b_off[it], so_);                                                         \
+            if (S3) rbl[S3 ? it : 0] = rp_bufld2(rs_b, b_off[it] + 128 - kqa * 8, so_);                        \
+        }                                                                                                     \
     }
 #define RP_S2_STORE_B()                                                                                        \
     {                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = rb[it]; \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) {                                              \
+            *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LD]) = rb[it];                               \
+            if (S3) *reinterpret_cast<float2*>(&Bt[b_lds0 + 32 - kqa * 2 + it * PSTEP * LD]) = rbl[S3 ? it : 0]; \
+        }                                                                                                     \
     }
 
     RP_S2_LOAD_A(0, 0)
@@ -1107,13 +1209,13 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
             const int sidx = cp * 4 + tt;
             if (sidx + 1 < nstep) RP_S2_LOAD_B(sidx + 1)
             if (tt == 0 && !lastp) RP_S2_LOAD_A((cp + 1) >> 2, (cp + 1) & 3)
-            const int aoff = ((tt >> 1) * HW1 + (tt & 1)) * LDK;
+            const int aoff = ((tt >> 1) * HW1 + (tt & 1)) * LD;
             {
                 int ar_[MI], br_[NI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) br_[j] = brow + j * 32 * LDK;
+                for (int j = 0; j < NI; ++j) br_[j] = brow + j * 32 * LD;
                 rp_tile_mma<SPLIT, MI, NI>(acc, At, ar_, Bt, br_);
             }
             __syncthreads();
@@ -1182,11 +1284,14 @@ __global__ __launch_bounds__(256, MI * NI <= 2 ? 4 : 3) void conv_s2_tile_kernel
 // groups in registers, selected per staged position).  Used for split-K layers only: the epilogue writes partial sums
 // [ks][M][cout_pad], reduced (and BatchNorm statistics taken) by the existing kernels.
 template <int NI, int SPLIT = 0>
-__global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256, SPLIT >= 4 ? 2 : 3) void conv_s2_strip_kernel(const ConvDesc* __restrict__ descs) {
+    constexpr int LD = RowLd<SPLIT>::v;                               // LDS row stride (floats)
+    constexpr bool S3 = SPLIT >= 4;                                   // three-piece bf16 operands: 6 bytes per weight, rows [hi | mid | lo]
+    constexpr int WB = S3 ? 6 : 4;
     constexpr int BM = 128, SMAX = 224, PSTEP = 256 / KQ, A_SLOTS = SMAX / PSTEP, B_ROWS = NI * 32, B_SLOTS = B_ROWS / PSTEP;
     static_assert(BK == 32 && SMAX % PSTEP == 0 && B_ROWS % PSTEP == 0, "slot layout");
-    __shared__ __attribute__((aligned(16))) float At[SMAX * LDK];
-    __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LDK];
+    __shared__ __attribute__((aligned(16))) float At[SMAX * LD];
+    __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LD];
     const ConvDesc d = descs[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ks = blockIdx.y / d.ntiles_n, n0 = (blockIdx.y - ks * d.ntiles_n) * NI * 32;
@@ -1198,7 +1303,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
     const int nvalid = pos_of(min(m0 + BM, d.M) - 1) + W1 + 2 - pmin;          // staged positions (host guarantees <= SMAX)
     const int g0 = (m0 / hw) >> 1;                                             // first BatchNorm group of the tile; rsrc starts at image 2 g0
     const int kqa = tid % KQ;
-    const int a_lds0 = (tid / KQ) * LDK + kqa * 4;
+    const int a_lds0 = (tid / KQ) * LD + kqa * 4;
     // slot it = position pmin + tid / 8 + PSTEP it: input pixel index of plane (0, 0) relative to image 2 g0, edge bits (as in
     // conv_s2_tile_kernel) and the BatchNorm group (0 / 1 relative to g0), packed: a_in[it] = index, bits in a_edge (4 per slot) / a_grp
     int a_in[A_SLOTS], a_edge = 0, a_grp = 0;
@@ -1219,29 +1324,30 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
     const int nimg_left = min(4, d.Nimg - 2 * g0);
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(d.src[0].x + base_px * d.src[0].cstride), 0,
                                                                          nimg_left * d.Hin * d.Win * 4 * d.src[0].cstride, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.cout_pad * d.K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.cout_pad * d.K * WB, 0x00020000);
     // scale / shift of the two groups the tile can touch (clamped to the last group)
     const int ng = d.Nimg / 2;
     const float* ss0 = reinterpret_cast<const float*>(d.src[0].ss + (size_t)g0 * d.src[0].sstride) + kqa * 8;
     const float* ss1 = reinterpret_cast<const float*>(d.src[0].ss + (size_t)min(g0 + 1, ng - 1) * d.src[0].sstride) + kqa * 8;
     int b_off[B_SLOTS];
 #pragma unroll
-    for (int it = 0; it < B_SLOTS; ++it) b_off[it] = ((n0 + tid / KQ + it * PSTEP) * d.K + kqa * 4) * 4;
-    const int b_lds0 = (tid / KQ) * LDK + kqa * 4;
+    for (int it = 0; it < B_SLOTS; ++it) b_off[it] = (n0 + tid / KQ + it * PSTEP) * d.K * WB + kqa * 16;
+    const int b_lds0 = (tid / KQ) * LD + kqa * 4;
     floatx16 acc[1][NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
     const int mrow = min(m0 + 32 * wave + l31, d.M - 1);                        // this lane's MFMA row (rows past M are never stored)
-    const int arow = (pos_of(mrow) - pmin) * LDK + h * 4;
-    const int brow = l31 * LDK + h * 4;
+    const int arow = (pos_of(mrow) - pmin) * LD + h * 4;
+    const int brow = l31 * LD + h * 4;
     const float slope = d.src[0].slope;
     const int scs4 = d.src[0].cstride * 4;
     const int nchunk = d.Cin / BK;
     const int cpk = (nchunk + d.ksplit - 1) / d.ksplit;
     const int ch_begin = ks * cpk, ch_end = min(nchunk, ch_begin + cpk);
     float4 ra[A_SLOTS], rb[B_SLOTS];
+    float2 rbl[S3 ? B_SLOTS : 1];                                              // (S3) the lo pieces of the weight rows
     float4 sc0a, sc0b, sc1a, sc1b;                                             // {scale, shift} pairs of the thread's 4 channels, groups g0 / g0 + 1
 
 #define RP_ST_LOAD_SS(CH)                                                                                       \
@@ -1276,19 +1382,25 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
             const rp_v2f mk_ = {okf_, okf_};                                                                  \
             v01 = (rp_v2f){fmaxf(v01.x, t01.x), fmaxf(v01.y, t01.y)} * mk_;                                   \
             v23 = (rp_v2f){fmaxf(v23.x, t23.x), fmaxf(v23.y, t23.y)} * mk_;                                   \
-            rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LDK], kqa, v01, v23);                  \
+            rp_tile_store_a<SPLIT>(&At[a_lds0 - kqa * 4 + it * PSTEP * LD], kqa, v01, v23);                  \
         }                                                                                                     \
     }
 #define RP_ST_LOAD_B(S)                                                                                        \
     {                                                                                                         \
         const int ch_ = (S) >> 4, pl_ = ((S) >> 2) & 3, tt_ = (S) & 3;                                        \
         const int ky_ = (pl_ >> 1) ? 2 * (tt_ >> 1) : 1 + 2 * (tt_ >> 1), kx_ = (pl_ & 1) ? 2 * (tt_ & 1) : 1 + 2 * (tt_ & 1); \
-        const int so_ = ((ky_ * 4 + kx_) * d.Cin + ch_ * BK) * 4;                                             \
-        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) rb[it] = rp_bufld4(rs_b, b_off[it], so_);       \
+        const int so_ = ((ky_ * 4 + kx_) * d.Cin + ch_ * BK) * WB;                                            \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) {                                              \
+            rb[it] = rp_bufld4(rs_b, b_off[it], so_);                                                         \
+            if (S3) rbl[S3 ? it : 0] = rp_bufld2(rs_b, b_off[it] + 128 - kqa * 8, so_);                        \
+        }                                                                                                     \
     }
 #define RP_ST_STORE_B()                                                                                        \
     {                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LDK]) = rb[it]; \
+        _Pragma("unroll") for (int it = 0; it < B_SLOTS; ++it) {                                              \
+            *reinterpret_cast<float4*>(&Bt[b_lds0 + it * PSTEP * LD]) = rb[it];                               \
+            if (S3) *reinterpret_cast<float2*>(&Bt[b_lds0 + 32 - kqa * 2 + it * PSTEP * LD]) = rbl[S3 ? it : 0]; \
+        }                                                                                                     \
     }
 
     if (ch_begin < ch_end) {
@@ -1311,12 +1423,12 @@ __global__ __launch_bounds__(256, 3) void conv_s2_strip_kernel(const ConvDesc* _
                     // can be fetched straight into the registers (consumed when its plane 0 is stored, 4 taps from now)
                     if (((cp + 1) & 3) == 0) RP_ST_LOAD_SS((cp + 1) >> 2)
                 }
-                const int aoff = ((tt >> 1) * W1 + (tt & 1)) * LDK;
+                const int aoff = ((tt >> 1) * W1 + (tt & 1)) * LD;
                 {
                     const int ar_[1] = {arow + aoff};
                     int br_[NI];
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) br_[j] = brow + j * 32 * LDK;
+                    for (int j = 0; j < NI; ++j) br_[j] = brow + j * 32 * LD;
                     rp_tile_mma<SPLIT, 1, NI>(acc, At, ar_, Bt, br_);
                 }
                 __syncthreads();
@@ -2045,6 +2157,7 @@ struct Phase {                       // one launch of the implicit GEMM
     size_t ws_off = 0;               // the same weights split into bf16 hi / lo halves per 32-wide k-tile (bf16x3 mode; 0 = none)
     size_t wh_off = 0;               // ... into float16 hi / lo halves (f16x3 mode), pre-multiplied by 1 / wh_scale
     float wh_scale = 1.f;            // power of two
+    size_t w3_off = 0;               // ... into THREE bf16 pieces per 32-wide k-tile [32 hi | 32 mid | 32 lo] (bf16x9 / bf16x6: w = hi + mid + lo exactly)
     int K;
 };
 
@@ -2271,6 +2384,23 @@ int pack_layer(RelposeSCNet* net, const LayerSpec& sp, std::vector<float>& blob)
                         _Float16* o = wh + ((size_t)n_ * P.K + kt * 32) * 2;
                         o[e] = hi; o[32 + e] = lo;
                     }
+            // three-piece bf16 split (bf16x9 / bf16x6): 8 + 8 + 8 significand bits, w = hi + mid + lo EXACTLY (both remainders are exact
+            // fp32 differences; bf16 has the fp32 exponent range, so no pre-scale); 192 bytes per k-tile and row
+            P.w3_off = blob.size();
+            blob.resize(blob.size() + (size_t)L.cout_pad * P.K * 3 / 2, 0.f);
+            w = blob.data() + P.w_off;
+            uint16_t* w3 = reinterpret_cast<uint16_t*>(blob.data() + P.w3_off);
+            for (int n_ = 0; n_ < L.cout_pad; ++n_)
+                for (int kt = 0; kt < P.K / 32; ++kt)
+                    for (int e = 0; e < 32; ++e) {
+                        const float v = w[(size_t)n_ * P.K + kt * 32 + e];
+                        const uint16_t hi = f32_to_bf16(v);
+                        const float r1 = v - bf16_to_f32(hi);
+                        const uint16_t mid = f32_to_bf16(r1);
+                        const uint16_t lo = f32_to_bf16(r1 - bf16_to_f32(mid));
+                        uint16_t* o = w3 + ((size_t)n_ * P.K + kt * 32) * 3;
+                        o[e] = hi; o[32 + e] = mid; o[64 + e] = lo;
+                    }
         }
     net->layers[L.name] = L;
     return 0;
@@ -2429,8 +2559,9 @@ void Builder::conv(const std::string& layer, Src s0, const Src* s1, int Hin, con
         }
         d.ntaps = P.ntaps;
         memcpy(d.offy, P.offy, 16); memcpy(d.offx, P.offx, 16);
-        d.w = net->d_w + ((net->prec == 1 && P.ws_off) ? P.ws_off : (net->prec >= 2 && P.wh_off) ? P.wh_off : P.w_off);
-        d.wscale = (net->prec >= 2 && P.wh_off) ? P.wh_scale : 1.f;
+        const bool f16w = (net->prec == RELPOSE_PREC_F16X3 || net->prec == RELPOSE_PREC_F16) && P.wh_off;
+        d.w = net->d_w + ((net->prec == 1 && P.ws_off) ? P.ws_off : f16w ? P.wh_off : (net->prec >= RELPOSE_PREC_BF16X9 && P.w3_off) ? P.w3_off : P.w_off);
+        d.wscale = f16w ? P.wh_scale : 1.f;
         d.Cout = L.cout; d.cout_pad = L.cout_pad;
         d.y = buf(out); d.Hout = Hout; d.Wout = Hout; d.ycstride = (out == "OUT") ? net->cf : O.C; d.ychoff = ochoff;
         d.bias = (L.kind == 2) ? net->d_w + L.bias_off : nullptr;
@@ -2495,7 +2626,8 @@ void Builder::end_group() {
         static const bool dt_strip = RP_ENV("RELPOSE_DT_STRIP") != nullptr;   // 56-wide grids (deconv3): no gain measured (one 7-wave workgroup per CU)
         static const bool no_pair = RP_ENV("RELPOSE_DT_NO_PAIR") != nullptr;
         //   4: <1, 1> pairs of 8 x 8 patches (grids that tile into 8 x 8 only: deconv3, 56 x 56), 3 per CU, Cout 64 as two N tiles
-        dt_cfg = Wg % 16 == 0 ? (cp == 32 ? 2 : 1) : ((Wg == 56 && dt_strip) ? 3 : ((Wg % 8 == 0 && !no_pair) ? 4 : -1));
+        // (three-piece bf16 rows: the <1, 2> variant's two weight tiles would need 95 KB of LDS -- Cout 64 as two N tiles of 32 there)
+        dt_cfg = Wg % 16 == 0 ? ((cp == 32 || net->prec >= RELPOSE_PREC_BF16X9) ? 2 : 1) : ((Wg == 56 && dt_strip) ? 3 : ((Wg % 8 == 0 && !no_pair) ? 4 : -1));
         if (dt_var >= 0 && dt_var <= 2 && Wg % 16 == 0 && !(dt_var == 0 && cp != 32) && !(dt_var == 1 && cp != 64)) dt_cfg = dt_var;
         const int PRt = dt_cfg == 0 ? 16 : (dt_cfg == 3 ? 4 : 8), PWt = dt_cfg == 3 ? 56 : (dt_cfg == 4 ? 8 : 16);
         dtile = !no_dt && dt_cfg >= 0 && net->prec != 1 && (cp == 32 || cp == 64) && count % 4 == 0;
@@ -2854,7 +2986,7 @@ int64_t relpose_scnet_num_params(const RelposeSCNet* net) {
 }
 
 int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode) {
-    if (!net || mode < RELPOSE_PREC_F32 || mode > RELPOSE_PREC_F16) return RELPOSE_EINVAL;
+    if (!net || mode < RELPOSE_PREC_F32 || mode > RELPOSE_PREC_BF16X6) return RELPOSE_EINVAL;
     if (net->prec != mode) { net->prec = mode; free_plan(net); }     // the launch plans hold weight pointers and kernel variants
     return 0;
 }
@@ -3159,6 +3291,14 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
                     if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 3);                                \
                     else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 3);                        \
                     else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, 3);                                     \
+                } else if (op.split == 4) {                                                                    \
+                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 4);                                \
+                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 4);                        \
+                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, 4);                                     \
+                } else if (op.split == 5) {                                                                    \
+                    if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 5);                                \
+                    else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 5);                        \
+                    else RP_LAUNCH_V(WM_, WN_, MI_, NI_, false, false, 5);                                     \
                 } else {                                                                                       \
                     if (op.uni) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, true, 0);                                \
                     else if (op.sslds) RP_LAUNCH_V(WM_, WN_, MI_, NI_, true, false, 0);                        \
@@ -3186,6 +3326,16 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
             do {                                                          \
                 if (op.split == 2) { LAUNCH_(2); }                        \
                 else if (op.split == 3) { LAUNCH_(3); }                   \
+                else if (op.split == 4) { LAUNCH_(4); }                   \
+                else if (op.split == 5) { LAUNCH_(5); }                   \
+                else { LAUNCH_(0); }                                      \
+            } while (0)
+            /* (variants that exist for the experiment log only: no three-piece instantiations) */ \
+#define RP_TILE_SPLIT_X(LAUNCH_)                                          \
+            do {                                                          \
+                if (op.split == 2) { LAUNCH_(2); }                        \
+                else if (op.split == 3) { LAUNCH_(3); }                   \
+                else if (op.split >= 4) return RELPOSE_EINVAL;            \
                 else { LAUNCH_(0); }                                      \
             } while (0)
 #define RP_L_STRIP(SP_) hipLaunchKernelGGL((conv_s2_strip_kernel<4, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
@@ -3198,7 +3348,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
 #define RP_L_S2B(SP_) hipLaunchKernelGGL((conv_s2_tile_kernel<1, 2, 16, false, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
 #define RP_L_S2C(SP_) hipLaunchKernelGGL((conv_s2_tile_kernel<1, 4, 8, true, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
             if (op.cfg == 0) RP_TILE_SPLIT(RP_L_S2A);
-            else if (op.cfg == 2) RP_TILE_SPLIT(RP_L_S2B);
+            else if (op.cfg == 2) RP_TILE_SPLIT_X(RP_L_S2B);
             else RP_TILE_SPLIT(RP_L_S2C);
 #undef RP_L_S2A
 #undef RP_L_S2B
@@ -3211,17 +3361,18 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
 #define RP_L_DT2(SP_) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 16, false, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
 #define RP_L_DT4(SP_) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 4, 8, true, SP_>), op.grid, dim3(256), 0, s, plan->d_descs + op.first)
 #define RP_L_DT3(SP_) hipLaunchKernelGGL((deconv_tile_kernel<1, 1, 7, 8, false, SP_>), op.grid, dim3(448), 0, s, plan->d_descs + op.first)
-            if (op.cfg == 0) RP_TILE_SPLIT(RP_L_DT0);
-            else if (op.cfg == 1) RP_TILE_SPLIT(RP_L_DT1);
+            if (op.cfg == 0) RP_TILE_SPLIT_X(RP_L_DT0);
+            else if (op.cfg == 1) RP_TILE_SPLIT_X(RP_L_DT1);
             else if (op.cfg == 2) RP_TILE_SPLIT(RP_L_DT2);
             else if (op.cfg == 4) RP_TILE_SPLIT(RP_L_DT4);
-            else RP_TILE_SPLIT(RP_L_DT3);
+            else RP_TILE_SPLIT_X(RP_L_DT3);
 #undef RP_L_DT0
 #undef RP_L_DT1
 #undef RP_L_DT2
 #undef RP_L_DT3
 #undef RP_L_DT4
 #undef RP_TILE_SPLIT
+#undef RP_TILE_SPLIT_X
             mark(-1);
         } else if (op.type == OP_CONV1) {
             mark(1);

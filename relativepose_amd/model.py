@@ -19,7 +19,7 @@ from . import _lib
 from .weights import state_dict_spec
 
 # relpose_scnet_set_precision modes (include/relpose.h: RELPOSE_PREC_*)
-PRECISION_CODES = {"f32": 0, "bf16x3": 1, "f16x3": 2, "f16": 3}
+PRECISION_CODES = {"f32": 0, "bf16x3": 1, "f16x3": 2, "f16": 3, "bf16x9": 4, "bf16x6": 5}
 
 BUFFER_SHAPES = {"X0": (224, 16), "A1": (224, 192), "A2": (112, 384), "A3": (56, 768), "A4": (28, 256), "A5": (14, 512),
                  "A6": (7, 512), "A7": (3, 512), "A8": (3, 512), "A9": (1, 1024), "D9": (3, 512), "D8": (3, 512),

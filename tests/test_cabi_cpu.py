@@ -79,7 +79,8 @@ def test_precision_codes_match_the_header():
     from relativepose_amd import model
     hdr = open(os.path.join(ROOT, "include", "relpose.h")).read()
     enum = dict((k, int(v)) for k, v in re.findall(r"(RELPOSE_PREC_[A-Z0-9]+)\s*=\s*(\d+)", hdr))
-    want = {"f32": "RELPOSE_PREC_F32", "bf16x3": "RELPOSE_PREC_BF16X3", "f16x3": "RELPOSE_PREC_F16X3", "f16": "RELPOSE_PREC_F16"}
+    want = {"f32": "RELPOSE_PREC_F32", "bf16x3": "RELPOSE_PREC_BF16X3", "f16x3": "RELPOSE_PREC_F16X3", "f16": "RELPOSE_PREC_F16",
+            "bf16x9": "RELPOSE_PREC_BF16X9", "bf16x6": "RELPOSE_PREC_BF16X6"}
     assert set(model.PRECISION_CODES) == set(want)
     for name, sym in want.items():
         assert enum[sym] == model.PRECISION_CODES[name], (name, sym)

@@ -60,7 +60,7 @@ def make_net(S, tanh, seed):
     return net, sd
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x9", "bf16x6", "f16x3", "bf16x3"])
 @pytest.mark.parametrize("case", SCNET_CASES)
 def test_scnet_layers_and_output_vs_oracle(case, prec, golden_dir):
     """prec = f32 is the parity configuration.  The opt-in split-16-bit modes run through the SAME layer-by-layer check
@@ -151,7 +151,7 @@ def test_scnet_batched_groups_equal_single_pairs():
         assert torch.equal(y1, yb[2 * i:2 * i + 2]), i      # deterministic kernels: bitwise equal
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x9", "bf16x6", "f16x3", "bf16x3"])
 def test_scnet_zero_warp_plan_is_bitwise_the_full_forward(prec):
     """Level 0 of the recurrence (util.py:95-96: the identity pose warps to zeros): with channels 8:16 zero in every image the
     RELPOSE_FWD_ZERO_WARP plan -- warped-view streams of conv2 / conv3 on the first BatchNorm group only, their K slices of conv4
@@ -181,7 +181,7 @@ def test_scnet_zero_warp_plan_is_bitwise_the_full_forward(prec):
     log("scnet_zero_warp", prec=prec, images=int(x.shape[0]), bitwise=True)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x9", "bf16x6", "f16x3", "bf16x3"])
 def test_scnet_self_stream_cache_is_bitwise_the_full_forward(prec):
     """Levels >= 1 of the recurrence: channels 0:8 (the masked own views) are those of level 0, only the warped view changed
     (evaluation.py:217-242), and the reference runs the self-view streams as separate module calls with their own batch statistics
@@ -288,7 +288,7 @@ def test_scnet_rejects_odd_batch_like_reference():
         net(torch.zeros(1, 16, 160, 640, device="cuda"))
 
 
-@pytest.mark.parametrize("mode,bound_max,bound_mean", [("f16x3", 5e-4, 2e-5), ("bf16x3", 2e-3, 1e-4), ("f16", 1e-1, 5e-3)])
+@pytest.mark.parametrize("mode,bound_max,bound_mean", [("bf16x9", 5e-4, 2e-5), ("bf16x6", 5e-4, 2e-5), ("f16x3", 5e-4, 2e-5), ("bf16x3", 2e-3, 1e-4), ("f16", 1e-1, 5e-3)])
 @pytest.mark.parametrize("hw", [(160, 640), (320, 1280)])
 def test_scnet_split_precision_options_close_to_f32_and_reversible(hw, mode, bound_max, bound_mean):
     """relpose_scnet_set_precision(F16X3 / BF16X3): split 16-bit MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate) are
