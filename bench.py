@@ -100,11 +100,6 @@ def parse_args(argv=None):
     ap.add_argument("--h2d-inflight", type=int, default=2,
                     help="batches in flight during the PCIe-inclusive run (0 = --inflight): with the copy stream beside them two in flight measured better than "
                          "three (configs[4]: 937 vs 769-876 pairs/s PCIe-inclusive), while three are better with resident inputs")
-    ap.add_argument("--split-forward", type=int, default=0, choices=[0, 1],
-                    help="A/B: every SCNet forward enqueued in two halves with the bottleneck chain on a third stream (RELPOSE_FWD_PART_FRONT / _BACK): "
-                         "a batch's chain runs under the next batch's encoder")
-    ap.add_argument("--mid-priority", type=int, default=-1, help="--split-forward: HIP stream priority of the chain's stream")
-    ap.add_argument("--slot-cus", type=int, default=0, help="A/B: CU-mask the slot streams (head, tail, geometry, matcher) to this many compute units; 0 = no mask")
     ap.add_argument("--hw-queues", type=int, default=0,
                     help="A/B: GPU_MAX_HW_QUEUES for this process (the HIP runtime multiplexes streams onto 4 hardware queues by default); 0 = leave the environment alone")
     ap.add_argument("--keypoint-mode", choices=["given", "reference"], default="given",
@@ -271,7 +266,7 @@ def worker(args):
     pipe = RelativePosePipeline(net, ds, mm, sigmas, max_edges=min(Cc * (Cc - 1), (1 << 20) * max(1, (N // 200) ** 2)),
                                 outputs="pose" if args.pose_outputs else "all", self_stream_cache=not args.no_self_cache,
                                 tail_overlap=not args.no_tail_overlap, net_priority=args.net_priority, loop_fit_cluster=args.fit_cluster,
-                                keypoints=args.keypoint_mode, split_forward=bool(args.split_forward), slot_cus=args.slot_cus, mid_priority=args.mid_priority)
+                                keypoints=args.keypoint_mode)
     ref_kp = args.keypoint_mode == "reference"
     if ref_kp:
         from relativepose_amd import rputil
@@ -392,7 +387,7 @@ def worker(args):
                                             f"{args.sift} synthetic detections per view; up to {batches[0]['N']} keypoints per view); NOT the BASELINE workload") if ref_kp
                                            else "given (one injected set per view for all levels: the BASELINE workload, SURVEY 8d)",
                           "recurrent_levels": 3, "conv_precision": prec, "parallelism": f"pairs sharded x{world}",
-                          "batches_in_flight": depth, "split_forward": bool(args.split_forward), "slot_stream_cus": args.slot_cus or None, "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"), "prepared_batches_rotated": nbatch, "setup_passes_before_warmup": depth if args.warmup < depth else 0,
+                          "batches_in_flight": depth, "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"), "prepared_batches_rotated": nbatch, "setup_passes_before_warmup": depth if args.warmup < depth else 0,
                           "scnet_outputs": "pose path only (normal, depth, features): opt-in, NOT the BASELINE metric" if args.pose_outputs else "all (like the reference)",
                           "level0_zero_warp_plan": True,
                           # levels 1-2 take the self-view encoder streams (conv1-3 self members, conv4 self K slices) from level 0 of the same

@@ -70,8 +70,9 @@ typedef struct RelposeParams {
 void relpose_default_params(RelposeParams* p_host);
 
 /* Process-wide kernel-selection knobs.  Every setting produces the same results (the parity tests force each variant
- * through the same checks); they exist for those tests and for tuning, not for the data path.  Returns the previous
- * value, RELPOSE_EINVAL for an unknown key.  Not synchronised with calls in flight on other threads.
+ * through the same checks); they exist for those tests and for tuning, NOT for the data path: nothing in the product path sets them
+ * (round 6: the one per-call choice the serving loop makes, the fit's workgroups per pair, is an argument of relpose_match_pairs_ex).
+ * Returns the previous value, RELPOSE_EINVAL for an unknown key.  Not synchronised with calls in flight on other threads.
  *   RELPOSE_TUNE_AFFINITY_KERNEL    0 = by batch size (default), 1 = row kernel (targets in registers), 2 = tile kernel
  *                                   (fp16-MFMA candidates + exact arithmetic on them), 3 = LDS kernel (the nt_max > 512 path),
  *                                   4 = pool variant (round 5: the tile kernel's stages as separate dense launches; auto-selected for the
@@ -90,14 +91,6 @@ enum { RELPOSE_TUNE_AFFINITY_KERNEL = 0, RELPOSE_TUNE_FIT_MAX_PRODUCTS = 1, RELP
        RELPOSE_TUNE_FIT_GLOBAL_VECTORS = 3, RELPOSE_TUNE_FIT_FIXED_CHECKS = 4, RELPOSE_TUNE_COUNT = 8 };
 int relpose_set_tuning(int32_t key, int32_t value);
 const char* relpose_version(void);
-/* A HIP stream whose kernels may only use the first `n_cus` compute units of the device's CU-mask order (hipExtStreamCreateWithCUMask; on gfx950 the
- * mask bits interleave over the 8 XCDs, so n_cus = 64 is 8 CUs of every XCD); n_cus <= 0 or >= the device's CU count = an ordinary stream.  For the
- * serving loop (pipeline.run_pipelined): the HBM- / latency-bound work of the batches in flight (head, tail, geometry, matcher) is confined to a slice of
- * the chip instead of taking wave slots from the other batch's convolutions on every CU.  No reference counterpart (the reference runs one pair at a
- * time on the default stream, evaluation.py:203-284).  relpose_stream_destroy releases it. */
-int relpose_stream_create_cu_limited(void** stream_out, int32_t n_cus);
-int relpose_stream_destroy(void* stream);
-
 /* ------------------------------------------------------------------ matcher
  * Keypoint sets of B scan pairs, padded to ns_max / nt_max rows.
  * Mirrors the dict the reference helper takes (rpmodule.py:317-326):
@@ -142,6 +135,32 @@ size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, 
 int relpose_match_pairs(const RelposeParams* params_host, const RelposeKeypoints* kp_host,
                         void* workspace, size_t workspace_bytes, int64_t max_edges,
                         double* pose, int32_t* status, const RelposeMatchDebug* debug_host, void* stream);
+
+/* relpose_match_pairs with its per-call choices IN the call (round 6; the reference call carries its own `para`, rpmodule.py:317-326): a
+ * struct_size-versioned argument block like RelposeForwardArgs -- fields beyond the caller's struct_size take their defaults (0).
+ *   params_host .. stream  as relpose_match_pairs
+ *   fit_cluster            workgroups per scan pair in the robust fit (rpmodule.py:212-315): 0 = by problem size (small batches of large pairs
+ *                          get helper workgroups: a latency tool), 1 = none (what a serving loop with several batches in flight wants: helpers
+ *                          take compute units from the other batches' convolutions), 2 / 4 / 8.  Every setting gives bitwise the same poses.
+ *                          This is the per-call form of RELPOSE_TUNE_FIT_CLUSTER; a non-zero value here wins over the process-wide test knob,
+ *                          so concurrent callers with different choices do not interfere (pipeline.run_pipelined uses it).
+ *   affinity_kernel        0 = by batch size, 1..4 as RELPOSE_TUNE_AFFINITY_KERNEL (same results); a non-zero value wins over the test knob. */
+typedef struct RelposeMatchArgs {
+    uint32_t struct_size;
+    int32_t fit_cluster;
+    const RelposeParams* params_host;
+    const RelposeKeypoints* kp_host;
+    void* workspace;
+    size_t workspace_bytes;
+    int64_t max_edges;
+    double* pose;
+    int32_t* status;
+    const RelposeMatchDebug* debug_host;
+    void* stream;
+    int32_t affinity_kernel;
+    int32_t reserved0;
+} RelposeMatchArgs;
+int relpose_match_pairs_ex(const RelposeMatchArgs* args);
 
 /* Stage A+B alone (rpmodule.py:342-379): N x N affinity build and row top-K.
  * wij may be NULL (fused variant: the matrix is never materialised). */
@@ -280,66 +299,50 @@ int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode);
 size_t relpose_scnet_workspace_bytes(const RelposeSCNet* net, int32_t n_images, int32_t H, int32_t W);
 
 /* forward: x [n,16,H,W] -> out [n,7+S+32,H,W]; n even, BatchNorm statistics over each
- * consecutive group of 2 images (the reference always feeds batch 2, evaluation.py:242). */
+ * consecutive group of 2 images (the reference always feeds batch 2, evaluation.py:242).
+ * Replaces the reference call `f = net(x)` (evaluation.py:242, rpmodule.py:623; SCNet.forward, model/mymodel.py:259-380). */
 int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
                           void* workspace, size_t workspace_bytes, void* stream);
-/* The same forward with its HBM-bound ends -- the head (input resize mymodel.py:261 + conv1* :266-286) and the tail (the five 1x1
- * heads deconv1* :312-376 + the final resize :379) -- enqueued on `tail_stream` and the MFMA-bound middle on `stream`, ordered by
- * events: `stream` is busy with this forward only between conv2 and deconv2, so the next forward -- of ANOTHER workspace -- overlaps
- * its convolutions with this head / tail (pipeline.run_pipelined).  x is read and `out` written on tail_stream only.
- * tail_stream == stream is relpose_scnet_forward. */
-int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
-                           void* workspace, size_t workspace_bytes, void* stream, void* tail_stream);
-/* relpose_scnet_forward2 with flags.  RELPOSE_FWD_ZERO_WARP: the caller guarantees that channels 8:16 of EVERY image are zero -- level 0
- * of the recurrence, where the pose estimate is the identity and util.warping returns zeros (util.py:95-96, evaluation.py:232-236).
- * The three warped-view encoder streams (conv1*..conv3* on rgb_t2s / norm_t2s / depth_t2s, mymodel.py:278-288) then produce the same
- * activations for every image, so conv2* / conv3* of those streams run for the first BatchNorm group only and their conv3 outputs
- * (+ BatchNorm scale / shift) are copied to the other images before conv4: results are bitwise those of the flag-less forward.
- * With the flag set and a non-zero warped view the output is undefined.
- * RELPOSE_FWD_POSE_OUTPUTS: compute only the outputs the pose path consumes -- normal (channels 3:6), depth (6) and the 32 feature
- * channels (7+S:), evaluation.py:246-253 / rpmodule.py:629-636 -- and skip the decoder branches that feed nothing else (deconv3/2/1 of the
- * rgb and semantic heads, mymodel.py:312-316,364-368); channels 0:3 and 7:7+S of `out` are written as zeros, the other channels are
- * bitwise those of the full forward.  Opt-in for callers that only want poses; never the default. */
-/* RELPOSE_FWD_NEW_WORKSPACE (relpose_scnet_forward4): the caller (re)allocated the workspace since its last forward -- possibly at the
- * same address --: whatever self-stream cache the library associates with the pointer is dropped before this forward. */
-/* RELPOSE_FWD_PART_FRONT / RELPOSE_FWD_PART_BACK (relpose_scnet_forward_ex, round 5): ONE forward enqueued by TWO calls with otherwise identical
- * arguments.  FRONT enqueues the head, the encoder (conv1..conv4) and the bottleneck chain (conv4's split-K reduction .. deconv6 with their
- * reductions and BatchNorm finalizes: ~30 dispatches of a few hundred workgroups at most, mymodel.py:293-304) -- the chain on `mid_stream`
- * when one is given; BACK waits for the chain and enqueues the decoder (deconv5..deconv2) on `stream` and the tail on `tail_stream`.
- * Between the two calls the caller may enqueue the FRONT of another forward (another workspace) on `stream`: that forward's large
- * encoder grids then run while this forward's chain trickles through `mid_stream` (pipeline.run_pipelined(split_forward=True)).  A BACK
- * without a pending FRONT on the workspace (or with another n / plan) returns RELPOSE_EINVAL; the output is bitwise that of the one-call forward. */
-enum { RELPOSE_FWD_ZERO_WARP = 1, RELPOSE_FWD_POSE_OUTPUTS = 2, RELPOSE_FWD_NEW_WORKSPACE = 4, RELPOSE_FWD_PART_FRONT = 8, RELPOSE_FWD_PART_BACK = 16 };
-int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
-                           void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags);
-/* relpose_scnet_forward3 with a self-stream cache.  Inside one scan pair's recurrence (evaluation.py:217-242) the masked own views --
- * channels 0:8 of every image -- never change between the levels, only the warped partner view (channels 8:16) does, and the reference
- * runs the self-view encoder streams as module calls of their own with their own batch statistics (conv1/2/3{rgb,n,d} on x[:,0:8],
- * mymodel.py:266-276; the warped-view calls are :278-288).  `self_tag` names the content of channels 0:8: when it is non-zero and
- * equal to the tag (and n, H, W) of the PREVIOUS forward on this workspace, the self-view blocks of conv1 / conv2 / conv3, their BatchNorm
- * scale / shift and conv4's three self K slices are taken from the workspace instead of being recomputed -- bitwise the values the
- * full forward would produce.  Any other tag (or 0) runs the full forward and leaves the cache filled for the next call.
- * Contract: two forwards on one workspace that carry the same non-zero tag have identical channels 0:8 (the caller draws a fresh tag
- * whenever it rewrites them); the weights / precision may not change in between (set_param / finalize / set_precision drop the cache).
- * RELPOSE_FWD_ZERO_WARP forwards always compute (and cache) the self streams. */
-int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_t n_images, int32_t H, int32_t W,
-                           void* workspace, size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags, uint64_t self_tag);
 
-/* ONE entry point for every forward variant above (round 5): the four relpose_scnet_forward* functions are thin wrappers that fill this
- * block.  Replaces the reference call `f = net(x)` (evaluation.py:242, rpmodule.py:623; SCNet.forward, model/mymodel.py:259-380).
+/* The same forward with every option of the serving loop, in ONE struct_size-versioned argument block (round 5; round 6 removed the
+ * accreted relpose_scnet_forward2 / 3 / 4 exports, which were thin wrappers filling this block).
  *   struct_size           sizeof(RelposeForwardArgs) as the CALLER compiled it: fields beyond it take their defaults (0), so the block can grow
- *   flags                 RELPOSE_FWD_* (as relpose_scnet_forward3)
- *   x, out, n_images, H, W, workspace, workspace_bytes   as relpose_scnet_forward
- *   stream, tail_stream   as relpose_scnet_forward2 (tail_stream NULL = stream)
- *   self_tag              as relpose_scnet_forward4 (0 = always recompute the self-view streams)
- *   mid_stream            (round 5) the bottleneck chain of the forward (see RELPOSE_FWD_PART_FRONT) runs on this stream, ordered by events behind the
- *                         encoder and in front of the decoder; NULL = `stream`.  Honoured by one-call forwards as well.
+ *   x, out, n_images, H, W, workspace, workspace_bytes, stream   as relpose_scnet_forward
+ *   tail_stream           NULL = `stream`.  Otherwise the HBM-bound ends of the forward -- the head (input resize mymodel.py:261 + conv1*
+ *                         :266-286) and the tail (the five 1x1 heads deconv1* :312-376 + the final resize :379) -- are enqueued on `tail_stream` and
+ *                         the MFMA-bound middle on `stream`, ordered by events: `stream` is busy with this forward only between conv2 and deconv2,
+ *                         so the next forward -- of ANOTHER workspace -- overlaps its convolutions with this head / tail
+ *                         (pipeline.run_pipelined).  x is read and `out` written on tail_stream only.
+ *   flags                 RELPOSE_FWD_ZERO_WARP: the caller guarantees that channels 8:16 of EVERY image are zero -- level 0 of the recurrence,
+ *                         where the pose estimate is the identity and util.warping returns zeros (util.py:95-96, evaluation.py:232-236).  The
+ *                         three warped-view encoder streams (conv1*..conv3* on rgb_t2s / norm_t2s / depth_t2s, mymodel.py:278-288) then produce
+ *                         the same activations for every image, so they run for the first BatchNorm group only: results are bitwise those of
+ *                         the flag-less forward.  With the flag set and a non-zero warped view the output is undefined.
+ *                         RELPOSE_FWD_POSE_OUTPUTS: compute only the outputs the pose path consumes -- normal (channels 3:6), depth (6) and the
+ *                         32 feature channels (7+S:), evaluation.py:246-253 / rpmodule.py:629-636 -- and skip the decoder branches that feed
+ *                         nothing else (deconv3/2/1 of the rgb and semantic heads, mymodel.py:312-316,364-368); channels 0:3 and 7:7+S of `out`
+ *                         are written as zeros, the others are bitwise those of the full forward.  Opt-in; never the default.
+ *                         RELPOSE_FWD_NEW_WORKSPACE: the caller (re)allocated the workspace since its last forward -- possibly at the same
+ *                         address --: whatever self-stream cache the library associates with the pointer is dropped before this forward.
+ *   self_tag              the self-stream cache.  Inside one scan pair's recurrence (evaluation.py:217-242) the masked own views -- channels 0:8
+ *                         of every image -- never change between the levels, only the warped partner view (channels 8:16) does, and the
+ *                         reference runs the self-view encoder streams as module calls of their own with their own batch statistics
+ *                         (conv1/2/3{rgb,n,d} on x[:,0:8], mymodel.py:266-276; the warped-view calls are :278-288).  `self_tag` names the
+ *                         content of channels 0:8: when it is non-zero and equal to the tag (and n, H, W) of the PREVIOUS forward on this
+ *                         workspace, the self-view blocks of conv1 / conv2 / conv3, their BatchNorm scale / shift, conv4's three self K slices
+ *                         and the skip-connection halves of the decoder are taken from the workspace instead of being recomputed -- bitwise the
+ *                         values the full forward would produce.  Any other tag (or 0) runs the full forward and leaves the cache filled.
+ *                         Contract: two forwards on one workspace that carry the same non-zero tag have identical channels 0:8 (the caller
+ *                         draws a fresh tag whenever it rewrites them); set_param / finalize / set_precision drop the cache.
+ *                         RELPOSE_FWD_ZERO_WARP forwards always compute (and cache) the self streams.
  *   workspace_generation  the caller's name for THIS ALLOCATION of `workspace` (e.g. a counter bumped whenever the buffer is re-allocated),
  *                         sent with every call: the self-stream cache is used only when the previous forward on the pointer carried the
  *                         same generation -- a workspace re-created at a recycled address is never mistaken for the old one, whichever call
  *                         touches it first (RELPOSE_FWD_NEW_WORKSPACE needs the first call to carry the flag).  0 = not tracked.
+ *   reserved1             must be NULL (the experiments build -- RP_EXPERIMENTS -- reads a third stream here, see below).
  * Error behaviour: a call that returns != 0 leaves no self-stream record on the workspace (the next forward recomputes everything); a
  * self-cached plan that cannot be built falls back to the full forward (same output) instead of failing. */
+enum { RELPOSE_FWD_ZERO_WARP = 1, RELPOSE_FWD_POSE_OUTPUTS = 2, RELPOSE_FWD_NEW_WORKSPACE = 4 };
 typedef struct RelposeForwardArgs {
     uint32_t struct_size;
     int32_t flags;
@@ -352,9 +355,19 @@ typedef struct RelposeForwardArgs {
     void* tail_stream;
     uint64_t self_tag;
     uint64_t workspace_generation;
-    void* mid_stream;
+    void* reserved1;
 } RelposeForwardArgs;
 int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args);
+
+#ifdef RP_EXPERIMENTS
+/* Experiments build only (tools/build_variant.py xp -DRP_EXPERIMENTS): scheduling variants of the serving loop that were measured in round 5
+ * and LOST (profiles/r05_loop_experiments.txt); they are not part of the product ABI.
+ * RELPOSE_FWD_PART_FRONT / _BACK: one forward enqueued by two calls cut behind the bottleneck chain (conv4's split-K reduction .. deconv6),
+ * the chain on the stream in RelposeForwardArgs::reserved1.  relpose_stream_create_cu_limited: a HIP stream confined to the first n_cus compute units. */
+enum { RELPOSE_FWD_PART_FRONT = 8, RELPOSE_FWD_PART_BACK = 16 };
+int relpose_stream_create_cu_limited(void** stream_out, int32_t n_cus);
+int relpose_stream_destroy(void* stream);
+#endif
 
 /* Multiply-accumulates one forward of a plan family executes (host-only, no device access): flags as above, self_cached != 0 = the plan
  * a forward takes when it finds its self_tag on the workspace.  The full forward (flags 0, self_cached 0) counts every member of

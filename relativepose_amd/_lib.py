@@ -35,19 +35,25 @@ class ForwardArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("flags", c_int), ("x", c_void_p), ("out", c_void_p),
                 ("n_images", c_int), ("H", c_int), ("W", c_int), ("reserved0", c_int),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("stream", c_void_p), ("tail_stream", c_void_p),
-                ("self_tag", C.c_uint64), ("workspace_generation", C.c_uint64), ("mid_stream", c_void_p)]
+                ("self_tag", C.c_uint64), ("workspace_generation", C.c_uint64), ("reserved1", c_void_p)]
+
+
+class MatchArgs(C.Structure):
+    """RelposeMatchArgs (include/relpose.h): the argument block of relpose_match_pairs_ex -- the per-call choices travel with the call."""
+    _fields_ = [("struct_size", C.c_uint32), ("fit_cluster", c_int), ("params_host", C.POINTER(Params)), ("kp_host", C.POINTER(Keypoints)),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("max_edges", c_int64), ("pose", c_void_p), ("status", c_void_p),
+                ("debug_host", C.POINTER(MatchDebug)), ("stream", c_void_p), ("affinity_kernel", c_int), ("reserved0", c_int)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/relpose.h
 SIGNATURES = {
     "relpose_default_params": (None, [C.POINTER(Params)]),
     "relpose_version": (c_char_p, []),
-    "relpose_stream_create_cu_limited": (c_int, [C.POINTER(c_void_p), c_int]),
-    "relpose_stream_destroy": (c_int, [c_void_p]),
     "relpose_set_tuning": (c_int, [c_int, c_int]),
     "relpose_match_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int64]),
     "relpose_match_pairs": (c_int, [C.POINTER(Params), C.POINTER(Keypoints), c_void_p, c_size_t, c_int64,
                                     c_void_p, c_void_p, C.POINTER(MatchDebug), c_void_p]),
+    "relpose_match_pairs_ex": (c_int, [C.POINTER(MatchArgs)]),
     "relpose_affinity_topk": (c_int, [C.POINTER(Params), C.POINTER(Keypoints), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "relpose_apply_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "relpose_build_view": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -77,10 +83,6 @@ SIGNATURES = {
     "relpose_scnet_num_params": (c_int64, [c_void_p]),
     "relpose_scnet_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "relpose_scnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "relpose_scnet_forward2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
-    "relpose_scnet_forward3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int]),
-    "relpose_scnet_forward4": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int,
-                                       C.c_uint64]),
     "relpose_scnet_forward_ex": (c_int, [c_void_p, C.POINTER(ForwardArgs)]),
     "relpose_scnet_plan_macs": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_double)]),
     "relpose_scnet_read_tap": (c_int64, [c_void_p, c_char_p, c_void_p, c_void_p, c_void_p]),

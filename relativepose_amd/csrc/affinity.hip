@@ -1487,8 +1487,8 @@ static int launch_affinity_pool(const RelposeParams& p, const RelposeKeypoints& 
 
 }  // namespace
 
-int rp_launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s) {
-    const int sel = g_rp_tune[RELPOSE_TUNE_AFFINITY_KERNEL];      // 0: by size, 1: row kernel, 2: tile kernel, 3: LDS kernel, 4: pool variant
+int rp_launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s, int sel_call) {
+    const int sel = sel_call > 0 ? sel_call : g_rp_tune[RELPOSE_TUNE_AFFINITY_KERNEL];      // 0: by size, 1: row kernel, 2: tile kernel, 3: LDS kernel, 4: pool variant
     const RpPairConsts kc = rp_make_consts(p);
     AffConsts ac;
     ac.den[0] = kc.den_other; ac.den[1] = kc.den_both;

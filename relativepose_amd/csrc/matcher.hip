@@ -1319,6 +1319,7 @@ void relpose_default_params(RelposeParams* p) {
 
 const char* relpose_version(void) { return "relpose-hip 0.1 (gfx950)"; }
 
+#ifdef RP_EXPERIMENTS
 int relpose_stream_create_cu_limited(void** stream_out, int32_t n_cus) {
     if (!stream_out) return RELPOSE_EINVAL;
     int dev = 0, ncu = 0;
@@ -1345,6 +1346,7 @@ int relpose_stream_destroy(void* stream) {
     RP_HIP(hipStreamDestroy((hipStream_t)stream));
     return 0;
 }
+#endif
 
 size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, int32_t topK, int64_t max_edges) {
     if (nt_max > RELPOSE_MAX_TARGETS) return 0;
@@ -1355,11 +1357,33 @@ size_t relpose_match_workspace_bytes(int32_t B, int32_t ns_max, int32_t nt_max, 
 int relpose_affinity_topk(const RelposeParams* p, const RelposeKeypoints* kp, float* wij, int32_t* corres_j, double* corres_w,
                           int32_t* k_eff, void* stream) {
     if (!kp_ok(kp, p) || !corres_j || !corres_w || !k_eff) return RELPOSE_EINVAL;
-    return rp_launch_affinity(*p, *kp, wij, corres_j, corres_w, k_eff, (hipStream_t)stream);
+    return rp_launch_affinity(*p, *kp, wij, corres_j, corres_w, k_eff, (hipStream_t)stream, 0);
 }
 
 int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void* workspace, size_t workspace_bytes, int64_t max_edges,
                         double* pose, int32_t* status, const RelposeMatchDebug* dbg, void* stream) {
+    RelposeMatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.struct_size = (uint32_t)sizeof(a);
+    a.params_host = p; a.kp_host = kp; a.workspace = workspace; a.workspace_bytes = workspace_bytes; a.max_edges = max_edges;
+    a.pose = pose; a.status = status; a.debug_host = dbg; a.stream = stream;
+    return relpose_match_pairs_ex(&a);
+}
+
+int relpose_match_pairs_ex(const RelposeMatchArgs* args) {
+    if (!args || args->struct_size < offsetof(RelposeMatchArgs, stream) + sizeof(void*)) return RELPOSE_EINVAL;
+    const RelposeParams* p = args->params_host;
+    const RelposeKeypoints* kp = args->kp_host;
+    void* workspace = args->workspace;
+    const size_t workspace_bytes = args->workspace_bytes;
+    const int64_t max_edges = args->max_edges;
+    double* pose = args->pose;
+    int32_t* status = args->status;
+    const RelposeMatchDebug* dbg = args->debug_host;
+    void* stream = args->stream;
+    const int call_cluster = args->fit_cluster;
+    const int call_affinity = args->struct_size >= offsetof(RelposeMatchArgs, affinity_kernel) + sizeof(int32_t) ? args->affinity_kernel : 0;
+    if (call_cluster < 0 || call_cluster > 8 || call_affinity < 0 || call_affinity > 4) return RELPOSE_EINVAL;
     if (!kp_ok(kp, p) || !workspace || !pose || !status) return RELPOSE_EINVAL;
     if (p->method < 0 || p->method > 3) return RELPOSE_EINVAL;
     if ((int64_t)kp->ns_max * p->topK > RP_MAX_CORRES) return RELPOSE_EINVAL;
@@ -1380,7 +1404,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
     g.seg_cap = L.seg_cap; g.estride = L.estride;
     g.segptr = (int32_t*)(ws + L.segptr); g.segrow = (int32_t*)(ws + L.segrow); g.part = (double*)(ws + L.part);
     RP_HIP(hipMemsetAsync(ws + L.counters, 0, (size_t)kp->B * 16, s));
-    int rc = rp_launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s);
+    int rc = rp_launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s, call_affinity);
     if (rc) return rc;
     const RpPairConsts kc = rp_make_consts(*p);
     dim3 grid_rows((L.Cmax + 3) / 4, kp->B);
@@ -1423,7 +1447,7 @@ int relpose_match_pairs(const RelposeParams* p, const RelposeKeypoints* kp, void
         // RELPOSE_TUNE_FIT_CLUSTER forces a size (1 = none).
         int G = 1;
         if (in_lds && m != RELPOSE_FIT_SPECTRAL) {
-            const int want = g_rp_tune[RELPOSE_TUNE_FIT_CLUSTER];
+            const int want = call_cluster > 0 ? call_cluster : g_rp_tune[RELPOSE_TUNE_FIT_CLUSTER];     // the call's own choice wins over the test knob
             if (want > 0) G = want > 8 ? 8 : want;
             else if (L.Cmax >= 512) { G = L.Cmax > 1024 ? 8 : 4; while (G > 1 && (long long)kp->B * G > 32) G >>= 1; }
         }

@@ -27,4 +27,5 @@ static inline RpPairConsts rp_make_consts(const RelposeParams& p) {
 extern int32_t g_rp_tune[RELPOSE_TUNE_COUNT];
 
 // affinity.hip: rpmodule.py:342-379 for a batch of pairs (wij may be null: fused variant)
-int rp_launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s);
+// sel_call: the call's own kernel choice (RelposeMatchArgs::affinity_kernel), 0 = the process-wide test knob / by size
+int rp_launch_affinity(const RelposeParams& p, const RelposeKeypoints& kp, float* wij, int32_t* cj, double* cw, int32_t* keff, hipStream_t s, int sel_call);

@@ -30,6 +30,11 @@
 #include <stdlib.h>
 #include <stddef.h>
 
+#ifndef RP_EXPERIMENTS
+// (the two-part forward exists in the experiments build only, include/relpose.h; the product build rejects these flag bits)
+enum { RELPOSE_FWD_PART_FRONT = 8, RELPOSE_FWD_PART_BACK = 16 };
+#endif
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -3104,24 +3109,6 @@ int relpose_scnet_forward(RelposeSCNet* net, const float* x, float* out, int32_t
     return relpose_scnet_forward_ex(net, &a);
 }
 
-int relpose_scnet_forward2(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
-                           size_t workspace_bytes, void* stream, void* tail_stream) {
-    const RelposeForwardArgs a = rp_fwd_args(x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, 0, 0);
-    return relpose_scnet_forward_ex(net, &a);
-}
-
-int relpose_scnet_forward3(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
-                           size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags) {
-    const RelposeForwardArgs a = rp_fwd_args(x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, flags, 0);
-    return relpose_scnet_forward_ex(net, &a);
-}
-
-int relpose_scnet_forward4(RelposeSCNet* net, const float* x, float* out, int32_t n, int32_t H, int32_t W, void* workspace,
-                           size_t workspace_bytes, void* stream, void* tail_stream, int32_t flags, uint64_t self_tag) {
-    const RelposeForwardArgs a = rp_fwd_args(x, out, n, H, W, workspace, workspace_bytes, stream, tail_stream, flags, self_tag);
-    return relpose_scnet_forward_ex(net, &a);
-}
-
 int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) {
     // (fields beyond the caller's struct_size take their defaults: a caller compiled against an older header keeps working)
     if (!net || !args || args->struct_size < offsetof(RelposeForwardArgs, self_tag)) return RELPOSE_EINVAL;
@@ -3135,7 +3122,13 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
     if (flags & ~(RELPOSE_FWD_ZERO_WARP | RELPOSE_FWD_POSE_OUTPUTS | RELPOSE_FWD_NEW_WORKSPACE | RELPOSE_FWD_PART_FRONT | RELPOSE_FWD_PART_BACK)) return RELPOSE_EINVAL;
     const int part = flags & (RELPOSE_FWD_PART_FRONT | RELPOSE_FWD_PART_BACK);
     if (part == (RELPOSE_FWD_PART_FRONT | RELPOSE_FWD_PART_BACK)) return RELPOSE_EINVAL;
-    void* mid_stream = (args->struct_size >= offsetof(RelposeForwardArgs, mid_stream) + sizeof(void*) && args->mid_stream) ? args->mid_stream : args->stream;
+#ifdef RP_EXPERIMENTS
+    void* mid_stream = (args->struct_size >= offsetof(RelposeForwardArgs, reserved1) + sizeof(void*) && args->reserved1) ? args->reserved1 : args->stream;
+#else
+    // product build: one call = one forward, the bottleneck chain stays on `stream` (the two-part / third-stream forms lost their A/Bs, round 5)
+    if (part || (args->struct_size >= offsetof(RelposeForwardArgs, reserved1) + sizeof(void*) && args->reserved1)) return RELPOSE_EINVAL;
+    void* mid_stream = args->stream;
+#endif
     const int G = n / 2;
     // (nothing to share with one BatchNorm group; the tile kernels' patch pairing wants the 2-image members' patch count even as well)
     const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2;

@@ -55,12 +55,13 @@ def shard_range(total, rank, world):
 COLLECTIVES = {"all_gather": 0}      # data-path collectives issued by this process (bench.py reports the count)
 
 
-def gather_poses(pose_local, status_local, total, world):
+def gather_poses(pose_local, status_local, total, world, force_collective=False):
     """all_gather of per-rank [b_r,4,4] poses and [b_r] status into [total,4,4] / [total] on every rank
-    (ragged blocks are padded to the largest block)."""
+    (ragged blocks are padded to the largest block).  force_collective: issue the collective even with ONE rank (test hook: the
+    1-GPU box runs the RCCL all_gather of the [B,17] f64 block through exactly this code, tests/test_gpu_rccl.py)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force_collective:
         return pose_local, status_local
     bmax = (total + world - 1) // world
     buf = torch.zeros(bmax, 17, dtype=torch.float64, device=pose_local.device)
@@ -76,6 +77,24 @@ def gather_poses(pose_local, status_local, total, world):
         poses.append(out[r][:hi - lo, :16].reshape(-1, 4, 4))
         status.append(out[r][:hi - lo, 16].to(torch.int32))
     return torch.cat(poses), torch.cat(status)
+
+
+def rccl_info():
+    """{"rccl_version", "librccl_loaded"}: what the process actually linked and loaded ("nccl" IS RCCL on ROCm); diagnostic for the bench's
+    per-rank stderr line and the RCCL test."""
+    import torch
+    info = {}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:      # noqa: BLE001
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    try:
+        with open("/proc/self/maps") as f:
+            libs = sorted({line.split()[-1] for line in f if "rccl" in line.lower()})
+        info["librccl_loaded"] = libs
+    except OSError:
+        info["librccl_loaded"] = None
+    return info
 
 
 def barrier(world):

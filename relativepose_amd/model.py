@@ -156,11 +156,10 @@ class SCNet(torch.nn.Module):
         return cls._tag_counter
 
     FLAG_ZERO_WARP, FLAG_POSE_OUTPUTS = 1, 2       # RELPOSE_FWD_* (include/relpose.h)
-    FLAG_PART_FRONT, FLAG_PART_BACK = 8, 16
 
-    def forward(self, x, out=None, tail_stream=None, ws_key=None, zero_warp=False, outputs="all", self_tag=0, mid_stream=None, part=None):
+    def forward(self, x, out=None, tail_stream=None, ws_key=None, zero_warp=False, outputs="all", self_tag=0):
         """tail_stream (a torch stream; not part of the reference interface): run the HBM-bound tail of the forward (heads + final
-        resize) there, behind the convolutions on the current stream (relpose_scnet_forward2) -- `out` is then valid on tail_stream only.
+        resize) there, behind the convolutions on the current stream (RelposeForwardArgs::tail_stream) -- `out` is then valid on tail_stream only.
         ws_key: name of the workspace to use (forwards that may overlap need different workspaces; default: one per stream).
         zero_warp: the caller guarantees x[:, 8:16] == 0 for every image (level 0 of the recurrence: util.warping returns zeros for the
         identity pose, util.py:95-96); the warped-view encoder streams then run once per batch instead of once per image
@@ -170,15 +169,11 @@ class SCNet(torch.nn.Module):
         those of the full forward).
         self_tag: non-zero = the caller's name for the content of x[:, 0:8] (the masked own views, constant across the levels of a scan
         pair's recurrence, evaluation.py:217-242): a forward that finds the previous forward of its workspace carried the same tag reuses
-        that forward's self-view encoder streams (relpose_scnet_forward4; bitwise the same output).  0 = always recompute.
-        mid_stream (a torch stream): the bottleneck chain of the forward (conv4's split-K reduction .. deconv6) runs there.
-        part: None = the whole forward; "front" / "back" = ONE forward enqueued by two calls with the same arguments (`out` given), so that the
-        caller can enqueue another forward's front half on the current stream in between (RELPOSE_FWD_PART_FRONT / _BACK)."""
+        that forward's self-view encoder streams (RelposeForwardArgs::self_tag; bitwise the same output).  0 = always recompute."""
         flags = (self.FLAG_ZERO_WARP if zero_warp else 0) | {"all": 0, "pose": self.FLAG_POSE_OUTPUTS}[outputs]
-        flags |= {None: 0, "front": self.FLAG_PART_FRONT, "back": self.FLAG_PART_BACK}[part]
-        return self.forward_flags(x, out, flags, self_tag, tail_stream, ws_key, mid_stream)
+        return self.forward_flags(x, out, flags, self_tag, tail_stream, ws_key)
 
-    def forward_flags(self, x, out=None, flags=0, self_tag=0, tail_stream=None, ws_key=None, mid_stream=None):
+    def forward_flags(self, x, out=None, flags=0, self_tag=0, tail_stream=None, ws_key=None):
         """The forward as the C ABI sees it (relpose_scnet_forward_ex): `flags` = RELPOSE_FWD_* bits, `tail_stream` a torch stream, a raw
         HIP stream handle (int) or None.  `forward` and torch.ops.relpose.scnet_forward both end here."""
         import torch
@@ -190,11 +185,7 @@ class SCNet(torch.nn.Module):
         n, _, H, W = x.shape
         if isinstance(tail_stream, int):
             tail_stream = None if tail_stream == 0 else torch.cuda.ExternalStream(tail_stream)
-        if isinstance(mid_stream, int):
-            mid_stream = None if mid_stream == 0 else torch.cuda.ExternalStream(mid_stream)
-        if (int(flags) & (self.FLAG_PART_FRONT | self.FLAG_PART_BACK)) and out is None:
-            raise ValueError("a forward enqueued in two parts needs the caller's `out` buffer (the same in both calls)")
-        ws = self._workspace(n, H, W, x.device, ws_key, tuple(s_ for s_ in (tail_stream, mid_stream) if s_ is not None))
+        ws = self._workspace(n, H, W, x.device, ws_key, tuple(s_ for s_ in (tail_stream,) if s_ is not None))
         if tail_stream is not None:
             x.record_stream(tail_stream)                   # (the input resize runs there)
         if out is None:
@@ -205,7 +196,7 @@ class SCNet(torch.nn.Module):
             assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (n, self.out_channels, H, W)
         a = _lib.ForwardArgs()
         a.struct_size = C.sizeof(_lib.ForwardArgs)
-        a.flags = int(flags) & 27
+        a.flags = int(flags) & 3
         a.x, a.out = x.data_ptr(), out.data_ptr()
         a.n_images, a.H, a.W = n, H, W
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -213,7 +204,6 @@ class SCNet(torch.nn.Module):
         a.tail_stream = a.stream if tail_stream is None else tail_stream.cuda_stream
         a.self_tag = int(self_tag)
         a.workspace_generation = self._ws_gen
-        a.mid_stream = None if mid_stream is None else mid_stream.cuda_stream
         _lib.check(_lib.lib().relpose_scnet_forward_ex(self._h, C.byref(a)), "relpose_scnet_forward_ex")
         return out
 

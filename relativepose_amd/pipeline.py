@@ -22,11 +22,9 @@ class RelativePosePipeline:
     _chain_nets = False
     _net_stream = None
     _net_streams = None
-    _mid_stream = None
 
     def __init__(self, net, dataset="suncg", mask_method="second", sigmas=None, alter_steps=3, completion=1, max_edges=0, compose=0, outputs="all",
-                 self_stream_cache=True, tail_overlap=True, net_priority=None, loop_fit_cluster=1, keypoints="given", split_forward=False,
-                 slot_cus=0, mid_priority=-1):
+                 self_stream_cache=True, tail_overlap=True, net_priority=None, loop_fit_cluster=1, keypoints="given"):
         self.net = net
         # "given": prepare(pts, ptw) fixes the keypoints of every view for all levels.  "reference": prepare(sift=...) takes the views' SIFT
         # detections (panorama coordinates, rputil.map_detections) and every level derives its keypoints from its own feature maps, as
@@ -58,17 +56,9 @@ class RelativePosePipeline:
         self.tail_overlap = bool(tail_overlap)
         self.net_priority = net_priority
         # workgroups per scan pair in the fit while several batches are in flight (run_pipelined; 1 = no helper workgroups: they take CUs from the
-        # other slot's convolutions; A/B switch)
+        # other slot's convolutions; A/B switch).  It travels WITH every matcher call (RelposeMatchArgs::fit_cluster): two pipelines in
+        # one process with different settings do not interfere (round 5 set a process-wide knob around the loop here).
         self.loop_fit_cluster = int(loop_fit_cluster)
-        # split_forward (run_pipelined with the tail overlap): every forward is enqueued in two halves (SCNet.forward(part=...)) -- encoder + bottleneck
-        # chain, then decoder + tail -- and the chain (conv4's split-K reduction .. deconv6: ~30 dispatches of at most a few hundred workgroups,
-        # 1.0 ms alone / 2.7 ms under the slot streams' load, during which the SCNet stream's big grids wait) runs on a third stream: the
-        # loop's order on the SCNet stream is A.enc B.enc C.enc A.dec B.dec C.dec, so A's chain trickles through under B's encoder.
-        self.split_forward = bool(split_forward)
-        self.mid_priority = int(mid_priority)
-        # slot_cus > 0: the slot streams (head, tail, geometry, matcher of the batches in flight) are CU-masked to that many compute units
-        # (relpose_stream_create_cu_limited); 0 = ordinary streams
-        self.slot_cus = int(slot_cus)
 
     def prepare(self, rgb, norm, depth, pts, ptw, device, keep_host=False, sift=None, kp_seeds=None):
         """Host arrays (dataset dict layout: rgb/norm [B,2,3,h,4h], depth [B,2,h,4h] f32; pts [B,2,N,2],
@@ -211,8 +201,6 @@ class RelativePosePipeline:
         for st in states:
             cur.wait_stream(st["stream"])
         cur.wait_stream(self._net_stream)
-        if self._mid_stream is not None:
-            cur.wait_stream(self._mid_stream)
         self._chain_nets = False
         return [(o[0], o[1]) for o in out]
 
@@ -237,19 +225,6 @@ class RelativePosePipeline:
             new_stream.wait_stream(self._net_stream)            # forwards of the previous call stay ordered before this call's
         self._net_stream = new_stream
         self._net_stream.wait_stream(torch.cuda.current_stream())
-        if self.split_forward and self.tail_overlap:
-            if self._mid_stream is None:
-                self._mid_stream = torch.cuda.Stream(priority=self.mid_priority)
-            self._mid_stream.wait_stream(torch.cuda.current_stream())
-
-    def _new_slot_stream(self):
-        import ctypes as C
-        import torch
-        if self.slot_cus <= 0:
-            return torch.cuda.Stream()
-        h = C.c_void_p()
-        _lib.check(_lib.lib().relpose_stream_create_cu_limited(C.byref(h), self.slot_cus), "relpose_stream_create_cu_limited")
-        return torch.cuda.ExternalStream(h.value)
 
     def run_pipelined(self, states, steps, on_result=None, depth=None, before_batch=None, provider=None):
         """`steps` consecutive batches through the hot path with `depth` of them in flight (a serving loop;
@@ -278,7 +253,7 @@ class RelativePosePipeline:
         # (4.5 ms per 2 batches, profiles/r02_overlap.txt).  net + default + 2 slots = 4 streams = 4 queues; a new batch is
         # ordered behind the finished batch of its own slot, whose matcher ran under the other slot's forward long before.
         while len(self._slot_streams) < depth:
-            self._slot_streams.append(self._new_slot_stream())
+            self._slot_streams.append(torch.cuda.Stream())
         for ss in self._slot_streams[:depth]:
             ss.wait_stream(cur)
         for st in states:
@@ -287,62 +262,63 @@ class RelativePosePipeline:
         results = [None] * steps
         live, nxt = {}, 0
         # batches in flight = a throughput loop: the fit's helper workgroups (a latency tool for a lone small batch)
-        # would take CUs from the other slot's convolutions, so the matcher calls enqueued here use one workgroup per pair
-        import contextlib
-        with (_lib.tuning(fit_cluster=self.loop_fit_cluster) if depth > 1 else contextlib.nullcontext()):
-            while nxt < steps or live:
-                for slot in range(depth):
-                    if slot not in live and nxt < steps:
-                        ss = self._slot_streams[slot]
+        # would take CUs from the other slot's convolutions, so the matcher calls enqueued here (_run_gen) carry fit_cluster = loop_fit_cluster
+        while nxt < steps or live:
+            for slot in range(depth):
+                if slot not in live and nxt < steps:
+                    ss = self._slot_streams[slot]
+                    if provider is not None:
+                        st = provider(nxt)               # (allocates + uploads on the caller's stream)
+                        ss.wait_stream(cur)
+                    else:
+                        st = states[nxt % nst]
+                    if st.get("stream") is not None and st["stream"] is not ss:
+                        # the buffers' previous use (another slot / run_interleaved): the batch that used them recorded its completion -- wait for
+                        # THAT, not for whatever else has been queued on its slot stream since (with 4 rotating batches and 3 in flight a state
+                        # changes slot every time: waiting for the whole stream serialised the slots, 592 vs 634 pairs/s at configs[2])
+                        if st.get("done_ev") is not None:
+                            ss.wait_event(st["done_ev"])
+                        else:
+                            ss.wait_stream(st["stream"])
+                    st["stream"] = ss
+                    if before_batch is not None:
+                        with torch.cuda.stream(st["stream"]):
+                            before_batch(nxt, st)
+                    live[slot] = (nxt, st, self._run_gen(st))
+                    nxt += 1
+                if slot not in live:
+                    continue
+                k, st, gen = live[slot]
+                done = None
+                with torch.cuda.stream(st["stream"]):
+                    try:
+                        next(gen)
+                    except StopIteration as e:
+                        done = e.value
+                if done is not None:
+                    del live[slot]
+                    # the batch's buffers are free again once this point of its stream is reached (a copy stream that refills them for a
+                    # later batch waits for THIS event, not for whatever else is queued on the slot stream: bench.py's upload look-ahead)
+                    st["done_ev"] = torch.cuda.Event()
+                    st["done_ev"].record(st["stream"])
+                    pose, status = done[0], done[1]
+                    if on_result is not None:
+                        cur.wait_stream(st["stream"])
+                        pose.record_stream(cur); status.record_stream(cur)
+                        results[k] = on_result(k, pose, status)
+                    else:
                         if provider is not None:
-                            st = provider(nxt)               # (allocates + uploads on the caller's stream)
-                            ss.wait_stream(cur)
-                        else:
-                            st = states[nxt % nst]
-                        if st.get("stream") is not None and st["stream"] is not ss:
-                            # the buffers' previous use (another slot / run_interleaved): the batch that used them recorded its completion -- wait for
-                            # THAT, not for whatever else has been queued on its slot stream since (with 4 rotating batches and 3 in flight a state
-                            # changes slot every time: waiting for the whole stream serialised the slots, 592 vs 634 pairs/s at configs[2])
-                            if st.get("done_ev") is not None:
-                                ss.wait_event(st["done_ev"])
-                            else:
-                                ss.wait_stream(st["stream"])
-                        st["stream"] = ss
-                        if before_batch is not None:
-                            with torch.cuda.stream(st["stream"]):
-                                before_batch(nxt, st)
-                        live[slot] = (nxt, st, self._run_gen(st))
-                        nxt += 1
-                    if slot not in live:
-                        continue
-                    k, st, gen = live[slot]
-                    done = None
-                    with torch.cuda.stream(st["stream"]):
-                        try:
-                            next(gen)
-                        except StopIteration as e:
-                            done = e.value
-                    if done is not None:
-                        del live[slot]
-                        # the batch's buffers are free again once this point of its stream is reached (a copy stream that refills them for a
-                        # later batch waits for THIS event, not for whatever else is queued on the slot stream: bench.py's upload look-ahead)
-                        st["done_ev"] = torch.cuda.Event()
-                        st["done_ev"].record(st["stream"])
-                        pose, status = done[0], done[1]
-                        if on_result is not None:
+                            # a provider's state was allocated on the caller's stream and is dropped right here: order the caller's stream behind
+                            # the batch, or the caching allocator may hand the blocks to the next provider() upload while kernels still read them
                             cur.wait_stream(st["stream"])
-                            pose.record_stream(cur); status.record_stream(cur)
-                            results[k] = on_result(k, pose, status)
-                        else:
-                            results[k] = (pose, status)
+                            cur.wait_stream(self._net_stream)
+                        results[k] = (pose, status)
         for st in states:
             if "stream" in st:
                 cur.wait_stream(st["stream"])
         for ss in self._slot_streams[:depth]:
             cur.wait_stream(ss)
         cur.wait_stream(self._net_stream)
-        if self._mid_stream is not None:
-            cur.wait_stream(self._mid_stream)
         self._chain_nets = False
         return results
 
@@ -387,18 +363,9 @@ class RelativePosePipeline:
                     # SCNet stream goes straight on to the other batch's forward, whose MFMA-bound convs overlap this tail.  Overlapping
                     # forwards need separate workspaces: one per stream (= per in-flight slot).
                     f = st["f"]
-                    if self.split_forward and self._mid_stream is not None:
-                        kw = dict(out=f, tail_stream=ms, ws_key=ms.cuda_stream, zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"],
-                                  mid_stream=self._mid_stream)
-                        with torch.cuda.stream(ns):
-                            self.net.forward(x, part="front", **kw)
-                        yield                                        # the other batches' front halves go onto the SCNet stream before this decoder
-                        with torch.cuda.stream(ns):
-                            self.net.forward(x, part="back", **kw)
-                    else:
-                        with torch.cuda.stream(ns):
-                            self.net.forward(x, out=f, tail_stream=ms, ws_key=ms.cuda_stream, zero_warp=(step == 0), outputs=self.outputs,
-                                             self_tag=st["self_tag"])
+                    with torch.cuda.stream(ns):
+                        self.net.forward(x, out=f, tail_stream=ms, ws_key=ms.cuda_stream, zero_warp=(step == 0), outputs=self.outputs,
+                                         self_tag=st["self_tag"])
                 else:
                     with torch.cuda.stream(ns):
                         f = self.net.forward(x, out=st["f"], zero_warp=(step == 0), outputs=self.outputs, self_tag=st["self_tag"])
@@ -415,7 +382,7 @@ class RelativePosePipeline:
             para = rpmodule.opts(*self.sigmas[min(step, len(self.sigmas) - 1)])
             res = rpmodule.match_pairs(pc[:, 0].contiguous(), nn[:, 0].contiguous(), ft[:, 0].contiguous(), w_s,
                                        pc[:, 1].contiguous(), nn[:, 1].contiguous(), ft[:, 1].contiguous(), w_t,
-                                       ns, nt, para, max_edges=self.max_edges)
+                                       ns, nt, para, max_edges=self.max_edges, fit_cluster=self.loop_fit_cluster if self._chain_nets else 0)
             R_hat, status = res.pose, res.status
         return R_hat, status, None
 

@@ -73,9 +73,10 @@ def _workspace(nbytes, dev):
     return buf
 
 
-def match_pairs(pc_s, n_s, f_s, w_s, pc_t, n_t, f_t, w_t, ns, nt, para, debug=False, want_wij=False, max_edges=0):
+def match_pairs(pc_s, n_s, f_s, w_s, pc_t, n_t, f_t, w_t, ns, nt, para, debug=False, want_wij=False, max_edges=0, fit_cluster=0, affinity_kernel=0):
     """Batched matcher on device tensors.
     pc_*/n_* [B,N,3] f64, f_* [B,N,32] f32, w_* [B,N] f64, ns/nt [B] int32 (all CUDA, contiguous).
+    fit_cluster / affinity_kernel: the call's own kernel choices (RelposeMatchArgs; 0 = by problem size; same results whatever the value).
     Returns MatchResult with pose [B,4,4] f64 and status [B] int32 (device tensors)."""
     import torch
     dev = _lib.require_gpu()
@@ -116,9 +117,16 @@ def match_pairs(pc_s, n_s, f_s, w_s, pc_t, n_t, f_t, w_t, ns, nt, para, debug=Fa
             res.eig_iters = torch.zeros(B, 5, dtype=torch.int32, device=dev)
         dbg.wij, dbg.corres_j, dbg.corres_w = _lib.ptr(res.wij), _lib.ptr(res.corres_j), _lib.ptr(res.corres_w)
         dbg.counts, dbg.trace, dbg.eig_iters = _lib.ptr(res.counts), _lib.ptr(res.trace), _lib.ptr(res.eig_iters)
-    rc = L.relpose_match_pairs(C.byref(p), C.byref(kp), _lib.ptr(ws), ws.numel(), int(max_edges), _lib.ptr(res.pose),
-                               _lib.ptr(res.status), C.byref(dbg) if dbg is not None else None, _lib.stream_ptr())
-    _lib.check(rc, "relpose_match_pairs")
+    a = _lib.MatchArgs()
+    a.struct_size = C.sizeof(_lib.MatchArgs)
+    a.fit_cluster = int(fit_cluster)
+    a.affinity_kernel = _lib.AFFINITY_KERNELS.get(affinity_kernel, affinity_kernel) if isinstance(affinity_kernel, str) else int(affinity_kernel)
+    a.params_host, a.kp_host = C.pointer(p), C.pointer(kp)
+    a.workspace, a.workspace_bytes, a.max_edges = _lib.ptr(ws), ws.numel(), int(max_edges)
+    a.pose, a.status = _lib.ptr(res.pose), _lib.ptr(res.status)
+    a.debug_host = C.pointer(dbg) if dbg is not None else None
+    a.stream = _lib.stream_ptr()
+    _lib.check(L.relpose_match_pairs_ex(C.byref(a)), "relpose_match_pairs_ex")
     return res
 
 

@@ -268,29 +268,52 @@ def test_pipeline_self_stream_cache_gives_the_same_poses():
         assert torch.equal(pose, want[k][0]) and torch.equal(status, want[k][1]), k
 
 
-@pytest.mark.parametrize("slot_cus", [0, 64])
-def test_pipeline_split_forward_three_in_flight_equal_sequential_runs(slot_cus):
-    """The round-5 serving loop: three batches in flight, every SCNet forward enqueued in two halves with the bottleneck chain on a third
-    stream (A.enc B.enc C.enc A.dec B.dec C.dec on the SCNet stream), optionally with CU-masked slot streams -- the poses are bitwise
-    those of `run` batch by batch (same kernels, same data; only the enqueue order and the streams differ)."""
+def test_two_pipelines_in_two_threads_with_different_fit_cluster_equal_their_single_thread_runs():
+    """the fit's workgroups per pair travel WITH the matcher call (RelposeMatchArgs::fit_cluster), not through the process-wide
+    relpose_set_tuning knob round 5 set around the serving loop.  Two pipelines with different settings (1 and 4 workgroups per pair) run their serving
+    loops CONCURRENTLY in two threads of one process; each returns bitwise what it returns alone, and the process-wide knob is never touched.
+    Reference: the call carries its own `para` (RPModule/rpmodule.py:317-326)."""
+    import threading
     import torch
+    from relativepose_amd import _lib
     from relativepose_amd.pipeline import RelativePosePipeline
     dev = torch.device("cuda:0")
     ds, mm, S, tanh = "suncg", "second", 15, 1
-    net = _gpu_net(S, tanh, E2E_WEIGHT_SEED)
-    plain = RelativePosePipeline(net, ds, mm)
-    split = RelativePosePipeline(net, ds, mm, split_forward=True, slot_cus=slot_cus)
-    states, want = [], []
-    for j in range(4):
-        d = synth.make_pairs(2, 1900 + 10 * j, ds)
-        pts, ptw = synth.make_keypoints(2, 60, 1900 + 10 * j, mm)
-        st = plain.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev)
-        pose, status, _ = plain.run(st)
-        states.append(st); want.append((pose.clone(), status.clone()))
-    torch.cuda.synchronize()
-    for depth in (3, 2):
-        res = split.run_pipelined(states, 9, None, depth=depth)
+    pipes, states, want = [], [], []
+    for j, cluster in enumerate((1, 4)):
+        pipe = RelativePosePipeline(_gpu_net(S, tanh, E2E_WEIGHT_SEED), ds, mm, loop_fit_cluster=cluster)
+        sts = []
+        for q in range(2):
+            d = synth.make_pairs(2, 1700 + 10 * j + q, ds)
+            pts, ptw = synth.make_keypoints(2, 120, 1700 + 10 * j + q, mm)      # 600 correspondences per pair: helper workgroups are legal
+            sts.append(pipe.prepare(d["rgb"], d["norm"], d["depth"], pts, ptw, dev))
+        pipes.append(pipe); states.append(sts)
+    for pipe, sts in zip(pipes, states):                                      # alone, one after the other
+        res = pipe.run_pipelined(sts, 6)
         torch.cuda.synchronize()
-        for k, (pose, status) in enumerate(res):
-            assert torch.equal(pose, want[k % 4][0]) and torch.equal(status, want[k % 4][1]), (depth, k)
-    log("pipeline_split_forward", slot_cus=slot_cus, bitwise=True)
+        want.append([(p.clone(), s.clone()) for p, s in res])
+    knob0 = _lib.lib().relpose_set_tuning(_lib.TUNE_KEYS["fit_cluster"], 0)
+    assert knob0 == 0
+    got, errs = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                r = pipes[i].run_pipelined(states[i], 6)
+                torch.cuda.current_stream().synchronize()
+            got[i] = r
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    for rep in range(2):
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errs, errs
+        for i in range(2):
+            for k, (pose, status) in enumerate(got[i]):
+                assert torch.equal(pose, want[i][k][0]) and torch.equal(status, want[i][k][1]), (rep, i, k)
+    assert _lib.lib().relpose_set_tuning(_lib.TUNE_KEYS["fit_cluster"], 0) == 0      # nobody set the process-wide knob
+    log("pipeline_two_threads_fit_cluster", bitwise=True)

@@ -346,59 +346,3 @@ def test_scnet_small_panoramas_resize_out_generic_path(hw):
     err = float(np.abs(got - want).max())
     log("scnet_small_pano", hw=list(hw), max_abs_err=err)
     assert got.shape == want.shape and err < 5e-4
-
-
-def test_scnet_forward_in_two_parts_with_the_chain_on_a_third_stream_is_bitwise_the_forward():
-    """RELPOSE_FWD_PART_FRONT / _BACK (round 5): one forward enqueued by two calls, the bottleneck chain (conv4's split-K reduction ..
-    deconv6) on a third stream, ANOTHER workspace's front half enqueued on the main stream in between -- the order the serving loop
-    produces.  Output and raw layer outputs are bitwise those of the one-call forward, for the full plan, the level-0 plan and the
-    self-cached plan; a BACK without its FRONT, or with other arguments, is refused."""
-    import torch
-    tag, S, tanh, seed, ds, mm = SCNET_CASES[0]
-    net, _ = make_net(S, tanh, seed)
-    xa = torch.cat([torch.from_numpy(oracle_scnet_input(920 + i, ds, mm)).cuda() for i in range(2)])
-    xb = torch.cat([torch.from_numpy(oracle_scnet_input(930 + i, ds, mm)).cuda() for i in range(2)])
-    x0 = xa.clone(); x0[:, 8:] = 0
-    taps = ("A4", "A5", "A9", "D7", "D6", "D5", "D2")
-    ref = {}
-    for name, x, kw in (("full_a", xa, {}), ("full_b", xb, {}), ("zero", x0, dict(zero_warp=True))):
-        y = net.forward(x, **kw).clone()
-        ref[name] = (y, {t: net.read_tap(t).clone() for t in taps})
-    torch.cuda.synchronize()
-    main, mid, tail_a, tail_b = (torch.cuda.Stream() for _ in range(4))
-    for s_ in (main, mid, tail_a, tail_b):
-        s_.wait_stream(torch.cuda.current_stream())
-    out_a = torch.empty_like(ref["full_a"][0]); out_b = torch.empty_like(out_a)
-    ta, tb = net.new_self_tag(), net.new_self_tag()
-
-    def both(xa_, xb_, kwa, kwb):
-        ka = dict(out=out_a, tail_stream=tail_a, ws_key=101, mid_stream=mid, **kwa)
-        kb = dict(out=out_b, tail_stream=tail_b, ws_key=102, mid_stream=mid, **kwb)
-        with torch.cuda.stream(main):
-            net.forward(xa_, part="front", **ka)
-            net.forward(xb_, part="front", **kb)
-            net.forward(xa_, part="back", **ka)
-            net.forward(xb_, part="back", **kb)
-        torch.cuda.synchronize()
-
-    both(x0, xb, dict(zero_warp=True, self_tag=ta), dict(self_tag=tb))              # level 0 of a | a full tagged forward of b
-    assert torch.equal(out_a, ref["zero"][0]) and torch.equal(out_b, ref["full_b"][0])
-    both(xa, xb, dict(self_tag=ta), dict(self_tag=tb))                               # both self-cached now
-    assert torch.equal(out_a, ref["full_a"][0]) and torch.equal(out_b, ref["full_b"][0])
-    # raw layer outputs of workspace 102 (the last forward on it), read on its own streams' completion
-    net._workspace(xb.shape[0], xb.shape[2], xb.shape[3], xb.device, 102)
-    for t in taps:
-        assert torch.equal(net.read_tap(t), ref["full_b"][1][t]), t
-    # the one-call forward with a chain stream
-    with torch.cuda.stream(main):
-        y = net.forward(xa, tail_stream=tail_a, ws_key=101, mid_stream=mid)
-    torch.cuda.synchronize()
-    assert torch.equal(y, ref["full_a"][0])
-    # protocol errors: a BACK nobody started, a BACK with another tag
-    with pytest.raises(RuntimeError):
-        net.forward(xa, out=out_a, ws_key=101, part="back")
-    net.forward(xa, out=out_a, ws_key=101, part="front", self_tag=ta)
-    with pytest.raises(RuntimeError):
-        net.forward(xa, out=out_a, ws_key=101, part="back", self_tag=tb)
-    torch.cuda.synchronize()
-    log("scnet_forward_two_parts", images=int(xa.shape[0]), bitwise=True)

@@ -4,6 +4,7 @@
 #   layers P   : per-layer trace of one full forward in precision P (f32 | bf16x9 | bf16x6 | f16x3 | f16)
 #   bench ARGS : one bench line (python bench.py ARGS), last line kept in gpurun_out/bench_last.json
 #   suite      : the whole -m gpu suite + its parity log
+#   sq P       : SQ counter passes (MFMA busy, waits, LDS) of one forward in precision P -> gpurun_out/r06_scnet_sq_pmc_P.txt
 cd /tmp; export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -37,6 +38,16 @@ PY
   ;;
 layers) layers $1 ;;
 bench) timeout 900 python bench.py "$@" 2>&1 | tail -1 | tee gpurun_out/bench_last.json | cut -c1-600 ;;
+sq)
+  P=$1
+  run() { name=$1; shift; rm -rf gpurun_out/sq_$name; timeout 400 rocprofv3 --pmc "$@" --kernel-trace -d gpurun_out/sq_$name -o p -- python tools/scnet_only.py 64 2 $P > gpurun_out/sq_$name.log 2>&1; }
+  run a SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
+  run b SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_LDS_ADDR_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE
+  { echo "# rocprofv3 --pmc (own runs, --kernel-trace only) -- python tools/scnet_only.py 64 2 $P ; last forward; percentages = fractions of SQ_WAVE_CYCLES";
+    python tools/sq_summary.py gpurun_out/sq_a/p_results.db; echo "# LDS pass"; python tools/sq_summary.py gpurun_out/sq_b/p_results.db; } > gpurun_out/r06_scnet_sq_pmc_$P.txt 2>&1
+  rm -rf gpurun_out/sq_a gpurun_out/sq_b
+  cut -c1-330 gpurun_out/r06_scnet_sq_pmc_$P.txt
+  ;;
 suite)
   timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee gpurun_out/r06_gpu_suite_summary.txt
   ;;
