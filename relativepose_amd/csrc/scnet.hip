@@ -64,6 +64,22 @@ typedef float rp_f4v __attribute__((ext_vector_type(4)));
 #ifndef RP_AGPR
 #define RP_AGPR 0               // 1 = fp32 MFMA accumulators in AccVGPRs through inline asm (experiment)
 #endif
+#ifndef RP_TWO_CHAIN
+#define RP_TWO_CHAIN 0          // one-accumulator tiles in the split modes: 1 = small / large terms on two accumulator chains (rp_split_mma), 0 = one chain, 2 = only in the three-piece modes
+#endif
+#ifndef RP_TILE_ABLATE
+#define RP_TILE_ABLATE 0
+#endif
+#ifndef RP_SLOT_PRIO
+#define RP_SLOT_PRIO 0          // experiment: 1 = waves in odd hardware wave slots of their SIMD raise their priority (breaks the symmetry of co-resident workgroups)
+#endif
+// HW_REG_HW_ID (id 4) bits [3:0] = the wave's slot on its SIMD: s_getreg_b32 hwreg(4, 0, 4)
+#define RP_WAVE_SLOT() (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15)
+#define RP_APPLY_SLOT_PRIO()                                                      \
+    do {                                                                          \
+        if (RP_SLOT_PRIO == 1) { if (RP_WAVE_SLOT() & 1) __builtin_amdgcn_s_setprio(2); }                                  \
+        else if (RP_SLOT_PRIO == 2) { const unsigned sl_ = RP_WAVE_SLOT(); if (sl_ == 0) __builtin_amdgcn_s_setprio(3); else if (sl_ == 1) __builtin_amdgcn_s_setprio(2); else if (sl_ == 2) __builtin_amdgcn_s_setprio(1); } \
+    } while (0)
 #ifndef RP_STAGGER
 #define RP_STAGGER 0            // 0 = off; n = workgroups (blockIdx.x / n) % 3 get a start offset (see the k-loop prologue)
 #endif
@@ -137,20 +153,81 @@ __device__ __forceinline__ float2 rp_bufld2(__amdgpu_buffer_rsrc_t r, int voff, 
     return make_float2(f[0], f[1]);
 }
 
-// the partial products of one 16-channel step of the three-piece modes on ONE accumulator, smallest magnitude first
+// ---- the split-operand contraction of one staged 32-channel chunk (one tap) for MI x NI accumulators --------------------------------------
+// Staged rows hold NP pieces of 32 16-bit values each ([hi | lo] or [hi | mid | lo], 64 bytes per piece); a 16-channel step reads one 16-byte
+// fragment per piece and row and issues the mode's partial products as v_mfma_f32_32x32x16_{f16,bf16}:
+//   SPLIT 1 / 2 (x3): lo hi, hi lo, hi hi       SPLIT 3 (plain f16): hi hi       SPLIT 5 (bf16x6): lo hi, hi lo, mid mid, mid hi, hi mid, hi hi
+//   SPLIT 4 (bf16x9): lo lo, lo mid, mid lo, then the six of SPLIT 5
+// A dependent v_mfma_f32_32x32x16 (same accumulator) issues 40 cycles after its predecessor, an independent one after 32 (measured,
+// profiles/r06_mfma_bf16_chain.txt: 43.4 vs 38.1 "cycles" per MFMA for one wave per SIMD), and with one accumulator per wave every MFMA
+// of the round-5 kernels depended on the previous one (SQ_WAIT_INST_ANY 45-55 % of wave-cycles at 52-58 % MFMA busy,
+// profiles/r06_scnet_sq_pmc_bf16x6_v1.txt).  So consecutive MFMAs never share an accumulator here:
+//   MI NI > 1: term-major order -- every term runs over all MI x NI accumulators before the next term;
+//   MI NI = 1: TWO chains -- the small terms accumulate in a temporary that starts at 0 (an inline constant) and is added to the
+//              accumulator once per call (16 VALU adds per 12-18 MFMAs), the large terms go to the accumulator itself, alternating.
+// The summation order is fixed per instantiation, so the results stay deterministic and plan-invariant (the self-stream cache and the
+// level-0 plan run the same calls in the same order as the full forward).
+template <int SPLIT> struct SplitTerms;
+template <> struct SplitTerms<1> { static constexpr int NP = 2, NT = 3, NSMALL = 2; static constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0}; };
+template <> struct SplitTerms<2> { static constexpr int NP = 2, NT = 3, NSMALL = 2; static constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0}; };
+template <> struct SplitTerms<3> { static constexpr int NP = 1, NT = 1, NSMALL = 0; static constexpr int ta[1] = {0}, tb[1] = {0}; };
+template <> struct SplitTerms<4> { static constexpr int NP = 3, NT = 9, NSMALL = 5;
+                                   static constexpr int ta[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, tb[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; };
+template <> struct SplitTerms<5> { static constexpr int NP = 3, NT = 6, NSMALL = 3;
+                                   static constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0}; };
 template <int SPLIT>
-__device__ __forceinline__ void rp_mma3(floatx16& acc, const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
-    if constexpr (SPLIT == 4) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bm, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bl, acc, 0, 0, 0);
+__device__ __forceinline__ floatx16 rp_mfma16(const typename SplitT<SPLIT>::v8& a, const typename SplitT<SPLIT>::v8& b, const floatx16& c) {
+    if constexpr (SPLIT == 2 || SPLIT == 3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int SPLIT, int MI, int NI>
+__device__ __forceinline__ void rp_split_mma(floatx16 (&acc)[MI][NI], const float* At, const int (&a_rows)[MI], const float* Bt, const int (&b_rows)[NI]) {
+    typedef typename SplitT<SPLIT>::v8 h8;
+    typedef SplitTerms<SPLIT> TT;
+    constexpr int NP = TT::NP, NT = TT::NT, NS = TT::NSMALL, NL = NT - NS;
+    if constexpr (MI * NI == 1 && NS > 0 && (RP_TWO_CHAIN == 1 || (RP_TWO_CHAIN == 2 && SPLIT >= 4))) {
+        floatx16 tmp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            h8 a[NP], b[NP];
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+                a[pc] = *reinterpret_cast<const h8*>(&At[a_rows[0] + pc * 16 + st * 8]);
+                b[pc] = *reinterpret_cast<const h8*>(&Bt[b_rows[0] + pc * 16 + st * 8]);
+            }
+            // small term, large term, small term, ... (the small terms in ascending size, then the large ones in ascending size)
+#pragma unroll
+            for (int k = 0; k < (NS > NL ? NS : NL); ++k) {
+                if (k < NS) tmp = rp_mfma16<SPLIT>(a[TT::ta[k]], b[TT::tb[k]], tmp);
+                if (k < NL) acc[0][0] = rp_mfma16<SPLIT>(a[TT::ta[NS + k]], b[TT::tb[NS + k]], acc[0][0]);
+            }
+            // (keep the scheduler from hoisting the next steps' fragment reads above these MFMAs: with four phases of accumulators live the
+            // tile kernels have no registers for a second set of fragments -- it spilled 18-125 registers without this fence)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += tmp[r];
+    } else {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            h8 a[NP][MI], b[NP][NI];
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[pc][i] = *reinterpret_cast<const h8*>(&At[a_rows[i] + pc * 16 + st * 8]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[pc][j] = *reinterpret_cast<const h8*>(&Bt[b_rows[j] + pc * 16 + st * 8]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = rp_mfma16<SPLIT>(a[TT::ta[t]][i], b[TT::tb[t]][j], acc[i][j]);
+        }
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
 // Tile: WM x WN waves (WM*WN = 4), each wave MI x NI MFMA 32x32 blocks.
@@ -387,61 +464,14 @@ __global__ __launch_bounds__(WM * WN * 64, (NI == 4 || SPLIT >= 4) ? 2 : ((WM * 
 #if RP_ABLATE != 2 && RP_ABLATE != 5
         if (kt + 1 < nkt) RP_ISSUE_LOADS(kt + 1)
 #endif
-        if constexpr (SPLIT >= 4) {
-            // exact-product emulation: nine (six) bf16 MFMA terms per 16-channel step, smallest first
+        if constexpr (SPLIT != 0) {
+            // split-operand modes: 3 / 1 / 9 / 6 16-bit MFMA terms per product and 16-channel step (rp_split_mma: no two consecutive MFMAs share an accumulator)
+            int ar_[MI], br_[NI];
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                bf16x8 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
+            for (int i = 0; i < MI; ++i) ar_[i] = arow + i * 32 * LD;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    ah[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LD + st * 8]);
-                    am[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LD + 16 + st * 8]);
-                    al[i] = *reinterpret_cast<const bf16x8*>(&As[buf][arow + i * 32 * LD + 32 + st * 8]);
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LD + st * 8]);
-                    bm[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LD + 16 + st * 8]);
-                    bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[buf][brow + j * 32 * LD + 32 + st * 8]);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) rp_mma3<SPLIT>(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
-            }
-        } else if constexpr (SPLIT != 0) {
-            // x3 split: a*b ~= hi*hi + hi*lo + lo*hi on the 16-bit MFMA (fp32 accumulate), 2 steps of 16 k per tile
-            typedef typename SplitT<SPLIT>::v8 h8;
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                h8 ah[MI], al[MI], bh[NI], bl[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    ah[i] = *reinterpret_cast<const h8*>(&As[buf][arow + i * 32 * LDK + st * 8]);
-                    if (SPLIT != 3) al[i] = *reinterpret_cast<const h8*>(&As[buf][arow + i * 32 * LDK + 16 + st * 8]);
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    bh[j] = *reinterpret_cast<const h8*>(&Bs[buf][brow + j * 32 * LDK + st * 8]);
-                    if (SPLIT != 3) bl[j] = *reinterpret_cast<const h8*>(&Bs[buf][brow + j * 32 * LDK + 16 + st * 8]);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        if constexpr (SPLIT == 3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        } else if constexpr (SPLIT == 1) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        } else {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        }
-                    }
-            }
+            for (int j = 0; j < NI; ++j) br_[j] = brow + j * 32 * LD;
+            rp_split_mma<SPLIT, MI, NI>(acc, &As[buf][0], ar_, &Bs[buf][0], br_);
         } else
 #if RP_AGPR
         {   // experiment: accumulators pinned to AccVGPRs (the compiler picks the ArchVGPR form of the MFMA); fragments of step
@@ -657,56 +687,7 @@ __device__ __forceinline__ void rp_tile_mma(floatx16 (&acc)[MI][NI], const float
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-    } else if constexpr (SPLIT >= 4) {
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            bf16x8 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(&At[a_rows[i] + st * 8]);
-                am[i] = *reinterpret_cast<const bf16x8*>(&At[a_rows[i] + 16 + st * 8]);
-                al[i] = *reinterpret_cast<const bf16x8*>(&At[a_rows[i] + 32 + st * 8]);
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_rows[j] + st * 8]);
-                bm[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_rows[j] + 16 + st * 8]);
-                bl[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_rows[j] + 32 + st * 8]);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) rp_mma3<SPLIT>(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
-        }
-    } else {
-        typedef typename SplitT<SPLIT>::v8 h8;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            h8 ah[MI], al[MI], bh[NI], bl[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const h8*>(&At[a_rows[i] + st * 8]);
-                if (SPLIT != 3) al[i] = *reinterpret_cast<const h8*>(&At[a_rows[i] + 16 + st * 8]);
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                bh[j] = *reinterpret_cast<const h8*>(&Bt[b_rows[j] + st * 8]);
-                if (SPLIT != 3) bl[j] = *reinterpret_cast<const h8*>(&Bt[b_rows[j] + 16 + st * 8]);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if constexpr (SPLIT == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-                }
-        }
-    }
+    } else rp_split_mma<SPLIT, MI, NI>(acc, At, a_rows, Bt, b_rows);
 }
 
 // ---- stride-2 4x4 transposed conv, the four sub-pixel phases of a spatial patch in ONE workgroup -------------------------
@@ -750,6 +731,7 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
     __shared__ __attribute__((aligned(16))) float At[NPIX * LD];
     __shared__ __attribute__((aligned(16))) float Bt[4 * NI * 32 * LD];
     __shared__ __attribute__((aligned(16))) float sstab[2 * 512];   // per 4 channels: 4 scales, then 4 shifts
+    RP_APPLY_SLOT_PRIO();
     const ConvDesc* dh = descs + blockIdx.y * 4;
     const ConvDesc d = dh[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
@@ -919,7 +901,8 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
                 if (S3) *reinterpret_cast<float2*>(&Bt[b_lds0 + 32 - kqa * 2 + it * PSTEP * LD]) = RBL[S3 ? it : 0]; \
             }                                                                                                 \
     }
-    if constexpr (SPLIT != 0 && PAIR) {       // (deconv3's variant, which has the registers for it at 2 workgroups per CU; <1, 1> 8 x 16: no gain,
+    if constexpr (SPLIT != 0 && SPLIT < 4 && PAIR) {       // (three-piece modes: a phase is 48-72 MFMAs, the plain one-phase-ahead prefetch below is deep enough and needs one weight register set)
+                                              // (deconv3's variant, which has the registers for it at 2 workgroups per CU; <1, 1> 8 x 16: no gain,
                                               // <1, 2>: two weight sets + 128 accumulators spill, 896 -> 1415 us)
         // 16-bit modes: a phase is 24 MFMAs of 32 cycles (fp32: 64 of 64), shorter than a trip to L2, so the register prefetch runs
         // deeper: the weights of phase q + 2 are requested at the top of phase q (two register sets, alternating by phase parity) and
@@ -1076,6 +1059,7 @@ __global__ __launch_bounds__(256, SPLIT >= 4 ? 2 : (MI * NI <= 2 ? 4 : 3)) void 
     __shared__ __attribute__((aligned(16))) float At[NPIX * LD];
     __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LD];
     __shared__ __attribute__((aligned(16))) float sstab[2 * 128];
+    RP_APPLY_SLOT_PRIO();
     const ConvDesc d = descs[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ppx = d.Wp / PW, ppi = (d.Hp / PR) * ppx;
@@ -1212,10 +1196,12 @@ __global__ __launch_bounds__(256, SPLIT >= 4 ? 2 : (MI * NI <= 2 ? 4 : 3)) void 
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int sidx = cp * 4 + tt;
-            if (sidx + 1 < nstep) RP_S2_LOAD_B(sidx + 1)
-            if (tt == 0 && !lastp) RP_S2_LOAD_A((cp + 1) >> 2, (cp + 1) & 3)
+            // (RP_TILE_ABLATE: timing decomposition of this loop, experiments only -- 1 = no MFMAs / fragment reads, 2 = no staging (global loads,
+            // transforms, LDS stores), 3 = no barriers, 4 = weights staged but the A tile never re-staged; results are wrong in every one of them)
+            if (RP_TILE_ABLATE != 2) { if (sidx + 1 < nstep) RP_S2_LOAD_B(sidx + 1) }
+            if (RP_TILE_ABLATE != 2 && RP_TILE_ABLATE != 4) { if (tt == 0 && !lastp) RP_S2_LOAD_A((cp + 1) >> 2, (cp + 1) & 3) }
             const int aoff = ((tt >> 1) * HW1 + (tt & 1)) * LD;
-            {
+            if (RP_TILE_ABLATE != 1) {
                 int ar_[MI], br_[NI];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) ar_[i] = arow[i] + aoff;
@@ -1223,10 +1209,10 @@ __global__ __launch_bounds__(256, SPLIT >= 4 ? 2 : (MI * NI <= 2 ? 4 : 3)) void 
                 for (int j = 0; j < NI; ++j) br_[j] = brow + j * 32 * LD;
                 rp_tile_mma<SPLIT, MI, NI>(acc, At, ar_, Bt, br_);
             }
-            __syncthreads();
-            if (sidx + 1 < nstep) RP_S2_STORE_B()
-            if (tt == 3 && !lastp) RP_S2_STORE_A((cp + 1) >> 2, (cp + 1) & 3)
-            __syncthreads();
+            if (RP_TILE_ABLATE != 3) __syncthreads();
+            if (RP_TILE_ABLATE != 2) { if (sidx + 1 < nstep) RP_S2_STORE_B() }
+            if (RP_TILE_ABLATE != 2 && RP_TILE_ABLATE != 4) { if (tt == 3 && !lastp) RP_S2_STORE_A((cp + 1) >> 2, (cp + 1) & 3) }
+            if (RP_TILE_ABLATE != 3) __syncthreads();
         }
         (void)ch; (void)pl;
     }
@@ -1297,6 +1283,7 @@ __global__ __launch_bounds__(256, SPLIT >= 4 ? 2 : 3) void conv_s2_strip_kernel(
     static_assert(BK == 32 && SMAX % PSTEP == 0 && B_ROWS % PSTEP == 0, "slot layout");
     __shared__ __attribute__((aligned(16))) float At[SMAX * LD];
     __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LD];
+    RP_APPLY_SLOT_PRIO();
     const ConvDesc d = descs[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ks = blockIdx.y / d.ntiles_n, n0 = (blockIdx.y - ks * d.ntiles_n) * NI * 32;

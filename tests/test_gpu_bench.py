@@ -119,16 +119,17 @@ def test_bench_rccl_two_gpus_weak_and_strong():
 
 @pytest.mark.parametrize("config", [2, 3, 4])
 def test_bench_other_baseline_configs_run(config):
-    """--config 2|3|4 (Matterport N=400, ScanNet/kinect, SUNCG 320x1280 + f16x3) produce a line naming their workload; small batch."""
+    """--config 2|3|4 (Matterport N=400, ScanNet/kinect -- bf16x6 conv arithmetic --, SUNCG 320x1280 + f16x3) produce a line naming their workload; small batch."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--pairs", "2", "--steps", "2", "--warmup", "1",
                           "--no-cpu-baseline", "--no-aux", "--batches", "2"], capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     c = r["config"]
     assert c["baseline_config_index"] == config and r["status_ok_fraction"] == 1.0 and "pcie_inclusive" in r
-    want = {2: ("matterport", "second", "160x640", 400, "f32"), 3: ("scannet", "kinect", "160x640", 200, "f32"), 4: ("suncg", "second", "320x1280", 200, "f16x3")}[config]
+    want = {2: ("matterport", "second", "160x640", 400, "bf16x6"), 3: ("scannet", "kinect", "160x640", 200, "bf16x6"), 4: ("suncg", "second", "320x1280", 200, "f16x3")}[config]
     assert (c["dataset"], c["mask"], c["pano"], c["keypoints"], c["conv_precision"]) == want
-    assert (r["dtype"] == "f32") == (config != 4)
+    # configs 1-3: fp32 products emulated with full-width operands (the dtype string names the arithmetic); configs[4]: the 3-term fp16 path
+    assert r["dtype"].startswith("f32 (fp32 products on the bf16 matrix pipe") == (config != 4)
 
 
 def test_sharded_evaluation_eight_ranks_equal_one_rank(tmp_path):

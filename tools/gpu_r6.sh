@@ -37,6 +37,19 @@ PY
   done
   ;;
 layers) layers $1 ;;
+ab)    # A/B of library variants on the per-layer trace: bash tools/gpu_r6.sh ab PREC name1 [name2 ...]  (relativepose_amd/librelpose_hip_<name>.so; "main" = the product library)
+  P=$1; shift
+  for v in "$@"; do
+    if [ "$v" = main ]; then unset RELPOSE_LIB_PATH; else export RELPOSE_LIB_PATH=$GRAFT_REPO_ROOT/relativepose_amd/librelpose_hip_$v.so; fi
+    echo "=== variant $v ($P)"
+    rm -rf gpurun_out/prof_ab
+    timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_ab -o p -- python tools/scnet_only.py 64 3 $P > gpurun_out/prof_ab.log 2>&1
+    python tools/kernel_stats.py gpurun_out/prof_ab/p_results.db 64 > gpurun_out/r06_ab_${v}_$P.txt 2>&1
+    rm -rf gpurun_out/prof_ab
+    tail -21 gpurun_out/r06_ab_${v}_$P.txt | cut -c1-110
+  done
+  unset RELPOSE_LIB_PATH
+  ;;
 bench) timeout 900 python bench.py "$@" 2>&1 | tail -1 | tee gpurun_out/bench_last.json | cut -c1-600 ;;
 sq)
   P=$1
