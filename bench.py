@@ -45,10 +45,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X dense fp32 matrix peak (MI355X_MICRO
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16 / bf16
 MFMA_TERMS = {"bf16x3": 3, "f16x3": 3, "bf16x9": 9, "bf16x6": 6}      # 16-bit MFMA products issued per fp32 product
 DTYPE_EXACT = {
-    "bf16x9": "f32 (exact fp32 products on the bf16 matrix pipe: both operands cut into three bf16 pieces = all 24 significand bits, all nine partial "
-              "products issued as v_mfma_f32_32x32x16_bf16, each exact in the fp32 accumulator; fp32 accumulation, activations, BatchNorm statistics, conv1, heads)",
-    "bf16x6": "f32 (fp32 products on the bf16 matrix pipe: both operands cut into three bf16 pieces = all 24 significand bits, the six partial products "
-              ">= 2^-16 |a b| issued as v_mfma_f32_32x32x16_bf16, the three <= 2^-24 |a b| dropped; fp32 accumulation, activations, BatchNorm statistics, conv1, heads)",
+    "bf16x9": "f32 (fp32 products emulated on the bf16 matrix pipe: every operand cut into 3 bf16 pieces = its full 24 significand bits, all 9 partial products "
+              "issued as v_mfma_f32_32x32x16_bf16, each exact in the fp32 accumulator; fp32 accumulation / activations / BatchNorm statistics / conv1 / heads)",
+    "bf16x6": "f32 (fp32 products emulated on the bf16 matrix pipe: every operand cut into 3 bf16 pieces = its full 24 significand bits, the 6 partial products "
+              ">= 2^-16 |ab| issued as v_mfma_f32_32x32x16_bf16, the 3 below 2^-24 |ab| dropped: a product error <= 2^-25 |ab|, under the rounding of an fp32 "
+              "multiply; fp32 accumulation / activations / BatchNorm statistics / conv1 / heads; --precision f32 = the fp32 MFMA kernels)",
 }
 PEAK_HBM_GBS = 8000.0
 
@@ -57,6 +58,12 @@ CONFIGS = {
     # conv arithmetic of configs 1-3 (round 6): "bf16x6" -- fp32 products emulated on the bf16 matrix pipe with every operand at its full 24 bits
     # (DTYPE_EXACT; each product at least as accurate as a correctly rounded fp32 multiply, fp32 accumulation); --precision f32 runs the fp32 MFMA
     # kernels of rounds 1-5, --precision bf16x9 the all-nine-terms form (exact products).  Parity of all three: tests/test_gpu_scnet.py, test_gpu_e2e.py.
+    # configs[0]: the reference's own CPU-runnable plumbing case -- `evaluation.py --method=ours` on 4 SUNCG pairs (160x640, rgbdnsf); here the 4 pairs
+    # and N = 80 keypoints of the e2e fixtures (tests/golden/e2e.npz pins exactly this workload to the reference).  A latency-shaped line (one
+    # 4-pair batch per step does not fill the chip); the headline is configs[1].
+    0: dict(dataset="suncg", mask="second", h=160, N=80, S=15, tanh=1, pairs=4, precision="bf16x6", cpu_pairs=4,
+            label="evaluation.py --method=ours on 4 SUNCG pairs, 160x640 rgbdnsf, N=80 keypoints, alterStep=3 (BASELINE configs[0]: the reference's CPU-runnable case)",
+            parity_note="tests/golden/e2e.npz: these 4 pairs x 3 levels captured from the reference (tests/test_gpu_e2e.py, test_gpu_pipeline.py)"),
     1: dict(dataset="suncg", mask="second", h=160, N=200, S=15, tanh=1, pairs=32, precision="bf16x6", cpu_pairs=9,
             label="SUNCG 160x640, N=200 keypoints, batch=32 pairs per GPU, alterStep=3 (BASELINE configs[1])"),
     2: dict(dataset="matterport", mask="second", h=160, N=400, S=21, tanh=1, pairs=32, precision="bf16x6", cpu_pairs=3,
@@ -229,6 +236,41 @@ def geometry_roofline(cfg, n_img, N, dev, net_out_channels, feat_off):
     return out
 
 
+def _shared_state_dict(seed, S, rank, world):
+    """The random-init weights, generated ONCE per node and shared between the ranks (48.5 M floats: 2.3 s of numpy per rank otherwise, on
+    a host whose cores the 8 ranks also need for their input panoramas): rank 0 writes them to a file in shared memory, the others wait for it
+    behind the launcher's barrier.  A single rank (or any failure of the shared path) just generates them."""
+    from relativepose_amd import weights
+    if world == 1:
+        return weights.make_state_dict(seed, S)
+    import tempfile
+    import torch.distributed as dist
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(base, f"relpose_bench_weights_{os.environ.get('MASTER_PORT', '0')}_{seed}_{S}.npz")
+    sd = None
+    if rank == 0:
+        sd = weights.make_state_dict(seed, S)
+        try:
+            np.savez(path + ".tmp.npz", **sd)
+            os.replace(path + ".tmp.npz", path)
+        except OSError:
+            path = None
+    dist.barrier()
+    if rank != 0:
+        try:
+            with np.load(path) as z:
+                sd = {k: z[k] for k in z.files}
+        except Exception:       # noqa: BLE001 (rank 0 could not write it: every rank generates its own)
+            sd = weights.make_state_dict(seed, S)
+    dist.barrier()
+    if rank == 0 and path:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return sd
+
+
 def worker(args):
     if args.hw_queues > 0:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)      # (read by the HIP runtime when it initialises: before the first torch.cuda call)
@@ -243,6 +285,20 @@ def worker(args):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher provides WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        # one line per rank BEFORE any GPU work: which device this rank sits on, what it can reach over xGMI, which RCCL it runs -- so that a
+        # multi-GPU run that dies or hangs later still says where every rank was (the JSON line carries rank 0's view only)
+        import torch.distributed as dist
+        pa = D.peer_access_summary()
+        ri = D.rccl_info()
+        try:
+            prop = torch.cuda.get_device_properties(local)
+            devname = f"{prop.name}, {prop.total_memory / 2**30:.0f} GiB, {prop.multi_processor_count} CUs"
+        except Exception as e:      # noqa: BLE001
+            devname = f"unknown ({type(e).__name__})"
+        print(f"[bench rank {rank}/{world}] cuda:{local} ({devname}); visible GPUs {pa.get('gpus')}, peer-accessible pairs {pa.get('peer_accessible')}/{pa.get('peer_pairs')}; "
+              f"backend {dist.get_backend()} (RCCL {ri['rccl_version']}); MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}, "
+              f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
     cfg = dict(CONFIGS[args.config])
     prec = args.precision or cfg["precision"]
     ds, mm, h, S = cfg["dataset"], cfg["mask"], cfg["h"], cfg["S"]
@@ -263,7 +319,7 @@ def worker(args):
 
     # synthetic inputs + random-init weights (no dataset / checkpoint ships with the reference)
     net = SCNet(SimpleNamespace(batchnorm=1, useTanh=cfg["tanh"], skipLayer=1, outputType="rgbdnsf", snumclass=S))
-    net.load_state_dict(weights.make_state_dict(7, S))
+    net.load_state_dict(_shared_state_dict(7, S, rank, world))
     net.set_precision(prec)
     Cc = N * 5
     pipe = RelativePosePipeline(net, ds, mm, sigmas, max_edges=min(Cc * (Cc - 1), (1 << 20) * max(1, (N // 200) ** 2)),
@@ -475,10 +531,24 @@ def worker(args):
             a_small = affinity_roofline(N, nloc, dev, sigmas)
             a_big = affinity_roofline(N, 1024, dev, sigmas)
             tra = _traffic(f"affinity_b1024_n{N}")
+            ins = _traffic(f"affinity_b1024_n{N}_insts")
+            valu = None
+            if ins:
+                # the bound this kernel actually runs against: VALU issue.  Every VALU wave-instruction takes one 4-cycle issue slot
+                # of its SIMD, so wave_insts x 4 / (1024 SIMDs x 2.4 GHz) is the time the kernel cannot beat without issuing fewer instructions
+                floor_us = ins["valu"] * 4.0 / (1024 * 2.4e9) * 1e6
+                valu = {"wave_insts": ins["valu"], "salu_wave_insts": ins["salu"], "floor_us": floor_us, "measured_us": a_big["ms_per_launch"] * 1e3,
+                        "frac": floor_us / (a_big["ms_per_launch"] * 1e3), "lane_ops_per_entry": (ins["valu"] + ins["salu"]) * 64 / ins["entries"],
+                        "mfma_screened_entries_over_real": ins["mfma_screened_entries"] / ins["entries"],
+                        "hbm_frac_at_the_valu_floor": a_big["algorithmic_bytes_per_launch"] / (floor_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                        "profile": ins["profile"],
+                        "note": "frac = floor_us / measured_us: the share of the launch the VALU issue slots alone account for; at the floor the kernel would reach "
+                                "hbm_frac_at_the_valu_floor of HBM peak -- the >= 0.60 HBM target needs fewer instructions, not more bandwidth"}
             res["roofline_affinity"] = {"kernel": "affinity_tile_kernel + fix-up scan (batch 1024) / affinity_rows_kernel (bench batch), materialised fp32 wij", "bound": "hbm", "unit": "GB/s",
                                         "peak": PEAK_HBM_GBS, "achieved": a_big["achieved"], "frac": a_big["frac"],
                                         "traffic": tra["bytes"] if tra else None, "traffic_unit": "HBM bytes per launch at batch 1024 (rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                                         "traffic_profile": tra["profile"] if tra else None,
+                                        "valu": valu,
                                         "at_batch_1024": a_big, "at_bench_batch": a_small,
                                         "fused_at_batch_1024": affinity_roofline(N, 1024, dev, sigmas, want_wij=False),
                                         "note": "headline = batch 1024 (one launch at the bench batch moves only "

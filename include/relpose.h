@@ -257,12 +257,19 @@ int relpose_nms_sampling(const float* dist, double* pts, int32_t nmaps, int32_t 
  *   q_map_view [nq] the view whose map it searches, queries grouped by that view: q_off [n_views+1]; nq_view_max = max group size
  *   slot_kind [n_views,L]: the keypoint slots of every view in the reference's concatenation order: -1 empty, -2 a host coordinate
  *   (slot_xy [n_views,L,2]: SIFT detections, random points), >= 0 the pick with linear index query * topk + k
- * Outputs: pts [n_views,L,2] f64 pixel coordinates (x,y) compacted in slot order, weight [n_views,L] f64, npts [n_views]. */
+ * Outputs: pts [n_views,L,2] f64 pixel coordinates (x,y) compacted in slot order, weight [n_views,L] f64, npts [n_views].
+ * flags: RELPOSE_KP_OBSERVED_ONLY = getMatchingPrimitive(..., doCompletion = 0), rpmodule.py:534-537 (the 'ours_nc' method, evaluation.py:74): only
+ * the keypoints of weight 1 (inside the observed region) are kept -- the reference filters the sampled primitives by ptsW == 1, which is the same
+ * selection in the same order.  nq = 0 is legal (round 6): a batch whose views have no SIFT detections has no queries; a view whose slots are
+ * all empty gets npts = 0 and its pair the matcher's "return identity" status, like the reference (rputil.py:156-166, rpmodule.py:522-523,
+ * evaluation.py:280-282).  nq_view_max <= RELPOSE_KP_MAX_QUERIES_PER_VIEW (the per-view query descriptors and running bests live in LDS). */
+enum { RELPOSE_KP_OBSERVED_ONLY = 1 };
+#define RELPOSE_KP_MAX_QUERIES_PER_VIEW 1000
 size_t relpose_keypoints_reference_workspace_bytes(int32_t nq, int32_t H, int32_t W, int32_t topk);
 int relpose_keypoints_reference(const float* f, int64_t image_stride, int32_t feat_off, int32_t n_views, int32_t H, int32_t W,
                                 const int32_t* q_src_view, const float* q_pt, const int32_t* q_map_view, const int32_t* q_off, int32_t nq,
                                 int32_t nq_view_max, int32_t topk, int32_t window, const int32_t* slot_kind, const double* slot_xy, int32_t L,
-                                int32_t mask_method, double* pts, double* weight, int32_t* npts, void* workspace, size_t workspace_bytes,
+                                int32_t mask_method, int32_t flags, double* pts, double* weight, int32_t* npts, void* workspace, size_t workspace_bytes,
                                 void* stream);
 
 /* -------------------------------------------------------------------- SCNet

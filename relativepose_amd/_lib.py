@@ -74,7 +74,7 @@ SIGNATURES = {
     "relpose_nms_sampling": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "relpose_keypoints_reference_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "relpose_keypoints_reference": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                            c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                            c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "relpose_scnet_create": (c_void_p, [c_int, c_int]),
     "relpose_scnet_destroy": (None, [c_void_p]),
     "relpose_scnet_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),

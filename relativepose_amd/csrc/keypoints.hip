@@ -17,6 +17,7 @@
 // Compiled with -ffp-contract=off: the float32 distance and the bilinear gather must round like torch (no FMA fusion).
 #include "common.h"
 #include <limits.h>
+#include <algorithm>
 
 namespace {
 
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void kp_pick_kernel(const float* __restrict__ 
 // the observed region, 0.99 (MARKER) outside (:226-235 / :341-351: both bounds inclusive).
 __global__ __launch_bounds__(64) void kp_assemble_kernel(const int* __restrict__ slot_kind, const double* __restrict__ slot_xy, int L,
                                                           const int* __restrict__ picks, int H, int W, double bx0, double bx1, double by0,
-                                                          double by1, double* __restrict__ pts, double* __restrict__ weight,
+                                                          double by1, int observed_only, double* __restrict__ pts, double* __restrict__ weight,
                                                           int* __restrict__ npts) {
     const int v = blockIdx.x, lane = threadIdx.x;
     int base = 0;
@@ -219,11 +220,13 @@ __global__ __launch_bounds__(64) void kp_assemble_kernel(const int* __restrict__
             x = (double)picks[(size_t)kind * 2]; y = (double)picks[(size_t)kind * 2 + 1];
             ok = x < (double)(W - 1) && y < (double)(H - 1);
         }
+        const bool inside = x >= bx0 && x <= bx1 && y >= by0 && y <= by1;
+        if (observed_only) ok = ok && inside;          // doCompletion = 0 (rpmodule.py:534-537): the weight-1 keypoints, in their order
         const unsigned long long m = __ballot(ok);
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
         if (ok) {
             pts[((size_t)v * L + pos) * 2] = x; pts[((size_t)v * L + pos) * 2 + 1] = y;
-            weight[(size_t)v * L + pos] = (x >= bx0 && x <= bx1 && y >= by0 && y <= by1) ? 1.0 : 0.99;
+            weight[(size_t)v * L + pos] = inside ? 1.0 : 0.99;
         }
         base += __popcll(m);
     }
@@ -255,31 +258,39 @@ size_t relpose_keypoints_reference_workspace_bytes(int32_t nq, int32_t H, int32_
 int relpose_keypoints_reference(const float* f, int64_t image_stride, int32_t feat_off, int32_t n_views, int32_t H, int32_t W,
                                 const int32_t* q_src_view, const float* q_pt, const int32_t* q_map_view, const int32_t* q_off, int32_t nq,
                                 int32_t nq_view_max, int32_t topk, int32_t window, const int32_t* slot_kind, const double* slot_xy, int32_t L,
-                                int32_t mask_method, double* pts, double* weight, int32_t* npts, void* workspace, size_t workspace_bytes,
+                                int32_t mask_method, int32_t flags, double* pts, double* weight, int32_t* npts, void* workspace, size_t workspace_bytes,
                                 void* stream) {
-    if (!f || !q_src_view || !q_pt || !q_map_view || !q_off || !slot_kind || !slot_xy || !pts || !weight || !npts || !workspace) return RELPOSE_EINVAL;
-    if (n_views <= 0 || H <= 1 || W <= 1 || nq <= 0 || nq_view_max <= 0 || nq_view_max > 1024 || topk < 1 || topk > KP_MAXK || window < 0 || L <= 0 ||
-        feat_off < 0 || image_stride < (int64_t)(feat_off + 32) * H * W || mask_method < 0 || mask_method > 1)
+    if (!f || !q_off || !slot_kind || !slot_xy || !pts || !weight || !npts) return RELPOSE_EINVAL;
+    if (nq > 0 && (!q_src_view || !q_pt || !q_map_view || !workspace)) return RELPOSE_EINVAL;
+    if (n_views <= 0 || H <= 1 || W <= 1 || nq < 0 || nq_view_max < 0 || nq_view_max > RELPOSE_KP_MAX_QUERIES_PER_VIEW || (nq > 0 && nq_view_max == 0) || topk < 1 ||
+        topk > KP_MAXK || window < 0 || L <= 0 || feat_off < 0 || image_stride < (int64_t)(feat_off + 32) * H * W || mask_method < 0 || mask_method > 1 ||
+        (flags & ~RELPOSE_KP_OBSERVED_ONLY))
         return RELPOSE_EINVAL;
-    const KpWs o = kp_ws(nq, H, W, topk);
-    if (workspace_bytes < o.total) return RELPOSE_ENOMEM;
+    const KpWs o = kp_ws(std::max(nq, 1), H, W, topk);
+    if (nq > 0 && workspace_bytes < o.total) return RELPOSE_ENOMEM;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     float* desc = (float*)(ws + o.desc);
     u64* tilebest = (u64*)(ws + o.tilebest);
     int* picks = (int*)(ws + o.picks);
     const int ntx = (W + KP_TW - 1) / KP_TW, nty = (H + KP_TH - 1) / KP_TH, ntiles = ntx * nty;
-    hipLaunchKernelGGL(kp_desc_kernel, dim3((nq * 32 + 255) / 256), dim3(256), 0, s, f, (size_t)image_stride, feat_off, H, W, q_src_view, q_pt, desc, nq);
-    const size_t lds1 = (size_t)nq_view_max * (32 * sizeof(float) + 4 * sizeof(u64));
-    hipLaunchKernelGGL(kp_tile_best_kernel, dim3(ntiles, n_views), dim3(256), lds1, s, f, (size_t)image_stride, feat_off, H, W, desc, q_off, tilebest, ntx,
-                       ntiles);
-    hipLaunchKernelGGL(kp_pick_kernel, dim3(nq), dim3(256), (size_t)ntiles * sizeof(u64), s, f, (size_t)image_stride, feat_off, H, W, desc, q_map_view,
-                       tilebest, ntx, ntiles, topk, window, picks);
+    if (nq > 0) {       // (no query at all -- every view of the batch without SIFT detections --: only the slot tables are assembled)
+        hipLaunchKernelGGL(kp_desc_kernel, dim3((nq * 32 + 255) / 256), dim3(256), 0, s, f, (size_t)image_stride, feat_off, H, W, q_src_view, q_pt, desc, nq);
+        // 160 bytes of dynamic LDS per query of the largest view group: beyond the 64 KB default cap (409 queries) the launch needs the attribute
+        // (ADVICE r5); RELPOSE_KP_MAX_QUERIES_PER_VIEW = 1000 queries = 160 000 B, inside the CU's 160 KiB
+        const size_t lds1 = (size_t)nq_view_max * (32 * sizeof(float) + 4 * sizeof(u64));
+        if (lds1 > 48 * 1024) RP_HIP(hipFuncSetAttribute((const void*)kp_tile_best_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL(kp_tile_best_kernel, dim3(ntiles, n_views), dim3(256), lds1, s, f, (size_t)image_stride, feat_off, H, W, desc, q_off, tilebest, ntx,
+                           ntiles);
+        hipLaunchKernelGGL(kp_pick_kernel, dim3(nq), dim3(256), (size_t)ntiles * sizeof(u64), s, f, (size_t)image_stride, feat_off, H, W, desc, q_map_view,
+                           tilebest, ntx, ntiles, topk, window, picks);
+    }
     // observed region of the weights: getKeypoint :226 (x in [H, 2H]) / getKeypoint_kinect :341 (the 88 x 66 crop, bounds inclusive)
     double bx0, bx1, by0, by1;
     if (mask_method == RELPOSE_MASK_SECOND) { bx0 = H; bx1 = 2 * H; by0 = -1e300; by1 = 1e300; }
     else { bx0 = H + H / 2 - 88 / 2; bx1 = H + H / 2 + 88 / 2; by0 = H / 2 - 66 / 2; by1 = H / 2 + 66 / 2; }
-    hipLaunchKernelGGL(kp_assemble_kernel, dim3(n_views), dim3(64), 0, s, slot_kind, slot_xy, L, picks, H, W, bx0, bx1, by0, by1, pts, weight, npts);
+    hipLaunchKernelGGL(kp_assemble_kernel, dim3(n_views), dim3(64), 0, s, slot_kind, slot_xy, L, picks, H, W, bx0, bx1, by0, by1,
+                       (flags & RELPOSE_KP_OBSERVED_ONLY) ? 1 : 0, pts, weight, npts);
     RP_CHECK_LAUNCH();
     return 0;
 }

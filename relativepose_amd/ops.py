@@ -55,7 +55,7 @@ _lib.define("pose_inverse(Tensor pose) -> Tensor")
 _lib.define("sample_primitives(Tensor f, int feat_off, Tensor obs_norm, Tensor obs_depth, Tensor pts, Tensor npts, "
             "int mask_method, int compose, int dataset) -> (Tensor, Tensor, Tensor)")
 _lib.define("keypoints_reference(Tensor f, int feat_off, Tensor q_src, Tensor q_pt, Tensor q_map, Tensor q_off, int nq_view_max, int topk, int window, "
-            "Tensor slot_kind, Tensor slot_xy, int mask_method) -> (Tensor, Tensor, Tensor)")
+            "Tensor slot_kind, Tensor slot_xy, int mask_method, int flags=0) -> (Tensor, Tensor, Tensor)")
 _lib.define("affinity_topk(Tensor feat_s, Tensor weight_s, Tensor feat_t, Tensor weight_t, Tensor ns, Tensor nt, "
             "float[] params, int topK, bool want_wij) -> (Tensor, Tensor, Tensor, Tensor)")
 _lib.define("match_pairs(Tensor pc_s, Tensor normal_s, Tensor feat_s, Tensor weight_s, Tensor pc_t, Tensor normal_t, "
@@ -124,11 +124,11 @@ def _sample_primitives(f, feat_off, obs_norm, obs_depth, pts, npts, mask_method,
                                        npts.contiguous(), _INV_MASK[int(mask_method)], _INV_DATASET[int(dataset)], int(compose))
 
 
-def _keypoints_reference(f, feat_off, q_src, q_pt, q_map, q_off, nq_view_max, topk, window, slot_kind, slot_xy, mask_method):
+def _keypoints_reference(f, feat_off, q_src, q_pt, q_map, q_off, nq_view_max, topk, window, slot_kind, slot_xy, mask_method, flags=0):
     from . import rputil as _ru
     tab = {"q_src": q_src.contiguous(), "q_pt": q_pt.contiguous(), "q_map": q_map.contiguous(), "q_off": q_off.contiguous(), "nq": int(q_src.shape[0]),
            "nq_view_max": int(nq_view_max), "topk": int(topk), "slot_kind": slot_kind.contiguous(), "slot_xy": slot_xy.contiguous(), "L": int(slot_kind.shape[1])}
-    return _ru.keypoints_reference_dev(f.contiguous(), int(feat_off), tab, _INV_MASK[int(mask_method)], window=int(window))
+    return _ru.keypoints_reference_dev(f.contiguous(), int(feat_off), tab, _INV_MASK[int(mask_method)], window=int(window), observed_only=bool(int(flags) & 1))
 
 
 def _affinity_topk(feat_s, weight_s, feat_t, weight_t, ns, nt, params, topK, want_wij):

@@ -112,8 +112,6 @@ class RelativePosePipeline:
         import torch
         from . import rputil
         B, _, _, h, w = rgb.shape
-        if not self.completion:
-            raise NotImplementedError("keypoints='reference' with completion=0 (rpmodule.py:534-537 drops the weight != 1 keypoints) is not built")
         if sift is None or len(sift) != B:
             raise ValueError("keypoints='reference': prepare(sift=[(source detections, target detections)] * B) is required")
         kind = self.mask_method
@@ -131,7 +129,7 @@ class RelativePosePipeline:
         st["norm"] = t(norm.reshape(2 * B, 3, h, w), torch.float32)
         st["depth"] = t(depth.reshape(2 * B, h, w), torch.float32)
         st["kp"] = [rputil.upload_keypoint_tables(tb, device, L) for tb in tabs]
-        nb = max(_lib.lib().relpose_keypoints_reference_workspace_bytes(tb["nq"], h, w, tb["topk"]) for tb in tabs)
+        nb = max(_lib.lib().relpose_keypoints_reference_workspace_bytes(max(tb["nq"], 1), h, w, tb["topk"]) for tb in tabs)
         st["kp_ws"] = torch.empty(nb, dtype=torch.uint8, device=device)
         st["eye"] = torch.eye(4, dtype=torch.float64, device=device).repeat(B, 1, 1).contiguous()
         st["x"] = torch.empty(2 * B, 16, h, w, dtype=torch.float32, device=device)
@@ -149,7 +147,9 @@ class RelativePosePipeline:
             return st["pts"], st["npts"], st["w_s"], st["w_t"], st["ns"], st["nt"]
         from . import rputil
         B, N = st["B"], st["N"]
-        pts, w, npts = rputil.keypoints_reference_dev(f, self.feat_off, st["kp"][min(step, len(st["kp"]) - 1)], self.mask_method, L=N, workspace=st["kp_ws"])
+        # completion = 0 (the 'ours_nc' method, evaluation.py:74): only the observed-region keypoints take part (rpmodule.py:534-537)
+        pts, w, npts = rputil.keypoints_reference_dev(f, self.feat_off, st["kp"][min(step, len(st["kp"]) - 1)], self.mask_method, L=N, workspace=st["kp_ws"],
+                                                      observed_only=not self.completion)
         w = w.view(B, 2, N)
         n2 = npts.view(B, 2)
         return pts, npts, w[:, 0].contiguous(), w[:, 1].contiguous(), n2[:, 0].contiguous(), n2[:, 1].contiguous()

@@ -258,6 +258,9 @@ def _inside(kind, H):
     return lambda p: ((p[:, 0] >= x0) * (p[:, 0] <= H + H // 2 + FW // 2) * (p[:, 1] >= y0) * (p[:, 1] <= H // 2 + FH // 2))
 
 
+MAX_QUERIES_PER_VIEW = 1000        # include/relpose.h RELPOSE_KP_MAX_QUERIES_PER_VIEW (tests/test_cabi_cpu.py checks that they agree)
+
+
 def keypoint_plan(pts, ptt, kind, H, W, rng, n_match=30, topk=2):
     """The feature-INDEPENDENT half of getKeypoint ('second', rputil.py:141-237) / getKeypoint_kinect ('kinect', :240-353) for one scan
     pair and one recurrent level: every np.random call of the reference in its order (kinect: choice, choice for the 300 SIFT samples; then
@@ -270,7 +273,13 @@ def keypoint_plan(pts, ptt, kind, H, W, rng, n_match=30, topk=2):
     per query in query order, picks on the last row / column dropped."""
     pts, ptt = np.asarray(pts, dtype=np.float64).reshape(-1, 2), np.asarray(ptt, dtype=np.float64).reshape(-1, 2)
     if not len(pts) or not len(ptt):
-        raise ValueError("keypoint_plan: a view without SIFT detections (the reference skips such a pair, rputil.py:157-158)")
+        # A view without SIFT detections: the reference's getKeypoint returns None BEFORE drawing any random number (rputil.py:156-166), the level's
+        # pose becomes the identity and the loop goes on (rpmodule.py:522-523, evaluation.py:280-282).  The batched form of that: an EMPTY plan --
+        # no queries, no slots -- so both views of the pair get 0 keypoints at this level and the matcher takes its "return identity" status
+        # (RELPOSE_FEW_KEYPOINTS); the other pairs of the batch are untouched (ADVICE r5: raising here aborted the whole batch and, sharded,
+        # left the other ranks waiting in the pose all_gather).
+        e = np.zeros((0, 2))
+        return {"q1": e, "q2": e, "q3": e, "src_a": e, "src_b": e, "tgt_a": e, "topk": topk, "empty": True}
     if kind == "kinect":
         pts = pts[rng.choice(range(len(pts)), KINECT["N_SIFT"]), :]
         ptt = ptt[rng.choice(range(len(ptt)), KINECT["N_SIFT"]), :]
@@ -313,7 +322,7 @@ def keypoint_tables(plans, H, W):
         host = lambda a: [(-2, tuple(p)) for p in np.asarray(a, dtype=np.float64).reshape(-1, 2)]
         slots.append(host(P["src_a"]) + picks(first_q2, n2) + host(P["src_b"]))
         slots.append(host(P["tgt_a"]) + picks(first_q1, n1) + picks(first_q3, n3))
-    L = max(len(s_) for s_ in slots)
+    L = max(1, max(len(s_) for s_ in slots))          # (a batch of empty plans still needs one -- empty -- slot column)
     kind = np.full((2 * B, L), -1, dtype=np.int32)
     xy = np.zeros((2 * B, L, 2), dtype=np.float64)
     for v, sl in enumerate(slots):
@@ -323,14 +332,18 @@ def keypoint_tables(plans, H, W):
             else:
                 kind[v, i] = val
     q_off = np.asarray(q_off, dtype=np.int32)
+    if int(np.diff(q_off).max()) > MAX_QUERIES_PER_VIEW:
+        raise RuntimeError(f"keypoint_tables: {int(np.diff(q_off).max())} queries search one view's feature map; the library takes {MAX_QUERIES_PER_VIEW} "
+                           "(include/relpose.h: RELPOSE_KP_MAX_QUERIES_PER_VIEW)")
     return {"q_src": np.asarray(q_src, dtype=np.int32), "q_pt": np.concatenate(q_pt).astype(np.float32).reshape(-1, 2),
             "q_map": np.asarray(q_map, dtype=np.int32), "q_off": q_off, "nq": int(nq), "nq_view_max": int(np.diff(q_off).max()),
             "slot_kind": kind, "slot_xy": xy, "L": int(L), "topk": int(topk)}
 
 
-def keypoints_reference_dev(f, feat_off, tab, mask_method, window=15, L=None, workspace=None):
+def keypoints_reference_dev(f, feat_off, tab, mask_method, window=15, L=None, workspace=None, observed_only=False):
     """One recurrent level's keypoints of every view on the device: f [2B, C, H, W] the network output (CUDA), `tab` = keypoint_tables(...)
-    uploaded (torch tensors on f.device; see upload_keypoint_tables).  Returns (pts [2B, L, 2] f64, weight [2B, L] f64, npts [2B] i32)."""
+    uploaded (torch tensors on f.device; see upload_keypoint_tables).  Returns (pts [2B, L, 2] f64, weight [2B, L] f64, npts [2B] i32).
+    observed_only: keep the weight-1 keypoints only (getMatchingPrimitive(..., doCompletion=0), rpmodule.py:534-537)."""
     import torch
     from .util import MASKS
     _lib.require_gpu()
@@ -343,12 +356,12 @@ def keypoints_reference_dev(f, feat_off, tab, mask_method, window=15, L=None, wo
     pts = torch.empty(n, L, 2, dtype=torch.float64, device=dev)
     w = torch.empty(n, L, dtype=torch.float64, device=dev)
     npts = torch.empty(n, dtype=torch.int32, device=dev)
-    nbytes = _lib.lib().relpose_keypoints_reference_workspace_bytes(tab["nq"], H, W, tab["topk"])
+    nbytes = _lib.lib().relpose_keypoints_reference_workspace_bytes(max(tab["nq"], 1), H, W, tab["topk"])
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rc = _lib.lib().relpose_keypoints_reference(_lib.ptr(f), C * H * W, int(feat_off), n, H, W, _lib.ptr(tab["q_src"]), _lib.ptr(tab["q_pt"]),
                                                 _lib.ptr(tab["q_map"]), _lib.ptr(tab["q_off"]), tab["nq"], tab["nq_view_max"], tab["topk"], int(window),
-                                                _lib.ptr(tab["slot_kind"]), _lib.ptr(tab["slot_xy"]), L, MASKS[mask_method], _lib.ptr(pts), _lib.ptr(w),
+                                                _lib.ptr(tab["slot_kind"]), _lib.ptr(tab["slot_xy"]), L, MASKS[mask_method], 1 if observed_only else 0, _lib.ptr(pts), _lib.ptr(w),
                                                 _lib.ptr(npts), _lib.ptr(workspace), workspace.numel(), _lib.stream_ptr())
     _lib.check(rc, "relpose_keypoints_reference")
     return pts, w, npts

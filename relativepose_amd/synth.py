@@ -292,3 +292,15 @@ def make_keypoint_case(seed, kind="second", h=H):
         return rs, rt, feats, featt, det(57), det(43), rs_full, rt_full
     det = lambda n: np.stack((rs_.uniform(1, h - 3, n), rs_.uniform(1, h - 3, n)), 1)
     return rs, rt, feats, featt, det(41), det(25), None, None
+
+
+def make_matching_primitive_case(seed, kind="second"):
+    """Inputs of rpmodule.getMatchingPrimitive for the getKeypoint fixture (seed, kind) (tests/golden/gmp_nc.npz): make_keypoint_case + the depth /
+    normal maps of a seeded synthetic scan pair as the 'completed' geometry.  Returns (dataset, dataS, dataT, det_s, det_t) with 'feat' as numpy
+    (the caller wraps it in a tensor)."""
+    ds = "scannet" if kind == "kinect" else "suncg"
+    rs, rt, feats, featt, det_s, det_t, rs_full, rt_full = make_keypoint_case(seed, kind)
+    d = make_pairs(1, 4000 + seed, ds)
+    mk = lambda rgb, full, feat, v: {"rgb": rgb, "rgb_full": full, "feat": feat, "depth": d["depth"][0, v].astype(np.float64),
+                                     "normal": np.ascontiguousarray(d["norm"][0, v].transpose(1, 2, 0)).astype(np.float64)}
+    return ds, mk(rs, rs_full, feats, 0), mk(rt, rt_full, featt, 1), det_s, det_t

@@ -8,6 +8,7 @@ MATCH_CASES = [  # (N, Nt, seed, dataset, param row, inlier fraction)
     (2, 2, 19, "suncg", 0, 0.6), (6, 4, 20, "suncg", 0, 0.6), (30, 30, 21, "suncg", 0, 0.0),
 ]
 MATCH_METHODS = ("irls+sm", "horn87", "irls", "spectral")
+MATCH_BIG512 = (1000, 512, 78, "suncg", 0, 0.8, 0.002)   # 1000 source x 512 target keypoints: the largest shape the affinity tile / pool kernels take (matcher_stages_big512.npz)
 MATCH_BIG = (1000, 1000, 77, "suncg", 0, 0.8, 0.002)      # (N, Nt, seed, dataset, param row, inlier fraction, noise): matcher_big.npz
 
 GEOM_CASES = (("suncg", "second", 100), ("matterport", "second", 200), ("scannet", "kinect", 300))
@@ -24,6 +25,7 @@ E2E_WEIGHT_SEED = 7
 # every network output (= the measured float32 kernel-vs-reference output difference), this many noise seeds
 ENV_AMP = 3e-5
 ENV_SEEDS = 8
+TF_CASES = (0, 4, 5)           # E2E_CASES indices of the teacher-forced pipeline test (tests/test_gpu_pipeline.py) -> e2e_env_tf.npz
 
 # well-conditioned end-to-end fixtures: synth.make_wc_pair(seed, **WC_KW) + weights.make_descriptor_state_dict
 WC_CASES = (9000, 9002, 9004)

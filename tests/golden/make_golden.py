@@ -6,7 +6,7 @@ regenerated from seeds, expected outputs are stored) travel with the repo.
     python tests/golden/make_golden.py            # all groups
     python tests/golden/make_golden.py matcher    # one group
 
-Groups: matcher, matcher_stages, tune, matcher_big, geometry, scnet, e2e, e2e_env, e2e_wc, e2e_wc2, stats, keypoints, getkeypoint, metrics.  See SURVEY.md §8c for the plan.
+Groups: matcher, matcher_stages, matcher_stages_big512, tune, matcher_big, geometry, scnet, e2e, e2e_env, e2e_env_tf, e2e_wc, e2e_wc2, stats, keypoints, getkeypoint, gmp_nc, metrics.  See SURVEY.md §8c for the plan.
 """
 import hashlib
 import os
@@ -171,6 +171,24 @@ def gen_matcher_stages():
         for k, v in rec.items():
             out[f"{tag}_{k}"] = v
     np.savez_compressed(os.path.join(HERE, "matcher_stages.npz"), **out)
+
+
+def gen_matcher_stages_big512():
+    """matcher_stages_big512.npz: the stage intermediates of the reference helper (as gen_matcher_stages) for cases.MATCH_BIG512 -- 1000 source
+    x 512 target keypoints, the largest shape the affinity tile / pool kernels accept, so that every affinity kernel runs a 5000-correspondence
+    stage golden (the N = Nt = 1000 case can only run on the row / LDS kernels).  A file of its own: the other cases are not regenerated."""
+    from cases import MATCH_BIG512
+    R = ref_loader.load()
+    rp, ru = R["rpmodule"], R["rputil"]
+    params = load_params()
+    N, Nt, seed, ds, row, inl, noise = MATCH_BIG512
+    S, T, _ = synth.make_match_case(N, seed, inlier=inl, noise=noise, Nt=Nt)
+    spy = _HelperSpy(rp)
+    t = time.time()
+    pose = spy.run(S, T, ru.opts(*params[ds][row]))
+    rec = stage_record(spy, pose, N, Nt)
+    print(f"matcher_stages big512: N={N}/{Nt} {time.time()-t:.1f}s keys={sorted(rec)} trace={len(spy.trace)}")
+    np.savez_compressed(os.path.join(HERE, "matcher_stages_big512.npz"), **{f"big512_{k}": v for k, v in rec.items()})
 
 
 def gen_tune():
@@ -360,11 +378,12 @@ def gen_scnet():
     np.savez_compressed(os.path.join(HERE, "scnet.npz"), **out)
 
 
-def ref_loop(net, d, pts, ptw, ds, mm, S, sigmas, noise_amp=0.0, noise_seed=0, keep_prims=None):
+def ref_loop(net, d, pts, ptw, ds, mm, S, sigmas, noise_amp=0.0, noise_seed=0, keep_prims=None, R_forced=None):
     """evaluation.py:217-284 for ONE scan pair driven through the reference's own functions (util.apply_mask,
     util.warping, the reference SCNet, rpmodule.getMatchingPrimitive with getKeypoint replaced by the injected
     keypoints, rpmodule.RelativePoseEstimation_helper).  Returns [R_hat after each of the 3 steps].
-    noise_amp > 0 adds uniform(-amp, amp) float32 noise to every network output (perturbation envelope)."""
+    noise_amp > 0 adds uniform(-amp, amp) float32 noise to every network output (perturbation envelope).
+    R_forced: the pose estimate every level STARTS from (teacher forcing: level k warps with R_forced[k] instead of its own previous estimate)."""
     import torch
     R = ref_loader.load()
     util, rp, ru, top = R["util"], R["rpmodule"], R["rputil"], R["torch_op"]
@@ -394,6 +413,8 @@ def ref_loop(net, d, pts, ptw, ds, mm, S, sigmas, noise_amp=0.0, noise_seed=0, k
                 "normal": d["norm"][0, v].transpose(1, 2, 0)} for v in range(2)]
         fs, fe = 7 + S, 7 + S + 32
         for step in range(3):
+            if R_forced is not None:
+                R_hat = R_forced[step]
             t2s = top.v(util.warping(top.npy(views[1]), np.linalg.inv(R_hat), ds))
             s2t = top.v(util.warping(top.npy(views[0]), R_hat, ds))
             f = net(torch.cat((torch.cat((views[0], t2s), 1), torch.cat((views[1], s2t), 1))))
@@ -471,6 +492,37 @@ def gen_e2e_env():
         out[f"env_{ci}"] = env
         print(f"e2e_env case {ci} {ds}: max per step {env.max(0)}  median {np.median(env, 0)}  ({time.time()-t0:.1f}s)")
     np.savez_compressed(os.path.join(HERE, "e2e_env.npz"), **out)
+
+
+def gen_e2e_env_tf():
+    """gen_e2e_env for the TEACHER-FORCED loop (tests/test_gpu_pipeline.py::test_pipeline_teacher_forced_vs_oracle: level k starts from the
+    reference's own pose after level k - 1): the reference's one-level response to uniform(-ENV_AMP, ENV_AMP) noise on the network output, per
+    level, for the cases that test runs.  Free-running envelopes are O(1) after level 0 (the loop is chaotic with random weights); teacher-forced,
+    every level is ONE step from a fixed pose and its envelope bounds what a float32 kernel difference can do to that level's pose."""
+    from cases import TF_CASES
+    params = load_params()
+    ge = np.load(os.path.join(HERE, "e2e.npz"))
+    out = {"amp": np.array(ENV_AMP), "n_seeds": np.array(ENV_SEEDS)}
+    nets = {}
+    for ci in TF_CASES:
+        ds, mm, S, tanh, seed = E2E_CASES[ci]
+        key = (S, tanh)
+        if key not in nets:
+            nets[key] = ref_net(S, tanh, E2E_WEIGHT_SEED)
+        d = synth.make_pairs(1, seed, ds)
+        pts, ptw = synth.make_keypoints(1, E2E_N, seed, mm)
+        forced = [np.eye(4)] + [ge[f"e2e_{ci}_R{s}"] for s in range(2)]
+        base = ref_loop(nets[key], d, pts, ptw, ds, mm, S, params[ds], R_forced=forced)
+        drift = [float(np.linalg.norm(base[s][:3, :3] - ge[f"e2e_{ci}_R{s}"][:3, :3])) for s in range(3)]
+        assert max(drift) < 1e-9, drift           # forcing the reference with its own poses reproduces its free-running trajectory
+        env = np.zeros((ENV_SEEDS, 3))
+        t0 = time.time()
+        for k in range(ENV_SEEDS):
+            tr = ref_loop(nets[key], d, pts, ptw, ds, mm, S, params[ds], noise_amp=ENV_AMP, noise_seed=9000 + 100 * ci + k, R_forced=forced)
+            env[k] = [np.linalg.norm(tr[s][:3, :3] - ge[f"e2e_{ci}_R{s}"][:3, :3]) for s in range(3)]
+        out[f"env_tf_{ci}"] = env
+        print(f"e2e_env_tf case {ci} {ds}: max per level {env.max(0)}  median {np.median(env, 0)}  ({time.time()-t0:.1f}s)", flush=True)
+    np.savez_compressed(os.path.join(HERE, "e2e_env_tf.npz"), **out)
 
 
 def gen_e2e_wc():
@@ -575,6 +627,44 @@ def gen_getkeypoint():
     np.savez_compressed(os.path.join(HERE, "getkeypoint.npz"), **out)
 
 
+def gmp_inputs(ci):
+    from cases import GK_CASES
+    kind, seed = GK_CASES[ci]
+    return (kind, seed) + synth.make_matching_primitive_case(seed, kind)
+
+
+def gen_gmp_nc():
+    """gmp_nc.npz: rpmodule.getMatchingPrimitive of the REFERENCE (rpmodule.py:511-538) with doCompletion = 0 AND 1 -- the 'ours_nc' method of
+    evaluation.py:74 keeps the keypoints of the observed region only (:534-537) -- on one 'second' and one 'kinect' getKeypoint fixture (cv2 stub
+    with fixed detections as in gen_getkeypoint, np.random seeded): all eight outputs."""
+    import types
+    import torch
+    from relativepose_amd import rputil as mine
+    R = ref_loader.load()
+    rp, ru = R["rpmodule"], R["rputil"]
+    out = {}
+    for ci in (0, 2):
+        kind, seed, ds, dS, dT, det_s, det_t = gmp_inputs(ci)
+        for comp in (0, 1):
+            queue = [det_s, det_t]
+
+            class FakeSift:
+                def detectAndCompute(self, gray, mask):
+                    pts = queue.pop(0)
+                    return [types.SimpleNamespace(pt=(float(x), float(y))) for x, y in pts], None
+            ru.cv2.COLOR_BGR2GRAY = 6
+            ru.cv2.cvtColor = lambda img, code: mine.bgr2gray(img)
+            ru.cv2.xfeatures2d = types.SimpleNamespace(SIFT_create=lambda **kw: FakeSift())
+            rp.getKeypoint, rp.getKeypoint_kinect = ru.getKeypoint, ru.getKeypoint_kinect
+            np.random.seed(seed)
+            tS = dict(dS, feat=torch.from_numpy(dS["feat"])); tT = dict(dT, feat=torch.from_numpy(dT["feat"]))
+            res = rp.getMatchingPrimitive(tS, tT, ds, "skybox", comp)
+            for name, a in zip(("pts3d", "ptt3d", "ptsns", "ptsnt", "dess", "dest", "ptsW", "pttW"), res):
+                out[f"gmp_{ci}_c{comp}_{name}"] = np.asarray(a)
+            print(f"gmp_nc case {ci} {kind} doCompletion={comp}: {res[0].shape[1]} source / {res[1].shape[1]} target primitives")
+    np.savez_compressed(os.path.join(HERE, "gmp_nc.npz"), **out)
+
+
 def gen_stats():
     """util.parse_data + util.point_cloud_overlap of the reference on synthetic pairs."""
     R = ref_loader.load()
@@ -608,7 +698,7 @@ def gen_metrics():
 
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
-    groups = sys.argv[1:] or ["matcher", "matcher_stages", "tune", "matcher_big", "geometry", "scnet", "e2e", "e2e_env", "e2e_wc", "e2e_wc2", "stats", "keypoints", "getkeypoint", "metrics"]
+    groups = sys.argv[1:] or ["matcher", "matcher_stages", "matcher_stages_big512", "tune", "matcher_big", "geometry", "scnet", "e2e", "e2e_env", "e2e_env_tf", "e2e_wc", "e2e_wc2", "stats", "keypoints", "getkeypoint", "gmp_nc", "metrics"]
     for g in groups:
         t = time.time()
         globals()["gen_" + g]()

@@ -93,3 +93,5 @@ def test_capacity_limit_matches_the_header():
     hdr = open(os.path.join(ROOT, "include", "relpose.h")).read()
     assert int(re.search(r"#define RELPOSE_MAX_CORRESPONDENCES\s+(\d+)", hdr).group(1)) == rpmodule.MAX_CORRESPONDENCES
     assert int(re.search(r"#define RELPOSE_MAX_TARGETS\s+(\d+)", hdr).group(1)) == rpmodule.MAX_TARGETS
+    from relativepose_amd import rputil
+    assert int(re.search(r"#define RELPOSE_KP_MAX_QUERIES_PER_VIEW\s+(\d+)", hdr).group(1)) == rputil.MAX_QUERIES_PER_VIEW

@@ -194,3 +194,104 @@ def test_pipeline_reference_keypoints_equal_per_pair_getkeypoint_at_every_level(
             assert np.array_equal(helper, trace[lvl][b].cpu().numpy()), (lvl, b)
     log("pipeline_reference_keypoints", dataset=ds, mask=kind, pairs=B, levels=3, max_keypoints_per_view=worst, status=status.cpu().tolist())
     assert torch.isfinite(pose).all()
+
+
+# ---- round 6: doCompletion = 0 (the 'ours_nc' method) and views without detections ---------------------------------------------------------
+@pytest.mark.parametrize("ci", [0, 2])
+@pytest.mark.parametrize("comp", [0, 1])
+def test_getmatchingprimitive_shim_equals_the_reference_with_and_without_completion(golden_dir, ci, comp):
+    """rpmodule.getMatchingPrimitive (same-named shim over the C ABI) against the REFERENCE's own getMatchingPrimitive(…, doCompletion = 0 | 1)
+    (tests/golden/gmp_nc.npz, make_golden.gen_gmp_nc: reference run with the cv2 stub's fixed detections and np.random seeded): doCompletion = 0
+    keeps the observed-region keypoints only (rpmodule.py:534-537; the 'ours_nc' method, evaluation.py:74).  All eight outputs."""
+    import torch
+    from cases import GK_CASES
+    from relativepose_amd import rpmodule, rputil, synth
+    g = np.load(os.path.join(golden_dir, "gmp_nc.npz"))
+    kind, seed = GK_CASES[ci]
+    ds, dS, dT, det_s, det_t = synth.make_matching_primitive_case(seed, kind)
+    queue = [det_s, det_t]
+    old = rputil.set_sift_detector(lambda gray: queue.pop(0))
+    try:
+        np.random.seed(seed)
+        tS = dict(dS, feat=torch.from_numpy(dS["feat"])); tT = dict(dT, feat=torch.from_numpy(dT["feat"]))
+        res = rpmodule.getMatchingPrimitive(tS, tT, ds, "skybox", comp)
+    finally:
+        rputil.set_sift_detector(old)
+    err = {}
+    for name, a in zip(("pts3d", "ptt3d", "ptsns", "ptsnt", "dess", "dest", "ptsW", "pttW"), res):
+        ref = g[f"gmp_{ci}_c{comp}_{name}"]
+        assert np.asarray(a).shape == ref.shape, (name, np.asarray(a).shape, ref.shape)
+        err[name] = float(np.abs(np.asarray(a, dtype=np.float64) - ref).max()) if ref.size else 0.0
+    log("getmatchingprimitive_vs_reference", case=ci, kind=kind, doCompletion=comp, n_source=int(res[0].shape[1]), n_target=int(res[1].shape[1]), max_abs_diff=err)
+    assert err["ptsW"] == 0 and err["pttW"] == 0 and err["dess"] == 0 and err["dest"] == 0          # descriptors bit-exact
+    assert max(err["pts3d"], err["ptt3d"], err["ptsns"], err["ptsnt"]) < 1e-12
+    if not comp:
+        assert (np.asarray(res[6]) == 1).all() and (np.asarray(res[7]) == 1).all()
+
+
+@pytest.mark.parametrize("kind,cis", [("second", (0, 1)), ("kinect", (2, 3))])
+def test_batched_keypoints_observed_only_equal_the_reference_selection(golden_dir, kind, cis):
+    """RELPOSE_KP_OBSERVED_ONLY (RelativePosePipeline(keypoints="reference", completion=0)): the batched device derivation keeps exactly the
+    keypoints the reference keeps with doCompletion = 0 -- its own keypoint lists (getkeypoint.npz) filtered by its own weights == 1, in order
+    (rpmodule.py:534-537) -- and as many as the reference's getMatchingPrimitive(…, 0) returned (gmp_nc.npz)."""
+    import torch
+    from cases import GK_CASES
+    from relativepose_amd import rputil, synth
+    g = np.load(os.path.join(golden_dir, "getkeypoint.npz"))
+    gn = np.load(os.path.join(golden_dir, "gmp_nc.npz"))
+    dev = torch.device("cuda:0")
+    H, W, S = 160, 640, 15
+    off = 7 + S
+    f = torch.randn(4, off + 32, H, W, device=dev)
+    plans = []
+    for b, ci in enumerate(cis):
+        k, seed = GK_CASES[ci]
+        _, _, feats, featt, det_s, det_t, _, _ = synth.make_keypoint_case(seed, kind)
+        f[2 * b, off:] = torch.from_numpy(feats).to(dev)
+        f[2 * b + 1, off:] = torch.from_numpy(featt).to(dev)
+        plans.append(rputil.keypoint_plan(rputil.map_detections(det_s, kind, H), rputil.map_detections(det_t, kind, H), kind, H, W, np.random.RandomState(seed)))
+    tab = rputil.upload_keypoint_tables(rputil.keypoint_tables(plans, H, W), dev)
+    pts, w, npts = (t.cpu().numpy() for t in rputil.keypoints_reference_dev(f, off, tab, kind, observed_only=True))
+    for b, ci in enumerate(cis):
+        for v, (pn, wn, gname) in enumerate((("pts", "ptsW", "pts3d"), ("ptt", "pttW", "ptt3d"))):
+            keep = g[f"gk_{ci}_{wn}"] == 1
+            n = int(npts[2 * b + v])
+            assert n == int(keep.sum()) and np.array_equal(pts[2 * b + v, :n], g[f"gk_{ci}_{pn}"][keep]), (ci, pn)
+            assert (w[2 * b + v, :n] == 1).all() and not w[2 * b + v, n:].any()
+            if f"gmp_{ci}_c0_{gname}" in gn:
+                assert n == gn[f"gmp_{ci}_c0_{gname}"].shape[1], (ci, gname)
+    log("batched_keypoints_observed_only", kind=kind, keypoints_per_view=npts.tolist())
+
+
+def test_pipeline_pair_without_detections_returns_identity_and_leaves_the_batch_alone():
+    """a view without SIFT detections must not abort the batch.  The reference's getKeypoint returns None, that level's pose is
+    the identity and the loop goes on (rputil.py:156-166, rpmodule.py:522-523, evaluation.py:280-282).  Batched: the pair gets an empty keypoint
+    plan at every level -> 0 keypoints -> the matcher's "return identity" status; the other pairs' poses are bitwise what they are without it;
+    completion = 0 runs the same way."""
+    import torch
+    from types import SimpleNamespace
+    from relativepose_amd import params, rputil, synth, weights
+    from relativepose_amd.model import SCNet
+    from relativepose_amd.pipeline import RelativePosePipeline
+    dev = torch.device("cuda:0")
+    ds, kind, S, h = "suncg", "second", 15, 160
+    d = synth.make_pairs(3, 8300, ds)
+    net = SCNet(SimpleNamespace(batchnorm=1, useTanh=1, skipLayer=1, outputType="rgbdnsf", snumclass=S))
+    net.load_state_dict(weights.make_state_dict(9, S))
+    rs_ = np.random.RandomState(56)
+    dets = [(_sift_like(rs_, kind, 50 + 5 * b), _sift_like(rs_, kind, 40 + 5 * b)) for b in range(3)]
+    sift = [(rputil.map_detections(a, kind, h), rputil.map_detections(c, kind, h)) for a, c in dets]
+    seeds = [[100 * b + lvl + 3 for lvl in range(3)] for b in range(3)]
+    for completion in (1, 0):
+        pipe = RelativePosePipeline(net, ds, kind, params.final_params(ds), keypoints="reference", completion=completion)
+        pose_all, status_all, _ = pipe.run(pipe.prepare(d["rgb"], d["norm"], d["depth"], None, None, dev, sift=sift, kp_seeds=seeds))
+        sift_gap = [sift[0], (np.zeros((0, 2)), sift[1][1]), sift[2]]           # pair 1: the source view has no detections
+        keep = []
+        pose, status, _ = pipe.run(pipe.prepare(d["rgb"], d["norm"], d["depth"], None, None, dev, sift=sift_gap, kp_seeds=seeds), keep=keep)
+        assert int(status[1]) == 1 and torch.equal(pose[1], torch.eye(4, dtype=torch.float64, device=dev))      # RELPOSE_FEW_KEYPOINTS: identity
+        assert all(int(k["ns"][1]) == 0 and int(k["nt"][1]) == 0 for k in keep)
+        for b in (0, 2):
+            assert torch.equal(pose[b], pose_all[b]) and int(status[b]) == int(status_all[b]), (completion, b)
+        if not completion:
+            assert all(bool((k["w_s"][b, :int(k["ns"][b])] == 1).all()) and bool((k["w_t"][b, :int(k["nt"][b])] == 1).all()) for k in keep for b in (0, 2))
+    log("pipeline_pair_without_detections", status=status.cpu().tolist())

@@ -106,12 +106,14 @@ def test_matcher_stages_vs_oracle(gm, dev, ci, aff_kernel):
 
 
 def _stage_cases():
-    from cases import MATCH_BIG
-    return [(str(ci), c + (0.005,)) for ci, c in enumerate(MATCH_CASES)] + [("big", MATCH_BIG)]
+    """(tag, case, affinity kernel): every stage golden through every affinity kernel that takes its shape -- the tile / pool kernels take up to 512
+    targets, so the N = Nt = 1000 golden runs on the row (-> LDS) kernel and the 1000 x 512 golden ("big512") on all three: no case is skipped."""
+    from cases import MATCH_BIG, MATCH_BIG512
+    cases = [(str(ci), c + (0.005,)) for ci, c in enumerate(MATCH_CASES)] + [("big", MATCH_BIG), ("big512", MATCH_BIG512)]
+    return [(tag, c, k) for tag, c in cases for k in ("rows", "tile", "pool") if k == "rows" or c[1] <= 512]
 
 
-@pytest.mark.parametrize("aff_kernel", ["rows", "tile", "pool"])
-@pytest.mark.parametrize("tag,case", _stage_cases())
+@pytest.mark.parametrize("tag,case,aff_kernel", _stage_cases())
 def test_matcher_stages_vs_reference_stage_goldens(gm, dev, golden_dir, tag, case, aff_kernel):
     """Every stage of the HIP matcher against what the REFERENCE RUN ITSELF produced (tests/golden/matcher_stages.npz, captured by
     make_golden._HelperSpy from the helper's own locals / log lines / per-alternation poses -- no oracle in between): wij samples
@@ -120,10 +122,8 @@ def test_matcher_stages_vs_reference_stage_goldens(gm, dev, golden_dir, tag, cas
     (rpmodule.py:354-374, :404, :436, :457-467, :270-307), for all 11 cases and the N = 1000 pair, with both affinity kernels."""
     from relativepose_amd import _lib, rpmodule
     from test_oracle_golden import check_corres_sets
-    gs = np.load(os.path.join(golden_dir, "matcher_stages.npz"))
+    gs = np.load(os.path.join(golden_dir, "matcher_stages_big512.npz" if tag == "big512" else "matcher_stages.npz"))
     N, Nt, seed, ds, row, inl, noise = case
-    if aff_kernel in ("tile", "pool") and N > 512:
-        pytest.skip("the tile / pool kernels take up to 512 targets")
     S, T, _ = synth.make_match_case(N, seed, inlier=inl, noise=noise, Nt=Nt)
     para, _ = _params(gm, ds, row)
     with _lib.tuning(affinity_kernel=aff_kernel):

@@ -7,20 +7,22 @@ the float32 network adds ~1e-4 to the feature maps, so the loop is compared
 teacher-forced, stage by stage:
   * network output and sampled primitives within float32 tolerance,
   * the matcher, fed the ORACLE's primitives of that step, within 1e-4,
-  * the end-to-end pose is logged (and bounded loosely)."""
+  * the level's end-to-end pose against the reference's, inside the reference's own one-level perturbation envelope (e2e_env_tf.npz)."""
 import os
 from types import SimpleNamespace
 
 import numpy as np
 import pytest
 
-from cases import E2E_CASES, E2E_N, E2E_WEIGHT_SEED
+from cases import E2E_CASES, E2E_N, E2E_WEIGHT_SEED, ENV_AMP, TF_CASES
 from gpu_util import log
 from oracle import pipeline_oracle as P
 from oracle.scnet_oracle import SCNetOracle
 from relativepose_amd import synth, weights
 
 pytestmark = pytest.mark.gpu
+
+ENV_SLACK = 3.0      # as tests/test_gpu_e2e.py: the GPU run is one more sample of a heavy-tailed distribution of which the envelope holds 8
 
 
 def _gpu_net(S, tanh, seed):
@@ -30,13 +32,15 @@ def _gpu_net(S, tanh, seed):
     return net
 
 
-@pytest.mark.parametrize("ci", [0, 4, 5])
+@pytest.mark.parametrize("ci", TF_CASES)
 def test_pipeline_teacher_forced_vs_oracle(ci, golden_dir):
     import torch
     from relativepose_amd import rpmodule
     from relativepose_amd.pipeline import RelativePosePipeline
     ge = np.load(os.path.join(golden_dir, "e2e.npz"))
     gm = np.load(os.path.join(golden_dir, "matcher.npz"))
+    env_tf = np.load(os.path.join(golden_dir, "e2e_env_tf.npz"))
+    assert float(env_tf["amp"]) == ENV_AMP and ci in TF_CASES
     ds, mm, S, tanh, seed = E2E_CASES[ci]
     d = synth.make_pairs(1, seed, ds)
     pts, ptw = synth.make_keypoints(1, E2E_N, seed, mm)
@@ -73,7 +77,12 @@ def test_pipeline_teacher_forced_vs_oracle(ci, golden_dir):
         assert f_err < 1e-3
         assert pc_err < 1e-3 and ft_err < 1e-3
         assert iso_err < 1e-4
-        assert e2e_err < 5e-2          # ill-conditioned with random weights; see module docstring
+        # the level's pose against the REFERENCE's, bounded by the reference's OWN one-level response to +-3e-5 noise on the network output
+        # (e2e_env_tf.npz, make_golden.gen_e2e_env_tf: 8 noise seeds per case and level, teacher-forced like this test): the matching problem
+        # is ill-conditioned with random weights (module docstring), and the envelope says by how much -- 1e-4 ... 6e-3 depending on case and level
+        bound = ENV_SLACK * float(env_tf[f"env_tf_{ci}"][:, step].max())
+        log("pipeline_step_envelope", case=ci, step=step, e2e_rot_err_vs_reference=ref_err, reference_envelope_max=float(env_tf[f"env_tf_{ci}"][:, step].max()), bound=bound)
+        assert ref_err <= bound and e2e_err <= bound, (ci, step, ref_err, e2e_err, bound)
 
 
 def test_pipeline_batch_equals_single_and_is_deterministic():

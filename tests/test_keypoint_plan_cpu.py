@@ -65,6 +65,29 @@ def test_tables_are_consistent():
     assert np.array_equal(T["slot_xy"][0, :na], plans[0]["src_a"])
 
 
-def test_plan_requires_detections():
-    with pytest.raises(ValueError):
-        rputil.keypoint_plan(np.zeros((0, 2)), np.ones((3, 2)), "second", 160, 640, np.random.RandomState(0))
+def test_a_view_without_detections_gives_an_empty_plan_not_an_error():
+    """the reference does not fail when a view has no SIFT detections -- getKeypoint returns None before drawing any random number
+    (rputil.py:156-166), that level's pose is the identity and the loop continues (rpmodule.py:522-523, evaluation.py:280-282).  keypoint_plan
+    returns an EMPTY plan for such a pair (no queries, no slots: both views get 0 keypoints and the matcher its "return identity" status), the
+    random stream untouched, and keypoint_tables builds a batch's tables around it without disturbing the other pairs."""
+    from relativepose_amd import rputil
+    H, W = 160, 640
+    det = np.stack((np.linspace(170, 300, 9), np.linspace(10, 140, 9)), 1)
+    for ps, pt in ((np.zeros((0, 2)), det), (det, np.zeros((0, 2))), (np.zeros((0, 2)), np.zeros((0, 2)))):
+        rng = np.random.RandomState(5)
+        before = rng.get_state()[1].copy()
+        P = rputil.keypoint_plan(ps, pt, "second", H, W, rng)
+        assert P.get("empty") and all(len(P[k]) == 0 for k in ("q1", "q2", "q3", "src_a", "src_b", "tgt_a"))
+        assert np.array_equal(rng.get_state()[1], before)           # no np.random call was consumed, like the reference's early return
+    full = rputil.keypoint_plan(det, det + 3, "second", H, W, np.random.RandomState(5))
+    empty = rputil.keypoint_plan(np.zeros((0, 2)), det, "second", H, W, np.random.RandomState(6))
+    alone = rputil.keypoint_tables([full], H, W)
+    both = rputil.keypoint_tables([empty, full], H, W)
+    assert both["nq"] == alone["nq"] and both["L"] == alone["L"] and both["nq_view_max"] == alone["nq_view_max"]
+    assert list(both["q_off"][:3]) == [0, 0, 0] and np.array_equal(both["q_off"][2:] , alone["q_off"])
+    assert (both["slot_kind"][:2] == -1).all()
+    # the second pair's tables are the lone pair's, re-based to views 2, 3 (its pick indices are unchanged: the empty pair has no queries)
+    assert np.array_equal(both["slot_kind"][2:], alone["slot_kind"]) and np.array_equal(both["slot_xy"][2:], alone["slot_xy"])
+    assert np.array_equal(both["q_map"], alone["q_map"] + 2) and np.array_equal(both["q_src"], alone["q_src"] + 2)
+    only_empty = rputil.keypoint_tables([empty], H, W)
+    assert only_empty["nq"] == 0 and only_empty["L"] == 1 and (only_empty["slot_kind"] == -1).all()
