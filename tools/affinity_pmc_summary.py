@@ -1,6 +1,6 @@
 """Summarise the rocprofv3 --pmc passes of tools/affinity_pmc.py (one directory per counter set) per affinity kernel.
     python tools/affinity_pmc_summary.py ROOT TAG   (reads ROOT/TAG_<set>/p_results.db for every set that exists)
-Counter sets (tools/gpu_r3_affinity_pmc.sh): fetch (FETCH_SIZE), write (WRITE_SIZE), sqa (instruction mix), sqb (wait / issue breakdown), sqc (LDS)."""
+Counter sets (tools/gpu_evidence.sh affinity): fetch (FETCH_SIZE), write (WRITE_SIZE), sqa (instruction mix), sqb (wait / issue breakdown), sqc (LDS)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
