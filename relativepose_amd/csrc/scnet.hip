@@ -64,22 +64,20 @@ typedef float rp_f4v __attribute__((ext_vector_type(4)));
 #ifndef RP_AGPR
 #define RP_AGPR 0               // 1 = fp32 MFMA accumulators in AccVGPRs through inline asm (experiment)
 #endif
-#ifndef RP_TWO_CHAIN
-#define RP_TWO_CHAIN 0          // one-accumulator tiles in the split modes: 1 = small / large terms on two accumulator chains (rp_split_mma), 0 = one chain, 2 = only in the three-piece modes
-#endif
 #ifndef RP_TILE_ABLATE
 #define RP_TILE_ABLATE 0
 #endif
-#ifndef RP_SLOT_PRIO
-#define RP_SLOT_PRIO 0          // experiment: 1 = waves in odd hardware wave slots of their SIMD raise their priority (breaks the symmetry of co-resident workgroups)
+#ifndef RP_TILE_TIMING
+#define RP_TILE_TIMING 0
 #endif
-// HW_REG_HW_ID (id 4) bits [3:0] = the wave's slot on its SIMD: s_getreg_b32 hwreg(4, 0, 4)
-#define RP_WAVE_SLOT() (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15)
-#define RP_APPLY_SLOT_PRIO()                                                      \
-    do {                                                                          \
-        if (RP_SLOT_PRIO == 1) { if (RP_WAVE_SLOT() & 1) __builtin_amdgcn_s_setprio(2); }                                  \
-        else if (RP_SLOT_PRIO == 2) { const unsigned sl_ = RP_WAVE_SLOT(); if (sl_ == 0) __builtin_amdgcn_s_setprio(3); else if (sl_ == 1) __builtin_amdgcn_s_setprio(2); else if (sl_ == 2) __builtin_amdgcn_s_setprio(1); } \
-    } while (0)
+#if RP_TILE_TIMING
+__device__ unsigned long long g_tile_timing[8];
+extern "C" int relpose_debug_tile_timing(unsigned long long* out8_host, int reset) {
+    if (out8_host && hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(g_tile_timing), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_timing), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifndef RP_STAGGER
 #define RP_STAGGER 0            // 0 = off; n = workgroups (blockIdx.x / n) % 3 get a start offset (see the k-loop prologue)
 #endif
@@ -158,22 +156,19 @@ __device__ __forceinline__ float2 rp_bufld2(__amdgpu_buffer_rsrc_t r, int voff, 
 // fragment per piece and row and issues the mode's partial products as v_mfma_f32_32x32x16_{f16,bf16}:
 //   SPLIT 1 / 2 (x3): lo hi, hi lo, hi hi       SPLIT 3 (plain f16): hi hi       SPLIT 5 (bf16x6): lo hi, hi lo, mid mid, mid hi, hi mid, hi hi
 //   SPLIT 4 (bf16x9): lo lo, lo mid, mid lo, then the six of SPLIT 5
-// A dependent v_mfma_f32_32x32x16 (same accumulator) issues 40 cycles after its predecessor, an independent one after 32 (measured,
-// profiles/r06_mfma_bf16_chain.txt: 43.4 vs 38.1 "cycles" per MFMA for one wave per SIMD), and with one accumulator per wave every MFMA
-// of the round-5 kernels depended on the previous one (SQ_WAIT_INST_ANY 45-55 % of wave-cycles at 52-58 % MFMA busy,
-// profiles/r06_scnet_sq_pmc_bf16x6_v1.txt).  So consecutive MFMAs never share an accumulator here:
-//   MI NI > 1: term-major order -- every term runs over all MI x NI accumulators before the next term;
-//   MI NI = 1: TWO chains -- the small terms accumulate in a temporary that starts at 0 (an inline constant) and is added to the
-//              accumulator once per call (16 VALU adds per 12-18 MFMAs), the large terms go to the accumulator itself, alternating.
+// Terms in ascending magnitude; where a wave holds several accumulators (MI NI > 1) the loop is TERM-major, so consecutive MFMAs go to different
+// accumulators (a dependent v_mfma_f32_32x32x16 issues ~40 cycles after its predecessor, an independent one after 32: profiles/r06_mfma_bf16_chain.txt).
+// That order is free; giving the one-accumulator tiles a second accumulator chain was measured and LOST (16 more registers: spills in
+// deconv_tile_kernel; profiles/r06_split_experiments.txt 4) -- the dependent-accumulator latency is not what holds these kernels.
 // The summation order is fixed per instantiation, so the results stay deterministic and plan-invariant (the self-stream cache and the
 // level-0 plan run the same calls in the same order as the full forward).
 template <int SPLIT> struct SplitTerms;
-template <> struct SplitTerms<1> { static constexpr int NP = 2, NT = 3, NSMALL = 2; static constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0}; };
-template <> struct SplitTerms<2> { static constexpr int NP = 2, NT = 3, NSMALL = 2; static constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0}; };
-template <> struct SplitTerms<3> { static constexpr int NP = 1, NT = 1, NSMALL = 0; static constexpr int ta[1] = {0}, tb[1] = {0}; };
-template <> struct SplitTerms<4> { static constexpr int NP = 3, NT = 9, NSMALL = 5;
+template <> struct SplitTerms<1> { static constexpr int NP = 2, NT = 3; static constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0}; };
+template <> struct SplitTerms<2> { static constexpr int NP = 2, NT = 3; static constexpr int ta[3] = {1, 0, 0}, tb[3] = {0, 1, 0}; };
+template <> struct SplitTerms<3> { static constexpr int NP = 1, NT = 1; static constexpr int ta[1] = {0}, tb[1] = {0}; };
+template <> struct SplitTerms<4> { static constexpr int NP = 3, NT = 9;
                                    static constexpr int ta[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, tb[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; };
-template <> struct SplitTerms<5> { static constexpr int NP = 3, NT = 6, NSMALL = 3;
+template <> struct SplitTerms<5> { static constexpr int NP = 3, NT = 6;
                                    static constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0}; };
 template <int SPLIT>
 __device__ __forceinline__ floatx16 rp_mfma16(const typename SplitT<SPLIT>::v8& a, const typename SplitT<SPLIT>::v8& b, const floatx16& c) {
@@ -184,32 +179,8 @@ template <int SPLIT, int MI, int NI>
 __device__ __forceinline__ void rp_split_mma(floatx16 (&acc)[MI][NI], const float* At, const int (&a_rows)[MI], const float* Bt, const int (&b_rows)[NI]) {
     typedef typename SplitT<SPLIT>::v8 h8;
     typedef SplitTerms<SPLIT> TT;
-    constexpr int NP = TT::NP, NT = TT::NT, NS = TT::NSMALL, NL = NT - NS;
-    if constexpr (MI * NI == 1 && NS > 0 && (RP_TWO_CHAIN == 1 || (RP_TWO_CHAIN == 2 && SPLIT >= 4))) {
-        floatx16 tmp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            h8 a[NP], b[NP];
-#pragma unroll
-            for (int pc = 0; pc < NP; ++pc) {
-                a[pc] = *reinterpret_cast<const h8*>(&At[a_rows[0] + pc * 16 + st * 8]);
-                b[pc] = *reinterpret_cast<const h8*>(&Bt[b_rows[0] + pc * 16 + st * 8]);
-            }
-            // small term, large term, small term, ... (the small terms in ascending size, then the large ones in ascending size)
-#pragma unroll
-            for (int k = 0; k < (NS > NL ? NS : NL); ++k) {
-                if (k < NS) tmp = rp_mfma16<SPLIT>(a[TT::ta[k]], b[TT::tb[k]], tmp);
-                if (k < NL) acc[0][0] = rp_mfma16<SPLIT>(a[TT::ta[NS + k]], b[TT::tb[NS + k]], acc[0][0]);
-            }
-            // (keep the scheduler from hoisting the next steps' fragment reads above these MFMAs: with four phases of accumulators live the
-            // tile kernels have no registers for a second set of fragments -- it spilled 18-125 registers without this fence)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] += tmp[r];
-    } else {
+    constexpr int NP = TT::NP, NT = TT::NT;
+    {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             h8 a[NP][MI], b[NP][NI];
@@ -731,7 +702,6 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
     __shared__ __attribute__((aligned(16))) float At[NPIX * LD];
     __shared__ __attribute__((aligned(16))) float Bt[4 * NI * 32 * LD];
     __shared__ __attribute__((aligned(16))) float sstab[2 * 512];   // per 4 channels: 4 scales, then 4 shifts
-    RP_APPLY_SLOT_PRIO();
     const ConvDesc* dh = descs + blockIdx.y * 4;
     const ConvDesc d = dh[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
@@ -944,6 +914,17 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
             if (snap_mode == 1 && ch + 1 == nch1) snap_store();     // the skip source is done: the accumulators for the self-cached forwards
         }
     } else {
+#if RP_TILE_TIMING
+        // experiment (tools/build_variant.py tt -DRP_TILE_TIMING=1): s_memtime stamps around the segments of the main loop, summed over the waves of
+        // the launch in g_tile_timing: [0] load issue, [1] MFMAs + fragment reads, [2] first barrier, [3] LDS stores (+ A transform), [4] second barrier,
+        // [5] prologue, [6] whole kernel, [7] waves
+        unsigned long long tt_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long tt_start_ = __builtin_readcyclecounter();
+        unsigned long long tt_prev_ = tt_start_;
+#define RP_TT(i_) { const unsigned long long n_ = __builtin_readcyclecounter(); tt_[i_] += n_ - tt_prev_; tt_prev_ = n_; }
+#else
+#define RP_TT(i_)
+#endif
         if (snap_mode == 2) snap_load();        // the accumulators as the full forward left them after the skip source's chunks
         RP_DT_LOAD_A(c0_of(k_first))
         RP_DT_LOAD_B(0, c0_of(k_first))
@@ -951,6 +932,7 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
         RP_DT_STORE_A(c0_of(k_first))
         RP_DT_STORE_B()
         __syncthreads();
+        RP_TT(5)
         for (int ch = k_first; ch < nchunk; ++ch) {
             const int c0 = c0_of(ch), c0n = c0_of(ch + 1 < nchunk ? ch + 1 : ch);
 #pragma unroll
@@ -959,6 +941,7 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
                 const bool last = (ch + 1 == nchunk);
                 if (p < 3) RP_DT_LOAD_B(p + 1, c0)
                 else if (!last) { RP_DT_LOAD_B(0, c0n) RP_DT_LOAD_A(c0n) }
+                RP_TT(0)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int aoff = aoffs[p][t];
@@ -969,13 +952,22 @@ __global__ __launch_bounds__(NW * 64, RP_DT_OCC(MI, NI, NW, SPLIT, PAIR)) void d
                     for (int j = 0; j < NI; ++j) br_[j] = brow + (t * NI + j) * 32 * LD;
                     rp_tile_mma<SPLIT, MI, NI>(acc[p], At, ar_, Bt, br_);
                 }
+                RP_TT(1)
                 __syncthreads();                                          // every wave is done with this phase's weights (and, p == 3, the halo tile)
+                RP_TT(2)
                 if (p < 3 || !last) RP_DT_STORE_B()
                 if (p == 3 && !last) RP_DT_STORE_A(c0n)
+                RP_TT(3)
                 __syncthreads();
+                RP_TT(4)
             }
             if (snap_mode == 1 && ch + 1 == nch1) snap_store();         // the skip source is done: the accumulators for the self-cached forwards
         }
+#if RP_TILE_TIMING
+        tt_[6] = __builtin_readcyclecounter() - tt_start_; tt_[7] = 1;
+        if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_tile_timing[i], tt_[i]);
+#endif
+#undef RP_TT
     }
 #undef RP_DT_LOAD_B2
 #undef RP_DT_STORE_B2
@@ -1059,7 +1051,6 @@ __global__ __launch_bounds__(256, SPLIT >= 4 ? 2 : (MI * NI <= 2 ? 4 : 3)) void 
     __shared__ __attribute__((aligned(16))) float At[NPIX * LD];
     __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LD];
     __shared__ __attribute__((aligned(16))) float sstab[2 * 128];
-    RP_APPLY_SLOT_PRIO();
     const ConvDesc d = descs[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ppx = d.Wp / PW, ppi = (d.Hp / PR) * ppx;
@@ -1283,7 +1274,6 @@ __global__ __launch_bounds__(256, SPLIT >= 4 ? 2 : 3) void conv_s2_strip_kernel(
     static_assert(BK == 32 && SMAX % PSTEP == 0 && B_ROWS % PSTEP == 0, "slot layout");
     __shared__ __attribute__((aligned(16))) float At[SMAX * LD];
     __shared__ __attribute__((aligned(16))) float Bt[B_ROWS * LD];
-    RP_APPLY_SLOT_PRIO();
     const ConvDesc d = descs[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int ks = blockIdx.y / d.ntiles_n, n0 = (blockIdx.y - ks * d.ntiles_n) * NI * 32;
