@@ -326,6 +326,9 @@ def main(argv=None):
     ap.add_argument("--keypoint-mode", choices=["given", "reference"], default="given",
                     help="reference: every level derives its keypoints from its own feature maps like rputil.getKeypoint (synthetic SIFT detections)")
     ap.add_argument("--sift", type=int, default=120, help="--keypoint-mode reference: synthetic SIFT detections per view")
+    ap.add_argument("--precision", choices=["f32", "bf16x9", "bf16x6", "f16x3", "bf16x3", "f16"], default="f32",
+                    help="conv arithmetic of SCNet (SCNet.set_precision): f32 = the fp32 MFMA kernels (default), bf16x6 = what bench.py runs configs 1-3 in")
+    ap.add_argument("--completion", type=int, default=1, choices=[0, 1], help="0 = the reference's 'ours_nc' method (evaluation.py:74): observed-region keypoints only")
     args = ap.parse_args(argv)
 
     def worker():
@@ -343,7 +346,8 @@ def main(argv=None):
         mm, S, tanh = ("kinect", 21, 0) if ds == "scannet" else ("second", 21 if ds == "matterport" else 15, 1)
         net = SCNet(SimpleNamespace(batchnorm=1, useTanh=tanh, skipLayer=1, outputType="rgbdnsf", snumclass=S))
         net.load_state_dict(weights.make_state_dict(7, S))
-        pipe = RelativePosePipeline(net, ds, mm, params.final_params(ds), keypoints=args.keypoint_mode)
+        net.set_precision(args.precision)
+        pipe = RelativePosePipeline(net, ds, mm, params.final_params(ds), keypoints=args.keypoint_mode, completion=args.completion)
         batches = [SyntheticBatch(min(args.batch, args.pairs - k), args.seed + k, ds, mm, args.keypoints,
                                   sift=args.sift if args.keypoint_mode == "reference" else 0) for k in range(0, args.pairs, args.batch)]
         path = None if args.exp is None else args.exp + ".result.npy"

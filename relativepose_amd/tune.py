@@ -28,7 +28,8 @@ class PrimitiveSet:
 
 def cache_primitives(pipe, batches, device=None):
     """The producer of the primitive cache (trainRelativePoseModuleRecFD.py:129-212): run the recurrent loop over `batches` (dicts in the
-    DataLoader layout of evaluation.evaluate_pairs: rgb / norm [B,2,3,h,4h], depth [B,2,h,4h], pts [B,2,N,2], ptw [B,2,N], R [B,2,4,4]) and keep
+    DataLoader layout of evaluation.evaluate_pairs: rgb / norm [B,2,3,h,4h], depth [B,2,h,4h], R [B,2,4,4] and pts [B,2,N,2], ptw [B,2,N] -- or, for a
+    keypoints="reference" pipeline, sift = [(source detections, target detections)] * B --) and keep
     the LAST level's matching primitives of every scan pair in the reference's dict format (:207-208)
 
         {'pc_src' [n,3], 'normal_src' [n,3], 'feat_src' [n,32] f32, 'weight_src' [n], 'pc_tgt', 'normal_tgt', 'feat_tgt', 'weight_tgt', 'R_gt' [4,4]}
@@ -40,7 +41,11 @@ def cache_primitives(pipe, batches, device=None):
     dev = device if device is not None else _lib.require_gpu()
     out = []
     for batch in batches:
-        st = pipe.prepare(batch["rgb"], batch["norm"], batch["depth"], batch["pts"], batch["ptw"], dev)
+        # either keypoint mode: "given" batches carry pts / ptw, keypoints="reference" batches carry the views' SIFT detections.
+        # Note for the kinect convention: the per-level sets hold up to 560 keypoints per view -- beyond the 512 targets of the affinity tile /
+        # pool kernels, so that mode's affinity build runs on the (slower) LDS kernel (csrc/affinity.hip)
+        from .evaluation import _prepare_batch
+        st = _prepare_batch(pipe, batch, dev)
         prim = {}
         pipe.run(st, primitives=prim)
         pc, nn, ft = (prim[k].cpu().numpy() for k in ("pc", "nn", "ft"))
