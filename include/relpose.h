@@ -298,7 +298,9 @@ int64_t relpose_scnet_num_params(const RelposeSCNet* net);
  * pieces (8 + 8 + 8 = 24 significand bits: a = a1 + a2 + a3 exactly, fp32 exponent range), all nine partial products
  * ai * bj (each exact in the fp32 accumulator) are issued as v_mfma_f32_32x32x16_bf16, smallest first, fp32 accumulation:
  * the arithmetic of the fp32 MFMA path (exact products, fp32 sums in another order) at 9/16 of its matrix-pipe cycles.
- * RELPOSE_PREC_BF16X6: the same without the three partial products below 2^-24 |a b| (a2 b3, a3 b2, a3 b3).
+ * RELPOSE_PREC_BF16X6: the same without the three smallest partial products a2 b3, a3 b2, a3 b3: what is dropped is at most 2^-23 |a b| (two terms of
+ * <= 2^-24 |a b|), observed maximum 2^-24.3 and rms 2^-27.4 over 2e6 random float32 pairs -- a correctly rounded fp32 multiply errs by up to 2^-24 |a b| with an rms
+ * of 2^-25.2 (tests/test_split_arithmetic_cpu.py): the size of one fp32 rounding per product, where the fp32 accumulation that follows rounds once per product anyway.
  * May be switched at any time after finalize. */
 enum { RELPOSE_PREC_F32 = 0, RELPOSE_PREC_BF16X3 = 1, RELPOSE_PREC_F16X3 = 2, RELPOSE_PREC_F16 = 3, RELPOSE_PREC_BF16X9 = 4, RELPOSE_PREC_BF16X6 = 5 };
 int relpose_scnet_set_precision(RelposeSCNet* net, int32_t mode);

@@ -49,7 +49,7 @@ template <> struct SplitT<3> { typedef f16x8 v8; typedef f16x4 v4; };     // pla
 // cut into three bfloat16 pieces a = a1 + a2 + a3 (8 + 8 + 8 = 24 significand bits: the sum is exact, bf16 has the fp32 exponent range),
 // every partial product ai * bj is exact in the fp32 accumulator (16 significand bits), and a * b = sum of the 9 partial products.
 // SPLIT 4 ("bf16x9") issues all nine v_mfma_f32_32x32x16_bf16 terms, smallest first; SPLIT 5 ("bf16x6") drops a2 b3, a3 b2, a3 b3
-// (<= 2^-24 |a b| each: below the rounding of the fp32 accumulation itself).
+// (the two larger ones <= 2^-24 |a b| each: together at most 2^-23 |a b|, rms 2^-27.4 -- the size of one fp32 rounding, of which the accumulation that follows makes one per product).
 typedef float rp_f4v __attribute__((ext_vector_type(4)));
 
 #ifndef RP_ABLATE
