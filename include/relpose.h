@@ -231,6 +231,10 @@ int relpose_interpolate(const float* feat, const float* pt, float* out, int32_t 
  * P = relpose_observed_points(h, dataset) (25600 or 66*88 at h = 160). */
 int32_t relpose_observed_points(int32_t h, int32_t dataset);
 int relpose_depth2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, int32_t h, int32_t dataset, void* stream);
+/* util.depth2pc's full-resolution kinect branch (util.py:497-507, reached from util.parse_data :79-90 for the baseline methods on
+ * ScanNet): depth [n, 480, 640] f32 IMAGES (no panorama around them) -> pc [n, 480*640, 3] f64 in pixel order, valid = depth != 0.
+ * The reference defines the branch for this one shape; any other returns RELPOSE_EINVAL (round 6). */
+int relpose_depth2pc_full(const float* depth, double* pc, uint8_t* valid, int32_t n, int32_t hh, int32_t ww, void* stream);
 
 /* Nearest-neighbour distances behind util.point_cloud_overlap (util.py:21-40, sklearn KDTree there):
  * dist[i] = min_j || pose*query_i - ref_j || over valid ref points (pose [12+] row-major 3x4/4x4, or NULL);
@@ -273,11 +277,33 @@ int relpose_keypoints_reference(const float* f, int64_t image_stride, int32_t fe
                                 void* stream);
 
 /* -------------------------------------------------------------------- SCNet
- * Replaces SCNet (model/mymodel.py:141-380; skipLayer=1, batchnorm=1, outputType 'rgbdnsf'). */
+ * Replaces SCNet (model/mymodel.py:141-380).  relpose_scnet_create builds the configuration evaluation.py runs
+ * (skipLayer=1, batchnorm=1, outputType 'rgbdnsf'); relpose_scnet_create_ex (round 6) the other constructor variants. */
 typedef struct RelposeSCNet RelposeSCNet;
 
 RelposeSCNet* relpose_scnet_create(int32_t snumclass, int32_t use_tanh);
 void relpose_scnet_destroy(RelposeSCNet* net);
+
+/* The reference constructor's switches (model/mymodel.py:145-149, 189-243: args.batchnorm, args.skipLayer, args.outputType).
+ *   batchnorm   1: conv -> BatchNorm(batch statistics) -> LeakyReLU (mymodel.py:16-21); 0: conv + bias -> LeakyReLU (:22-25;
+ *               state-dict keys "<block>.0.bias" instead of "<block>.1.weight|bias").
+ *   skip_layer  1: every decoder block also reads the encoder activation of its resolution (:302-307); 0: the plain chain (:335-340).
+ *   output_mask which heads exist, RELPOSE_OUT_* bits in the reference's concatenation order rgb, n, d, s, f (:309-376).  A head that
+ *               was not constructed has no parameters and its decoder branch does not run.
+ * NULL for what the reference cannot run either: skip_layer = 0 with any of rgb / n / d (their 1x1 output convs always take 64
+ * input channels, 32 of them the skip: the reference fails inside torch, mymodel.py:192 vs :347) and the 'k' head (reads an
+ * undefined `xsift`, :328).
+ * The forward's `out` keeps the layout [n, 7 + snumclass + 32, H, W] for every variant: the channels of a head that does not
+ * exist are 0 (the reference concatenates only the existing heads; relativepose_amd.model.SCNet gathers them).  Variants run the
+ * same kernels under the plain launch plan on ONE stream: RELPOSE_FWD_ZERO_WARP / _POSE_OUTPUTS, `self_tag` and `tail_stream`
+ * are accepted and ignored (each is "bitwise the plain forward" by contract). */
+enum { RELPOSE_OUT_RGB = 1, RELPOSE_OUT_N = 2, RELPOSE_OUT_D = 4, RELPOSE_OUT_S = 8, RELPOSE_OUT_F = 16, RELPOSE_OUT_ALL = 31 };
+typedef struct RelposeSCNetConfig {
+    uint32_t struct_size;       /* sizeof(RelposeSCNetConfig) as the caller compiled it */
+    int32_t snumclass, use_tanh;
+    int32_t batchnorm, skip_layer, output_mask;
+} RelposeSCNetConfig;
+RelposeSCNet* relpose_scnet_create_ex(const RelposeSCNetConfig* cfg);
 
 /* One state_dict entry (key names = the reference module tree, e.g. "conv4.0.weight",
  * "deconv3rgb.1.bias", "deconv1f.weight"); data_host float32 in torch layout. */

@@ -3,8 +3,11 @@ of SCNet.forward, the completion + feature network.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this.  Follows /root/reference/model/mymodel.py: block builders :15-39, module
-tree :142-257, forward :259-380 (``skipLayer=1``, ``batchnorm=1``,
-``outputType='rgbdnsf'`` -- the configuration evaluation.py runs).  BatchNorm
+tree :142-257, forward :259-380.  Defaults ``skipLayer=1``, ``batchnorm=1``,
+``outputType='rgbdnsf'`` are the configuration evaluation.py runs; the other
+constructor variants (``batchnorm=0``: conv + bias + LeakyReLU, :22-25;
+``skipLayer=0``: the decoder without concatenations, :335-340; ``outputType``:
+which heads exist, :189-243) are restated too (round 6).  BatchNorm
 layers are built with track_running_stats=False (:19,32) so batch statistics
 are used at inference; the net is always fed a batch of 2 (evaluation.py:242).
 Pinned against the reference module (same state_dict) by make_golden.py.
@@ -22,23 +25,25 @@ def _t(a):
 
 
 class SCNetOracle:
-    def __init__(self, state_dict, snumclass=15, use_tanh=1):
+    def __init__(self, state_dict, snumclass=15, use_tanh=1, batchnorm=1, skip_layer=1, output_type="rgbdnsf"):
         self.p = {k: _t(v).float() for k, v in state_dict.items()}
         self.S = snumclass
         self.use_tanh = use_tanh
+        self.batchnorm, self.skip, self.output_type = batchnorm, skip_layer, output_type
         self.taps = {}
 
     def _bn_act(self, x, name):
-        x = F.batch_norm(x, None, None, self.p[f"{name}.1.weight"], self.p[f"{name}.1.bias"], True, 0.1, 1e-5)
-        return F.leaky_relu(x, 0.1)
+        if self.batchnorm:                                                      # mymodel.py:16-21 / :29-34
+            x = F.batch_norm(x, None, None, self.p[f"{name}.1.weight"], self.p[f"{name}.1.bias"], True, 0.1, 1e-5)
+        return F.leaky_relu(x, 0.1)                                             # (:22-25 / :35-38: the conv carried its bias)
 
     def conv(self, x, name, stride, pad):
-        y = F.conv2d(x, self.p[f"{name}.0.weight"], None, stride, pad)
+        y = F.conv2d(x, self.p[f"{name}.0.weight"], None if self.batchnorm else self.p[f"{name}.0.bias"], stride, pad)
         self.taps[name] = y
         return self._bn_act(y, name)
 
     def deconv(self, x, name, stride, pad):
-        y = F.conv_transpose2d(x, self.p[f"{name}.0.weight"], None, stride, pad)
+        y = F.conv_transpose2d(x, self.p[f"{name}.0.weight"], None if self.batchnorm else self.p[f"{name}.0.bias"], stride, pad)
         self.taps[name] = y
         return self._bn_act(y, name)
 
@@ -67,19 +72,25 @@ class SCNetOracle:
         x7 = self.conv(x6, "conv7", 2, 0)
         x8 = self.conv(x7, "conv8", 1, 1)
         x9 = self.conv(x8, "conv9", 1, 0)
+        sk = (lambda a, b: cat((a, b), 1)) if self.skip else (lambda a, b: a)   # mymodel.py:302-307 vs :335-340
         d9 = self.deconv(x9, "deconv9", 1, 0)
-        d8 = self.deconv(cat((d9, x8), 1), "deconv8", 1, 1)
-        d7 = self.deconv(cat((d8, x7), 1), "deconv7", 2, 0)
-        d6 = self.deconv(cat((d7, x6), 1), "deconv6", 2, 1)
-        d5 = self.deconv(cat((d6, x5), 1), "deconv5", 2, 1)
-        d4 = self.deconv(cat((d5, x4), 1), "deconv4", 2, 1)
+        d8 = self.deconv(sk(d9, x8), "deconv8", 1, 1)
+        d7 = self.deconv(sk(d8, x7), "deconv7", 2, 0)
+        d6 = self.deconv(sk(d7, x6), "deconv6", 2, 1)
+        d5 = self.deconv(sk(d6, x5), "deconv5", 2, 1)
+        d4 = self.deconv(sk(d5, x4), "deconv4", 2, 1)
         outs = []
         for m in ("rgb", "n", "d"):
+            if m not in self.output_type:
+                continue
             x1, x2, x3 = enc[m]
-            d3 = self.deconv(cat((d4, x3), 1), f"deconv3{m}", 2, 1)
-            d2 = self.deconv(cat((d3, x2), 1), f"deconv2{m}", 2, 1)
-            outs.append(self.head(cat((d2, x1), 1), f"deconv1{m}"))
+            d3 = self.deconv(sk(d4, x3), f"deconv3{m}", 2, 1)
+            d2 = self.deconv(sk(d3, x2), f"deconv2{m}", 2, 1)
+            # (skipLayer=0, :347: the 1x1 conv takes 64 channels and gets 32 -- torch raises there, and so does this head())
+            outs.append(self.head(sk(d2, x1), f"deconv1{m}"))
         for m in ("s", "f"):
+            if m not in self.output_type:
+                continue
             d3 = self.deconv(d4, f"deconv3{m}", 2, 1)
             d2 = self.deconv(d3, f"deconv2{m}", 2, 1)
             o = self.head(d2, f"deconv1{m}")

@@ -38,6 +38,12 @@ class ForwardArgs(C.Structure):
                 ("self_tag", C.c_uint64), ("workspace_generation", C.c_uint64), ("reserved1", c_void_p)]
 
 
+class SCNetConfig(C.Structure):
+    """RelposeSCNetConfig (include/relpose.h): the reference constructor's switches, relpose_scnet_create_ex."""
+    _fields_ = [("struct_size", C.c_uint32), ("snumclass", c_int), ("use_tanh", c_int), ("batchnorm", c_int), ("skip_layer", c_int),
+                ("output_mask", c_int)]
+
+
 class MatchArgs(C.Structure):
     """RelposeMatchArgs (include/relpose.h): the argument block of relpose_match_pairs_ex -- the per-call choices travel with the call."""
     _fields_ = [("struct_size", C.c_uint32), ("fit_cluster", c_int), ("params_host", C.POINTER(Params)), ("kp_host", C.POINTER(Keypoints)),
@@ -69,6 +75,7 @@ SIGNATURES = {
     "relpose_interpolate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "relpose_observed_points": (c_int, [c_int, c_int]),
     "relpose_depth2pc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "relpose_depth2pc_full": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "relpose_nn_dist": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "relpose_feature_distance_map": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "relpose_nms_sampling": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -76,6 +83,7 @@ SIGNATURES = {
     "relpose_keypoints_reference": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "relpose_scnet_create": (c_void_p, [c_int, c_int]),
+    "relpose_scnet_create_ex": (c_void_p, [C.POINTER(SCNetConfig)]),
     "relpose_scnet_destroy": (None, [c_void_p]),
     "relpose_scnet_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t]),
     "relpose_scnet_finalize": (c_int, [c_void_p]),

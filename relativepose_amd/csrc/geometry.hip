@@ -381,6 +381,21 @@ __global__ void depth2pc_kernel(const float* __restrict__ depth, double* __restr
     }
 }
 
+// util.depth2pc's full-resolution kinect branch (util.py:497-507): a 480 x 640 depth IMAGE (not a block of a panorama) back-projected with
+// the ScanNet intrinsics folded into the two divisors; feeds the baselines' point clouds through util.parse_data :79-90.
+__global__ void depth2pc_full_kernel(const float* __restrict__ depth, double* __restrict__ pc, uint8_t* __restrict__ valid, int hh, int ww) {
+    const int img = blockIdx.y, np_ = hh * ww;
+    const float* d = depth + (size_t)img * np_;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < np_; p += gridDim.x * blockDim.x) {
+        const int v = p / ww, u = p - v * ww;
+        const double z = (double)d[p];
+        const double xs = ((double)u / ww - 0.5) * 2, ys = (0.5 - (double)v / hh) * 2;
+        double* o = pc + ((size_t)img * np_ + p) * 3;
+        o[0] = (xs * z) / (0.8921875 * 2); o[1] = (ys * z) / (1.1895 * 2); o[2] = -z;
+        valid[(size_t)img * np_ + p] = (z != 0.0);
+    }
+}
+
 // Nearest-neighbour distance of every (optionally rigidly moved) query point to a reference set: brute force,
 // reference points staged through LDS in tiles of 1024.  Replaces the sklearn KDTree queries of
 // util.point_cloud_overlap (util.py:21-40); distances are sqrt((dx^2+dy^2)+dz^2) like KDTree's metric.
@@ -576,6 +591,14 @@ int relpose_depth2pc(const float* depth, double* pc, uint8_t* valid, int32_t n, 
     if (!depth || !pc || !valid || n <= 0 || h <= 0 || dataset < 0 || dataset > 2) return RELPOSE_EINVAL;
     const WarpSrc src = warp_src(dataset, h);
     hipLaunchKernelGGL(depth2pc_kernel, dim3((src.npts + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, depth, pc, valid, n, h, dataset, src);
+    RP_CHECK_LAUNCH();
+    return 0;
+}
+
+int relpose_depth2pc_full(const float* depth, double* pc, uint8_t* valid, int32_t n, int32_t hh, int32_t ww, void* stream) {
+    // (the reference defines this branch for exactly one shape, util.py:498; any other leaves its `pc` unbound)
+    if (!depth || !pc || !valid || n <= 0 || hh != 480 || ww != 640) return RELPOSE_EINVAL;
+    hipLaunchKernelGGL(depth2pc_full_kernel, dim3((hh * ww + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, depth, pc, valid, hh, ww);
     RP_CHECK_LAUNCH();
     return 0;
 }

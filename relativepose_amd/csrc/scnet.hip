@@ -1911,6 +1911,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nchun
     ss[(size_t)g * C + c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
 }
 
+// batchnorm = 0 nets (mymodel.py:22-25): the buffer's {scale, shift} are constants, {1, conv bias} (`gamma` / `beta` hold them), for every group
+__global__ void ss_fill_kernel(int C, int G, const float* __restrict__ gamma, const float* __restrict__ beta, float2* __restrict__ ss) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * G) return;
+    const int c = i % C;
+    ss[i] = make_float2(gamma[c], beta[c]);
+}
+
 // Same for record lists of up to a few hundred entries: a workgroup = 32 consecutive channels x 32 record parts of one group (lane =
 // channel: coalesced record reads); part k adds records k, k + 32, ..., the parts are then added in order.
 // skip_blk > 0 (self-stream cache): the even blocks of skip_blk channels (the self-view streams) keep the {scale, shift} they have
@@ -2158,6 +2166,11 @@ struct Buf { std::string name; int H, C; size_t off /*floats per image*/, ss_off
 
 struct RelposeSCNet {
     int S, use_tanh, cf;
+    // constructor variants (mymodel.py:145-149): BatchNorm after every conv (else a conv bias), skip concatenations in the decoder, and which of the
+    // five heads {rgb, n, d, s, f} exist (bit m of omask).  The evaluation.py configuration is bn = skip = 1, omask = 31; anything else is a
+    // `variant()`: same kernels, plain plans only (no level-0 / self-stream-cache / pose-output plans)
+    int bn = 1, skip = 1, omask = 31;
+    bool variant() const { return !(bn && skip && omask == 31); }
     std::map<std::string, std::vector<float>> params;   // raw state dict (host)
     std::map<std::string, std::vector<int64_t>> shapes;
     bool finalized = false;
@@ -2190,9 +2203,10 @@ namespace {
 
 struct LayerSpec { const char* name; int kind, cin, cout, k, s, p; };
 
-std::vector<LayerSpec> layer_specs(int S) {
+std::vector<LayerSpec> layer_specs(const RelposeSCNet* net) {
     std::vector<LayerSpec> t;
-    const int g = 64;
+    const int g = 64, S = net->S;
+    const int sm = net->skip ? 2 : 1;                                  // skip_multiplier (mymodel.py:149)
     t.push_back({"conv1", 0, 16, 192, 3, 1, 1});                       // fused conv1{rgb,n,d} x {self,t2s}
     const char* mods[3] = {"rgb", "n", "d"};
     static std::string names[64];
@@ -2208,20 +2222,30 @@ std::vector<LayerSpec> layer_specs(int S) {
     t.push_back({"conv8", 0, g * 8, g * 8, 3, 1, 1});
     t.push_back({"conv9", 0, g * 8, g * 16, 3, 1, 0});
     t.push_back({"deconv9", 1, g * 16, g * 8, 3, 1, 0});
-    t.push_back({"deconv8", 1, g * 16, g * 8, 3, 1, 1});
-    t.push_back({"deconv7", 1, g * 16, g * 8, 3, 2, 0});
-    t.push_back({"deconv6", 1, g * 16, g * 8, 4, 2, 1});
-    t.push_back({"deconv5", 1, g * 16, g * 4, 4, 2, 1});
-    t.push_back({"deconv4", 1, g * 8, g * 2, 4, 2, 1});
+    t.push_back({"deconv8", 1, g * 8 * sm, g * 8, 3, 1, 1});
+    t.push_back({"deconv7", 1, g * 8 * sm, g * 8, 3, 2, 0});
+    t.push_back({"deconv6", 1, g * 8 * sm, g * 8, 4, 2, 1});
+    t.push_back({"deconv5", 1, g * 8 * sm, g * 4, 4, 2, 1});
+    t.push_back({"deconv4", 1, g * 4 * sm, g * 2, 4, 2, 1});
     const int hc[5] = {3, 3, 1, S, 32};
     const char* heads[5] = {"rgb", "n", "d", "s", "f"};
     for (int m = 0; m < 5; ++m) {
-        const bool skip = m < 3;
+        if (!((net->omask >> m) & 1)) continue;                        // (a head that was not constructed has no parameters: mymodel.py:189-243)
+        const bool skip = m < 3;                                       // (rgb / n / d exist with skip connections only: relpose_scnet_create_ex)
         names[ni] = std::string("deconv3") + heads[m]; t.push_back({names[ni++].c_str(), 1, skip ? g * 4 : g * 2, g, 4, 2, 1});
         names[ni] = std::string("deconv2") + heads[m]; t.push_back({names[ni++].c_str(), 1, skip ? g * 2 : g, skip ? g / 2 : g, 4, 2, 1});
         names[ni] = std::string("deconv1") + heads[m]; t.push_back({names[ni++].c_str(), 2, g, hc[m], 1, 1, 0});
     }
     return t;
+}
+
+// index in {rgb, n, d, s, f} of the head a decoder block belongs to ("deconv3n" -> 1), -1 for the shared trunk
+int head_of(const std::string& block) {
+    if (block.compare(0, 7, "deconv3") && block.compare(0, 7, "deconv2") && block.compare(0, 7, "deconv1")) return -1;
+    const std::string h = block.substr(7);
+    const char* heads[5] = {"rgb", "n", "d", "s", "f"};
+    for (int m = 0; m < 5; ++m) if (h == heads[m]) return m;
+    return -1;
 }
 
 // input channels of the resized net input used by conv1 block q = 2*m + s  (mymodel.py:264-286)
@@ -2423,7 +2447,7 @@ std::vector<std::pair<std::string, int>> bn_blocks(const std::string& b) {
 // (sub-pixel phases of a transposed conv, the six shared-weight encoder streams, parallel heads) are
 // merged into ONE grid (blockIdx.z = member) so the 256 CUs see thousands of tiles per launch instead
 // of a few hundred (wave quantisation); layers with few output tiles are split along K.
-enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7, OP_CONV_STRIP = 8, OP_BCAST = 9, OP_NOP = 10 };
+enum { OP_CONV = 0, OP_REDUCE = 1, OP_STATS = 2, OP_CONV1 = 3, OP_STATS_FUSED = 4, OP_HEADS = 5, OP_DECONV_TILE = 6, OP_CONV_S2 = 7, OP_CONV_STRIP = 8, OP_BCAST = 9, OP_NOP = 10, OP_SS_FILL = 11 };
 struct Op { int type; int first, count, cfg; dim3 grid; std::string buf; int sslds = 0, uni = 0, split = 0; int ninner = 1, mt_max = 1; int skip_blk = 0; };
 
 struct Plan {
@@ -2482,6 +2506,14 @@ constexpr int MAX_DESCS = 256;
 
 void Builder::stats(const std::string& b) {
     Op o; o.buf = b; o.cfg = 0;
+    if (!net->bn) {
+        // batchnorm = 0: nothing to measure -- the buffer's {scale, shift} are the constants {1, conv bias} (relpose_scnet_finalize)
+        if (pend_first >= 0) for (int i = pend_first; i < pend_first + pend_count; ++i) plan->descs[i].stat_part = nullptr;
+        o.type = OP_SS_FILL; o.first = o.count = 0;
+        plan->ops.push_back(o);
+        pend_first = -1; pend_count = 0; pend_reduce = -1; pend_groups = 0;
+        return;
+    }
     if (pend_first >= 0 && pend_ok) { o.type = OP_STATS_FUSED; o.first = pend_first; o.count = pend_count; o.cfg = pend_bm; }
     else {
         o.type = OP_STATS; o.first = o.count = 0;
@@ -2785,7 +2817,7 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     // encoder, three modalities x two streams in concatenated buffers (mymodel.py:266-291)
     { Op o; o.type = OP_CONV1; o.first = o.count = o.cfg = 0; R.plan->ops.push_back(o); }   // direct kernel
     R.stats("A1");
-    R.plan->ops.back().cfg = 1;                   // partial records already written by conv1_direct_kernel
+    if (net->bn) R.plan->ops.back().cfg = 1;      // partial records already written by conv1_direct_kernel
     if (R.self_cached) R.plan->ops.back().skip_blk = 32;
     R.plan->head_count = (int)R.plan->ops.size();
     if (R.self_cached) {
@@ -2848,17 +2880,20 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
     one("conv8", R.src("A7", 0, 512), nullptr, 3, "A8", 0); R.stats("A8");
     one("conv9", R.src("A8", 0, 512), nullptr, 3, "A9", 0); R.stats("A9");
     // decoder with skip concatenations (mymodel.py:302-307)
+    // (skipLayer = 0, mymodel.py:335-340: the same chain without the second source)
     Src sk;
+    const Src* skp = net->skip ? &sk : nullptr;
     one("deconv9", R.src("A9", 0, 1024), nullptr, 1, "D9", 0); R.stats("D9");
-    sk = R.src("A8", 0, 512); one("deconv8", R.src("D9", 0, 512), &sk, 3, "D8", 0); R.stats("D8");
-    sk = R.src("A7", 0, 512); one("deconv7", R.src("D8", 0, 512), &sk, 3, "D7", 0); R.stats("D7");
-    sk = R.src("A6", 0, 512); one("deconv6", R.src("D7", 0, 512), &sk, 7, "D6", 0); R.stats("D6");
+    sk = R.src("A8", 0, 512); one("deconv8", R.src("D9", 0, 512), skp, 3, "D8", 0); R.stats("D8");
+    sk = R.src("A7", 0, 512); one("deconv7", R.src("D8", 0, 512), skp, 3, "D7", 0); R.stats("D7");
+    sk = R.src("A6", 0, 512); one("deconv6", R.src("D7", 0, 512), skp, 7, "D6", 0); R.stats("D6");
     R.plan->mid_end = (int)R.plan->ops.size();
-    sk = R.src("A5", 0, 512); one("deconv5", R.src("D6", 0, 512), &sk, 14, "D5", 0); R.stats("D5");
-    sk = R.src("A4", 0, 256); one("deconv4", R.src("D5", 0, 256), &sk, 28, "D4", 0); R.stats("D4");
+    sk = R.src("A5", 0, 512); one("deconv5", R.src("D6", 0, 512), skp, 14, "D5", 0); R.stats("D5");
+    sk = R.src("A4", 0, 256); one("deconv4", R.src("D5", 0, 256), skp, 28, "D4", 0); R.stats("D4");
     // heads (mymodel.py:309-376): rgb/n/d with skips from the self stream, s/f without
     // (RELPOSE_FWD_POSE_OUTPUTS: the rgb and semantic branches feed nothing the pose path reads; their blocks of D3 / D2 stay unwritten)
-    auto wanted = [&](int m) { return !R.pose_only || (m != 0 && m != 3); };
+    // (a net constructed without a head -- outputType, mymodel.py:189-243 -- leaves that head's blocks to the memset in front of the forward)
+    auto wanted = [&](int m) { return ((net->omask >> m) & 1) && (!R.pose_only || (m != 0 && m != 3)); };
     R.begin_group();
     for (int m = 0; m < 5; ++m) {
         if (!wanted(m)) continue;
@@ -2879,6 +2914,7 @@ void build_plan(RelposeSCNet* net, int n, Builder& R) {
         const int ooff[5] = {0, 3, 6, 7, 7 + net->S};
         R.begin_group();
         for (int m = 0; m < 5; ++m) {
+            if (!wanted(m)) continue;
             if (m < 3) { sk = R.src("A1", 2 * m * 32, 32); R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 32), &sk, 224, "OUT", ooff[m]); }
             else R.conv(std::string("deconv1") + heads[m], R.src("D2", d2off[m], 64), nullptr, 224, "OUT", ooff[m]);
         }
@@ -2943,6 +2979,19 @@ RelposeSCNet* relpose_scnet_create(int32_t snumclass, int32_t use_tanh) {
     return net;
 }
 
+RelposeSCNet* relpose_scnet_create_ex(const RelposeSCNetConfig* cfg) {
+    if (!cfg || cfg->struct_size < sizeof(RelposeSCNetConfig)) return nullptr;
+    const int om = cfg->output_mask;
+    if (om <= 0 || om > 31) return nullptr;
+    // without skip connections the reference can only build the s / f heads: its 1x1 rgb / n / d output convs always take 64 channels, 32 of them
+    // the skip (mymodel.py:192,200,208 vs :344-360 -- that combination raises inside torch); 'k' reads an undefined xsift (:328) in either mode
+    if (!cfg->skip_layer && (om & (RELPOSE_OUT_RGB | RELPOSE_OUT_N | RELPOSE_OUT_D))) return nullptr;
+    RelposeSCNet* net = relpose_scnet_create(cfg->snumclass, cfg->use_tanh);
+    if (!net) return nullptr;
+    net->bn = cfg->batchnorm ? 1 : 0; net->skip = cfg->skip_layer ? 1 : 0; net->omask = om;
+    return net;
+}
+
 void relpose_scnet_destroy(RelposeSCNet* net) {
     if (!net) return;
     if (net->d_w) (void)hipFree(net->d_w);
@@ -2978,7 +3027,7 @@ int relpose_scnet_finalize(RelposeSCNet* net) {
     free_plan(net);                  // descriptors of an earlier state dict point into the blob that is re-allocated below
     std::vector<float> blob;
     net->layers.clear();
-    for (const LayerSpec& sp : layer_specs(net->S)) {
+    for (const LayerSpec& sp : layer_specs(net)) {
         int rc = pack_layer(net, sp, blob);
         if (rc) return rc;
     }
@@ -3009,6 +3058,7 @@ int relpose_scnet_finalize(RelposeSCNet* net) {
         if (net->S > 24) return RELPOSE_EINVAL;
         int ob = 0;
         for (int m = 0; m < 5; ++m) {
+            if (!((net->omask >> m) & 1)) { ob += hc[m]; continue; }       // a head that was not constructed: zero weights and bias, its channels come out 0
             const float* W = net->params[std::string("deconv1") + hn[m] + ".weight"].data();     // [Cout][64]
             const float* Bv = net->params[std::string("deconv1") + hn[m] + ".bias"].data();
             for (int o = 0; o < hc[m]; ++o) {
@@ -3038,9 +3088,20 @@ int relpose_scnet_finalize(RelposeSCNet* net) {
             gb.resize(gboff + 2 * (size_t)b.C, 0.f);
             int c = 0;
             for (auto& blk : blocks) {
-                if (!have(net, blk.first + ".1.weight", blk.second) || !have(net, blk.first + ".1.bias", blk.second)) return RELPOSE_EINVAL;
-                memcpy(gb.data() + gboff + c, net->params[blk.first + ".1.weight"].data(), blk.second * sizeof(float));
-                memcpy(gb.data() + gboff + b.C + c, net->params[blk.first + ".1.bias"].data(), blk.second * sizeof(float));
+                const int hm = head_of(blk.first);
+                if (hm >= 0 && !((net->omask >> hm) & 1)) { c += blk.second; continue; }   // no such head: {gamma, beta} = 0, the block's activations read as 0
+                if (net->bn) {
+                    if (!have(net, blk.first + ".1.weight", blk.second) || !have(net, blk.first + ".1.bias", blk.second)) return RELPOSE_EINVAL;
+                    memcpy(gb.data() + gboff + c, net->params[blk.first + ".1.weight"].data(), blk.second * sizeof(float));
+                    memcpy(gb.data() + gboff + b.C + c, net->params[blk.first + ".1.bias"].data(), blk.second * sizeof(float));
+                } else {
+                    // batchnorm = 0 (mymodel.py:22-25): conv + bias + LeakyReLU.  The consumer's loader computes lrelu(scale * y + shift) anyway,
+                    // so the table holds {1, bias} -- 1 * y + bias is the bias add, rounded once like the reference's -- and OP_SS_FILL copies it
+                    // where the BatchNorm finalize would have written {gamma / sigma, beta - mean * gamma / sigma}
+                    if (!have(net, blk.first + ".0.bias", blk.second)) return RELPOSE_EINVAL;
+                    for (int i = 0; i < blk.second; ++i) gb[gboff + c + i] = 1.f;
+                    memcpy(gb.data() + gboff + b.C + c, net->params[blk.first + ".0.bias"].data(), blk.second * sizeof(float));
+                }
                 c += blk.second;
             }
             if (c != b.C) return RELPOSE_EINVAL;
@@ -3092,8 +3153,11 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
     const float* x = args->x; float* out = args->out;
     const int32_t n = args->n_images, H = args->H, W = args->W, flags = args->flags;
     void* workspace = args->workspace; const size_t workspace_bytes = args->workspace_bytes;
-    void* stream = args->stream; void* tail_stream = args->tail_stream ? args->tail_stream : args->stream;
-    const uint64_t self_tag = args->struct_size >= offsetof(RelposeForwardArgs, self_tag) + sizeof(uint64_t) ? args->self_tag : 0;
+    // a constructor variant (relpose_scnet_create_ex) runs the plain plan on one stream: the level-0 / pose-output / self-stream-cache plans and
+    // the two-stream form are built for the evaluation.py configuration only, and every one of them is "bitwise the plain forward" by contract
+    const bool variant = net->variant();
+    void* stream = args->stream; void* tail_stream = (args->tail_stream && !variant) ? args->tail_stream : args->stream;
+    const uint64_t self_tag = (!variant && args->struct_size >= offsetof(RelposeForwardArgs, self_tag) + sizeof(uint64_t)) ? args->self_tag : 0;
     const uint64_t ws_gen = args->struct_size >= offsetof(RelposeForwardArgs, workspace_generation) + sizeof(uint64_t) ? args->workspace_generation : 0;
     if (!net->finalized || !x || !out || !workspace || n <= 0 || (n & 1) || H <= 0 || W <= 0 || n >= (1 << 24)) return RELPOSE_EINVAL;
     if (flags & ~(RELPOSE_FWD_ZERO_WARP | RELPOSE_FWD_POSE_OUTPUTS | RELPOSE_FWD_NEW_WORKSPACE | RELPOSE_FWD_PART_FRONT | RELPOSE_FWD_PART_BACK)) return RELPOSE_EINVAL;
@@ -3108,8 +3172,8 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
 #endif
     const int G = n / 2;
     // (nothing to share with one BatchNorm group; the tile kernels' patch pairing wants the 2-image members' patch count even as well)
-    const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2;
-    const bool pose_only = (flags & RELPOSE_FWD_POSE_OUTPUTS) != 0;
+    const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2 && !variant;
+    const bool pose_only = (flags & RELPOSE_FWD_POSE_OUTPUTS) != 0 && !variant;
     Plan* plan = nullptr;
     RelposeSCNet::SelfState commit;          // what the workspace holds once this forward is through
     commit.tag = self_tag; commit.n = n; commit.H = H; commit.W = W; commit.pose_only = pose_only; commit.gen = ws_gen;
@@ -3189,6 +3253,14 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
     };
     const bool mid_split = plan->mid_first >= 0 && plan->mid_end > plan->mid_first && plan->mid_first >= plan->head_count && plan->mid_end <= plan->tail_first;
     if (part && !mid_split) return RELPOSE_EINVAL;
+    if (net->omask != 31) {
+        // heads the net was constructed without: their blocks of D3 / D2 (and, on the generic heads path, their channels of OUT) are written by
+        // nobody -- zero them so that what the heads kernel multiplies by its zero weights is finite; their output channels come out 0
+        for (const char* bn_ : {"D3", "D2", "OUT"}) {
+            const Buf& B = net->bufs[bn_];
+            RP_HIP(hipMemsetAsync(act + B.off * n, 0, (size_t)n * B.H * B.H * B.C * sizeof(float), s));
+        }
+    }
     if (part != RELPOSE_FWD_PART_BACK) {
         mark(3);
         hipLaunchKernelGGL(resize_in_kernel, dim3(2048), dim3(256), 0, s, x, act + net->bufs["X0"].off * n, n, H, W, plan->self_cached ? 8 : 0);
@@ -3360,6 +3432,12 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
             hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((B.C + 31) / 32, G), dim3(1024), 0, s, plan->d_descs + op.first, op.count, op.skip_blk,
                                B.C, 2 * B.H * B.H, net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C, ssp + B.ss_off * G);
             mark(-2);
+        } else if (op.type == OP_SS_FILL) {
+            const Buf& B = net->bufs[op.buf];
+            mark(2);
+            hipLaunchKernelGGL(ss_fill_kernel, dim3((B.C * G + 255) / 256), dim3(256), 0, s, B.C, G, net->d_gb + B.gb_off, net->d_gb + B.gb_off + B.C,
+                               ssp + B.ss_off * G);
+            mark(-2);
         } else if (op.type == OP_BCAST) {
             const Buf& B = net->bufs[op.buf];
             mark(2);
@@ -3437,6 +3515,7 @@ int relpose_scnet_forward_ex(RelposeSCNet* net, const RelposeForwardArgs* args) 
 // it by the same count of the full plan.  Host-only (a dry-run plan build: no device memory is touched).
 int relpose_scnet_plan_macs(RelposeSCNet* net, int32_t n, int32_t flags, int32_t self_cached, double* macs_out) {
     if (!net || !net->finalized || !macs_out || n <= 0 || (n & 1)) return RELPOSE_EINVAL;
+    if (net->variant()) { flags = 0; self_cached = 0; }          // (constructor variants run the plain plan whatever the flags)
     const bool zero_warp = (flags & RELPOSE_FWD_ZERO_WARP) && n > 2 && !self_cached;
     const bool pose_only = (flags & RELPOSE_FWD_POSE_OUTPUTS) != 0;
     Plan dry;

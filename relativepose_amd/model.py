@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .weights import state_dict_spec
+from .weights import HEADS, head_channels, parse_output_type, state_dict_spec
 
 # relpose_scnet_set_precision modes (include/relpose.h: RELPOSE_PREC_*)
 PRECISION_CODES = {"f32": 0, "bf16x3": 1, "f16x3": 2, "f16": 3, "bf16x9": 4, "bf16x6": 5}
@@ -35,14 +35,33 @@ class SCNet(torch.nn.Module):
 
     def __init__(self, args):
         super().__init__()
-        if not getattr(args, "batchnorm", 1) or not getattr(args, "skipLayer", 1):
-            raise NotImplementedError("only batchnorm=1, skipLayer=1 (the evaluation.py configuration) is built")
-        if getattr(args, "outputType", "rgbdnsf") != "rgbdnsf":
-            raise NotImplementedError("only outputType='rgbdnsf' is built")
         self.snumclass = int(args.snumclass)
         self.useTanh = int(getattr(args, "useTanh", 1))
-        self.out_channels = 7 + self.snumclass + 32
-        self._h = _lib.lib().relpose_scnet_create(self.snumclass, self.useTanh)
+        # the constructor variants (mymodel.py:145-149, 189-243).  What the reference itself cannot run raises ValueError here: 'k' in
+        # outputType (its forward reads an undefined xsift, :328) and skipLayer=0 with an rgb / n / d head (64-channel 1x1 convs fed 32, :347)
+        self.batchnorm = int(bool(getattr(args, "batchnorm", 1)))
+        self.skipLayer = int(bool(getattr(args, "skipLayer", 1)))
+        self.outputType = str(getattr(args, "outputType", "rgbdnsf"))
+        self.heads = parse_output_type(self.outputType)
+        self._spec = state_dict_spec(self.snumclass, self.batchnorm, self.skipLayer, self.outputType)
+        hc = head_channels(self.snumclass)
+        # the library keeps the full layout [rgb 3 | n 3 | d 1 | s S | f 32] (absent heads = 0); the reference concatenates the heads that exist
+        off, self._sel = 0, []
+        for h in HEADS:
+            if h in self.heads:
+                self._sel += list(range(off, off + hc[h]))
+            off += hc[h]
+        self.full_channels = off
+        self.out_channels = len(self._sel)
+        self.is_variant = not (self.batchnorm and self.skipLayer and self.heads == HEADS)
+        if self.is_variant:
+            cfg = _lib.SCNetConfig()
+            cfg.struct_size = C.sizeof(_lib.SCNetConfig)
+            cfg.snumclass, cfg.use_tanh, cfg.batchnorm, cfg.skip_layer = self.snumclass, self.useTanh, self.batchnorm, self.skipLayer
+            cfg.output_mask = sum(1 << i for i, h in enumerate(HEADS) if h in self.heads)
+            self._h = _lib.lib().relpose_scnet_create_ex(C.byref(cfg))
+        else:
+            self._h = _lib.lib().relpose_scnet_create(self.snumclass, self.useTanh)
         if not self._h:
             raise RuntimeError("relpose_scnet_create failed")
         self._state = {}
@@ -85,7 +104,7 @@ class SCNet(torch.nn.Module):
         torch.nn.DataParallel wrapper, mainPanoCompletion2view.py:154-156) is stripped.  May be called again with a
         different state dict (cached launch plans are rebuilt)."""
         L = _lib.lib()
-        spec = state_dict_spec(self.snumclass)
+        spec = self._spec
         if any(k.startswith("module.") for k in state_dict):
             state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
         missing = [k for k in spec if k not in state_dict]
@@ -188,7 +207,13 @@ class SCNet(torch.nn.Module):
         ws = self._workspace(n, H, W, x.device, ws_key, tuple(s_ for s_ in (tail_stream,) if s_ is not None))
         if tail_stream is not None:
             x.record_stream(tail_stream)                   # (the input resize runs there)
-        if out is None:
+        user_out = None
+        if self.is_variant:
+            # constructor variants: the library writes its full channel layout (absent heads = 0) on the current stream only; the
+            # reference's output is the concatenation of the heads that exist (mymodel.py:378)
+            tail_stream, user_out = None, out
+            out = torch.empty(n, self.full_channels, H, W, dtype=torch.float32, device=x.device)
+        elif out is None:
             out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
             if tail_stream is not None:
                 out.record_stream(tail_stream)
@@ -205,6 +230,12 @@ class SCNet(torch.nn.Module):
         a.self_tag = int(self_tag)
         a.workspace_generation = self._ws_gen
         _lib.check(_lib.lib().relpose_scnet_forward_ex(self._h, C.byref(a)), "relpose_scnet_forward_ex")
+        if self.is_variant:
+            sel = out if self.out_channels == self.full_channels else out[:, self._sel]
+            if user_out is None:
+                return sel.contiguous()
+            user_out.copy_(sel)
+            return user_out
         return out
 
     def plan_macs(self, n, flags=0, self_cached=False):
@@ -220,7 +251,7 @@ class SCNet(torch.nn.Module):
         cnt = L.relpose_scnet_read_tap(self._h, name.encode(), None, None, None)
         if cnt < 0:
             raise KeyError(name)
-        H, Cc = BUFFER_SHAPES[name] if name != "OUT" else (224, self.out_channels)
+        H, Cc = BUFFER_SHAPES[name] if name != "OUT" else (224, self.full_channels)
         out = torch.empty(cnt, dtype=torch.float32, device=self._ws.device)
         L.relpose_scnet_read_tap(self._h, name.encode(), _lib.ptr(out), _lib.ptr(self._ws), _lib.stream_ptr())
         return out.view(-1, H, H, Cc)
@@ -230,7 +261,7 @@ class SCNet(torch.nn.Module):
         import torch
         n, _, H, W = x.shape
         ws = self._workspace(n, H, W, x.device)
-        out = torch.empty(n, self.out_channels, H, W, dtype=torch.float32, device=x.device)
+        out = torch.empty(n, self.full_channels, H, W, dtype=torch.float32, device=x.device)
         g, o, k = C.c_double(), C.c_double(), C.c_int64()
         rc = _lib.lib().relpose_scnet_profile(self._h, _lib.ptr(x.contiguous()), _lib.ptr(out), n, H, W, _lib.ptr(ws), ws.numel(),
                                               iters, C.byref(g), C.byref(o), C.byref(k), _lib.stream_ptr())

@@ -278,9 +278,13 @@ def RelativePoseEstimationViaCompletion(net, data_s, data_t, args):
     import torch
     from . import util
     dev = _lib.require_gpu()
-    if args.outputType != 'rgbdnsf':
-        raise NotImplementedError("only outputType='rgbdnsf' is built")
-    args.idx_f_start = 3 + 3 + 1 + args.snumclass                                   # rpmodule.py:583-593
+    # rpmodule.py:583-593: the feature block starts behind the heads that exist.  The loop itself reads channels 3:6 as the completed
+    # normal and 6 as the depth (:625-630) and needs idx_f_end (set only with 'f', :592), so the reference runs with rgb, n, d and f present,
+    # with or without the semantic head: 'rgbdnsf' (evaluation.py) or 'rgbdnf'
+    for head in ('rgb', 'n', 'd', 'f'):
+        if head not in args.outputType:
+            raise ValueError(f"outputType {args.outputType!r}: RelativePoseEstimationViaCompletion reads the {head!r} head (rpmodule.py:592,625-630)")
+    args.idx_f_start = 3 + 3 + 1 + (args.snumclass if 's' in args.outputType else 0)
     args.idx_f_end = args.idx_f_start + args.featureDim
     assert args.featureDim == 32
     h = data_s['depth'].shape[0]

@@ -304,3 +304,14 @@ def make_matching_primitive_case(seed, kind="second"):
     mk = lambda rgb, full, feat, v: {"rgb": rgb, "rgb_full": full, "feat": feat, "depth": d["depth"][0, v].astype(np.float64),
                                      "normal": np.ascontiguousarray(d["norm"][0, v].transpose(1, 2, 0)).astype(np.float64)}
     return ds, mk(rs, rs_full, feats, 0), mk(rt, rt_full, featt, 1), det_s, det_t
+
+
+def make_full_res_pair(seed):
+    """A synthetic full-resolution kinect pair (what util.parse_data's baseline branch takes on ScanNet, util.py:78-90):
+    depth [1,2,480,640] f32 with holes (zeros), rgb uint8 [1,2,3,480,640]."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, 480), np.linspace(-1, 1, 640), indexing="ij")
+    depth = np.stack([(2.0 + 0.6 * np.sin(3 * xx + k) * np.cos(2 * yy - k) + 0.05 * rs.rand(480, 640)) for k in range(2)])[None].astype(np.float32)
+    depth[rs.rand(*depth.shape) < 0.15] = 0
+    rgb = rs.randint(0, 256, (1, 2, 3, 480, 640)).astype(np.uint8)
+    return depth, rgb

@@ -207,10 +207,17 @@ def depth2pc(depth, dataList):
     dev = _lib.require_gpu()
     ds = dataset_id(dataList)
     hh, ww = depth.shape
+    if ds == 2 and (hh, ww) == (480, 640):                # the full-resolution kinect image (util.py:497-507: the baselines' clouds)
+        dd = torch.from_numpy(np.ascontiguousarray(depth, dtype=np.float32)[None]).to(dev)
+        pc = torch.empty(1, hh * ww, 3, dtype=torch.float64, device=dev)
+        valid = torch.empty(1, hh * ww, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().relpose_depth2pc_full(_lib.ptr(dd), _lib.ptr(pc), _lib.ptr(valid), 1, hh, ww, _lib.stream_ptr()), "relpose_depth2pc_full")
+        m = valid[0].cpu().numpy().astype(bool)
+        return pc[0].cpu().numpy()[m], m
     h = 160 if ds == 2 else hh
     pano = np.zeros((1, h, 4 * h), np.float32)
     if ds == 2:
-        assert (hh, ww) == (66, 88), "only the kinect crop of the hot path is supported"
+        assert (hh, ww) == (66, 88), "scannet: the 66x88 crop or the 480x640 image (the reference defines no other shape, util.py:498,508)"
         pano[0, 47:113, 196:284] = depth
     else:
         pano[0, :, h:2 * h] = depth
@@ -220,29 +227,33 @@ def depth2pc(depth, dataList):
 
 
 def parse_data(depth, rgb, norm, dataList, method):
-    """util.py:42-92, same signature and 8-tuple: the observed block of both scans as point clouds (+ colours, normals).
-    depth [1,2,160,640], rgb uint8 [1,2,3,160,640], norm [1,2,3,160,640] numpy.  Built for the configurations the hot path
-    evaluates: suncg / matterport (face [160,320)) and scannet with method 'ours' (the 66x88 kinect crop)."""
+    """util.py:42-92, same signature and 8-tuple: both scans as point clouds (+ colours, normals).  suncg / matterport: the observed face
+    [160,320) of depth [1,2,160,640], rgb uint8 [1,2,3,160,640], norm [1,2,3,160,640].  scannet with an 'ours' method: the 66x88 kinect crop
+    of the same panoramas, normals renormalised (:56-76); scannet with a baseline method (:78-90): depth [1,2,480,640], rgb [1,2,3,480,640] are
+    the full-resolution kinect IMAGES, back-projected whole, and there are no normals (None, None)."""
+    full = False
     if 'suncg' in dataList or 'matterport' in dataList:
         ys, xs = slice(None), slice(160, 320)
     elif 'scannet' in dataList:
-        if 'ours' not in method:
-            raise NotImplementedError("parse_data: the full-resolution scannet branch (baselines) is outside the hot path")
-        ys, xs = slice(80 - 33, 80 + 33), slice(160 + 80 - 44, 160 + 80 + 44)
+        if 'ours' in method:
+            ys, xs = slice(80 - 33, 80 + 33), slice(160 + 80 - 44, 160 + 80 + 44)
+        else:
+            ys, xs, full = slice(None), slice(None), True
     else:
         raise ValueError(f"unknown dataset {dataList}")
     out = {}
     for v, tag in ((0, "src"), (1, "tgt")):
         d = depth[0, v, ys, xs]
         col = rgb[0, v, :, ys, xs].transpose(1, 2, 0)
-        nrm = norm[0, v, :, ys, xs].copy().transpose(1, 2, 0)
         pc, mask = depth2pc(d, dataList)
         col = col.reshape(-1, 3)[mask] / 255.
-        nrm = nrm.reshape(-1, 3)[mask]
-        if 'scannet' in dataList:
-            with np.errstate(divide="ignore", invalid="ignore"):
-                nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
-            nrm[np.isnan(nrm.sum(1))] = 0
+        nrm = None
+        if not full:
+            nrm = norm[0, v, :, ys, xs].copy().transpose(1, 2, 0).reshape(-1, 3)[mask]
+            if 'scannet' in dataList:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+                nrm[np.isnan(nrm.sum(1))] = 0
         out[tag] = (d, nrm, col, pc)
     s, t = out["src"], out["tgt"]
     return s[0], t[0], s[1], t[1], s[2], t[2], s[3], t[3]

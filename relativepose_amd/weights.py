@@ -17,10 +17,34 @@ import numpy as np
 NGF = 64
 
 
-def layer_table(snumclass=15):
+HEADS = ("rgb", "n", "d", "s", "f")          # the reference's concatenation order (mymodel.py:309-376)
+
+
+def parse_output_type(output_type):
+    """args.outputType -> tuple of head names in the reference's order.  The reference tests substrings ('rgb' in outputType, 'n' in
+    outputType, ...: mymodel.py:189-243), so 'rgbdnsf', 'dnf', 'sf' are all valid spellings; 'k' names a head whose forward reads an
+    undefined variable (mymodel.py:328) and is rejected."""
+    if "k" in output_type:
+        raise ValueError("outputType 'k': the reference's keypoint head reads an undefined xsift (mymodel.py:328); it cannot run there either")
+    heads = tuple(h for h in HEADS if h in output_type)
+    if not heads:
+        raise ValueError(f"outputType {output_type!r} selects no head")
+    return heads
+
+
+def head_channels(snumclass=15):
+    return {"rgb": 3, "n": 3, "d": 1, "s": snumclass, "f": 32}
+
+
+def layer_table(snumclass=15, skip_layer=1, output_type="rgbdnsf"):
     """[(name, kind, cin, cout, k, stride, pad)] in forward order; kind in
     {'conv','deconv','head'}."""
     g = NGF
+    sm = 2 if skip_layer else 1
+    heads = parse_output_type(output_type)
+    if not skip_layer and any(h in heads for h in ("rgb", "n", "d")):
+        raise ValueError("skipLayer=0 with an rgb / n / d head: the reference's 1x1 output convs take 64 channels, 32 of them the skip "
+                         "(mymodel.py:192 vs :347) -- that combination fails inside torch")
     t = []
     for m, cin in (("rgb", 4), ("n", 4), ("d", 2)):
         t += [(f"conv1{m}", "conv", cin, g // 2, 3, 1, 1),
@@ -33,47 +57,49 @@ def layer_table(snumclass=15):
           ("conv8", "conv", g * 8, g * 8, 3, 1, 1),
           ("conv9", "conv", g * 8, g * 16, 3, 1, 0),
           ("deconv9", "deconv", g * 16, g * 8, 3, 1, 0),
-          ("deconv8", "deconv", g * 16, g * 8, 3, 1, 1),
-          ("deconv7", "deconv", g * 16, g * 8, 3, 2, 0),
-          ("deconv6", "deconv", g * 16, g * 8, 4, 2, 1),
-          ("deconv5", "deconv", g * 16, g * 4, 4, 2, 1),
-          ("deconv4", "deconv", g * 8, g * 2, 4, 2, 1)]
+          ("deconv8", "deconv", g * 8 * sm, g * 8, 3, 1, 1),
+          ("deconv7", "deconv", g * 8 * sm, g * 8, 3, 2, 0),
+          ("deconv6", "deconv", g * 8 * sm, g * 8, 4, 2, 1),
+          ("deconv5", "deconv", g * 8 * sm, g * 4, 4, 2, 1),
+          ("deconv4", "deconv", g * 4 * sm, g * 2, 4, 2, 1)]
     for m, cout in (("rgb", 3), ("n", 3), ("d", 1)):
-        t += [(f"deconv3{m}", "deconv", g * 4, g, 4, 2, 1),
-              (f"deconv2{m}", "deconv", g * 2, g // 2, 4, 2, 1),
-              (f"deconv1{m}", "head", g, cout, 1, 1, 0)]
+        if m in heads:
+            t += [(f"deconv3{m}", "deconv", g * 4, g, 4, 2, 1),
+                  (f"deconv2{m}", "deconv", g * 2, g // 2, 4, 2, 1),
+                  (f"deconv1{m}", "head", g, cout, 1, 1, 0)]
     for m, cout in (("s", snumclass), ("f", 32)):
-        t += [(f"deconv3{m}", "deconv", g * 2, g, 4, 2, 1),
-              (f"deconv2{m}", "deconv", g, g, 4, 2, 1),
-              (f"deconv1{m}", "head", g, cout, 1, 1, 0)]
+        if m in heads:
+            t += [(f"deconv3{m}", "deconv", g * 2, g, 4, 2, 1),
+                  (f"deconv2{m}", "deconv", g, g, 4, 2, 1),
+                  (f"deconv1{m}", "head", g, cout, 1, 1, 0)]
     return t
 
 
-def state_dict_spec(snumclass=15):
-    """OrderedDict key -> shape, in the reference's registration order."""
+def state_dict_spec(snumclass=15, batchnorm=1, skip_layer=1, output_type="rgbdnsf"):
+    """OrderedDict key -> shape, in the reference's registration order.  batchnorm=0 (mymodel.py:22-25, 35-38): the blocks are
+    Sequential(conv(bias=True), LeakyReLU) -- '<block>.0.bias' instead of the BatchNorm affine '<block>.1.weight|bias'."""
     spec = OrderedDict()
-    for name, kind, cin, cout, k, s, p in layer_table(snumclass):
-        if kind == "conv":
-            spec[f"{name}.0.weight"] = (cout, cin, k, k)
-            spec[f"{name}.1.weight"] = (cout,)
-            spec[f"{name}.1.bias"] = (cout,)
-        elif kind == "deconv":
-            spec[f"{name}.0.weight"] = (cin, cout, k, k)
+    for name, kind, cin, cout, k, s, p in layer_table(snumclass, skip_layer, output_type):
+        if kind == "head":
+            spec[f"{name}.weight"] = (cout, cin, 1, 1)
+            spec[f"{name}.bias"] = (cout,)
+            continue
+        spec[f"{name}.0.weight"] = (cout, cin, k, k) if kind == "conv" else (cin, cout, k, k)
+        if batchnorm:
             spec[f"{name}.1.weight"] = (cout,)
             spec[f"{name}.1.bias"] = (cout,)
         else:
-            spec[f"{name}.weight"] = (cout, cin, 1, 1)
-            spec[f"{name}.bias"] = (cout,)
+            spec[f"{name}.0.bias"] = (cout,)
     return spec
 
 
-def make_state_dict(seed=0, snumclass=15):
+def make_state_dict(seed=0, snumclass=15, batchnorm=1, skip_layer=1, output_type="rgbdnsf"):
     """Xavier-normal conv weights, BN gamma ~ N(1,.02), beta = small noise,
     head bias ~ N(0,.05) -- the reference's init (mymodel.py:6-13) with non-zero
     betas/biases so that every parameter is exercised by parity tests."""
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
-    for key, shape in state_dict_spec(snumclass).items():
+    for key, shape in state_dict_spec(snumclass, batchnorm, skip_layer, output_type).items():
         if len(shape) == 4:
             rf = shape[2] * shape[3]
             fan_in, fan_out = shape[1] * rf, shape[0] * rf

@@ -16,6 +16,15 @@ WARP_ANGLES = (0.3, 1.5, 3.141592653589793)
 
 SCNET_CASES = (("a", 15, 1, 3, "suncg", "second"), ("b", 21, 0, 4, "scannet", "kinect"))
 
+# constructor variants of the reference SCNet (mymodel.py:145-149, 189-243): (tag, snumclass, useTanh, weight seed, dataset, mask,
+# batchnorm, skipLayer, outputType) -- every combination the reference itself can run is represented: no BatchNorm, no skip connections
+# (s / f heads only: the rgb / n / d heads fail inside torch without them), head subsets with and without the skip heads
+SCNET_VARIANT_CASES = (("bn0", 15, 1, 31, "suncg", "second", 0, 1, "rgbdnsf"),
+                       ("noskip_sf", 15, 1, 32, "suncg", "second", 1, 0, "sf"),
+                       ("dnf", 15, 0, 33, "matterport", "second", 1, 1, "dnf"),
+                       ("bn0_noskip_f", 15, 1, 34, "suncg", "second", 0, 0, "f"),
+                       ("rgbdnf", 21, 1, 35, "scannet", "kinect", 1, 1, "rgbdnf"))
+
 E2E_CASES = [("suncg", "second", 15, 1, 1000 + i) for i in range(4)] + \
     [("matterport", "second", 21, 1, 3000), ("scannet", "kinect", 21, 0, 4000)]
 E2E_N = 80

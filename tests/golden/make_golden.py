@@ -42,7 +42,7 @@ def sample_idx(n, k, seed):
     return np.random.RandomState(seed).randint(0, n, size=k)
 
 
-from cases import (MATCH_CASES, MATCH_METHODS, GEOM_CASES, WARP_ANGLES, SCNET_CASES, E2E_CASES, E2E_N, E2E_WEIGHT_SEED,  # noqa: E402
+from cases import (MATCH_CASES, MATCH_METHODS, GEOM_CASES, WARP_ANGLES, SCNET_CASES, SCNET_VARIANT_CASES, E2E_CASES, E2E_N, E2E_WEIGHT_SEED,  # noqa: E402
                    ENV_AMP, ENV_SEEDS, WC_CASES, WC_KW, WC_S, WC_SIGMAS, WC_WEIGHT_SEED, WC2_CASES, TUNE_CASE)
 
 
@@ -378,6 +378,55 @@ def gen_scnet():
     np.savez_compressed(os.path.join(HERE, "scnet.npz"), **out)
 
 
+def gen_scnet_variants():
+    """The reference SCNet built with the other constructor switches (mymodel.py:145-149), fed the seeded state dict of the same spec:
+    output samples + per-layer statistics, like gen_scnet.  Also records that the two combinations the product rejects fail in the
+    reference too ('k' head; skipLayer=0 with an rgb / n / d head)."""
+    import torch
+    R = ref_loader.load()
+    out = {}
+    for tag, S, tanh, seed, ds, mm, bn, skip, otype in SCNET_VARIANT_CASES:
+        a = _Args(S, tanh)
+        a.batchnorm, a.skipLayer, a.outputType = bn, skip, otype
+        net = R["mymodel"].SCNet(a)
+        sd = weights.make_state_dict(seed, S, bn, skip, otype)
+        assert list(sd) == list(net.state_dict()), "seeded spec != the reference's registration order"
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        x, _ = scnet_input(500 + seed, ds, mm)
+        taps, hooks = {}, []
+        for name, mod in net.named_modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: taps.setdefault(name, []).append(o.detach())))
+        with torch.no_grad():
+            y = net(x)
+        for h in hooks:
+            h.remove()
+        print(f"scnet variant {tag}: out {tuple(y.shape)} absmax {float(y.abs().max()):.3g}")
+        out[f"{tag}_out_crop"] = y[:, :, 40:72, 300:332].numpy()
+        out[f"{tag}_out_chmean"] = y.mean((2, 3)).numpy()
+        out[f"{tag}_out_chabsmax"] = y.abs().amax((2, 3)).numpy()
+        idx = sample_idx(y.numel(), 20000, 9)
+        out[f"{tag}_out_idx"], out[f"{tag}_out_val"] = idx, y.reshape(-1)[idx].numpy()
+        for name, lst in taps.items():
+            for ci, o in enumerate(lst):
+                out[f"{tag}_tap_{name}_{ci}_mean"] = o.mean((0, 2, 3)).numpy()
+                out[f"{tag}_tap_{name}_{ci}_std"] = o.std((0, 2, 3)).numpy()
+    # what the reference cannot run (the product raises ValueError for these instead of building them)
+    fails = []
+    for bn, skip, otype in ((1, 0, "rgbdnsf"), (1, 1, "rgbdnksf")):
+        a = _Args(15, 1)
+        a.batchnorm, a.skipLayer, a.outputType = bn, skip, otype
+        try:
+            with torch.no_grad():
+                R["mymodel"].SCNet(a)(scnet_input(531)[0])
+            fails.append("ran")
+        except Exception as e:
+            fails.append(type(e).__name__)
+    print("reference on the rejected combinations:", fails)
+    out["rejected_fail_types"] = np.array(fails)
+    np.savez_compressed(os.path.join(HERE, "scnet_variants.npz"), **out)
+
+
 def ref_loop(net, d, pts, ptw, ds, mm, S, sigmas, noise_amp=0.0, noise_seed=0, keep_prims=None, R_forced=None):
     """evaluation.py:217-284 for ONE scan pair driven through the reference's own functions (util.apply_mask,
     util.warping, the reference SCNet, rpmodule.getMatchingPrimitive with getKeypoint replaced by the injected
@@ -684,6 +733,22 @@ def gen_stats():
     np.savez_compressed(os.path.join(HERE, "stats.npz"), **out)
 
 
+def gen_stats_full():
+    """util.parse_data's full-resolution ScanNet branch (util.py:78-90: the baseline methods) and util.depth2pc :497-507 of the reference."""
+    R = ref_loader.load()
+    util = R["util"]
+    depth, rgb = synth.make_full_res_pair(77)
+    res = util.parse_data(depth, rgb, None, "scannet", "gs")
+    out = {"seed": np.array(77)}
+    assert res[2] is None and res[3] is None
+    for tag, pc, col in (("src", res[6], res[4]), ("tgt", res[7], res[5])):
+        out[f"{tag}_n"] = np.array(len(pc))
+        out[f"{tag}_pc_sha"] = np.array(hashlib.sha256(np.ascontiguousarray(pc, dtype=np.float64).tobytes()).hexdigest())
+        out[f"{tag}_pc_head"] = pc[:256]
+        out[f"{tag}_col_sha"] = np.array(hashlib.sha256(np.ascontiguousarray(col, dtype=np.float64).tobytes()).hexdigest())
+    np.savez_compressed(os.path.join(HERE, "stats_full.npz"), **out)
+
+
 def gen_metrics():
     """util.angular_distance_np of the reference (util.py:176-187) on random rotation pairs."""
     R = ref_loader.load()
@@ -698,7 +763,7 @@ def gen_metrics():
 
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not present"
-    groups = sys.argv[1:] or ["matcher", "matcher_stages", "matcher_stages_big512", "tune", "matcher_big", "geometry", "scnet", "e2e", "e2e_env", "e2e_env_tf", "e2e_wc", "e2e_wc2", "stats", "keypoints", "getkeypoint", "gmp_nc", "metrics"]
+    groups = sys.argv[1:] or ["matcher", "matcher_stages", "matcher_stages_big512", "tune", "matcher_big", "geometry", "scnet", "scnet_variants", "e2e", "e2e_env", "e2e_env_tf", "e2e_wc", "e2e_wc2", "stats", "stats_full", "keypoints", "getkeypoint", "gmp_nc", "metrics"]
     for g in groups:
         t = time.time()
         globals()["gen_" + g]()

@@ -12,7 +12,7 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 
-from cases import SCNET_CASES
+from cases import SCNET_CASES, SCNET_VARIANT_CASES
 from gpu_util import log
 from oracle.scnet_oracle import SCNetOracle
 from relativepose_amd import weights
@@ -98,6 +98,88 @@ def test_scnet_layers_and_output_vs_oracle(case, prec, golden_dir):
     log("scnet_output", case=tag_log, worst_layer_rel_err=worst, out224_abs_err=e224, out_abs_err=eout, out_abs_err_vs_reference=eref,
         out_absmax=float(np.abs(yo).max()))
     assert eout < 5e-4 and eref < 5e-4
+
+
+def make_variant_net(S, tanh, seed, bn, skip, otype, prec="f32"):
+    from relativepose_amd.model import SCNet
+    sd = weights.make_state_dict(seed, S, bn, skip, otype)
+    net = SCNet(SimpleNamespace(batchnorm=bn, useTanh=tanh, skipLayer=skip, outputType=otype, snumclass=S))
+    net.load_state_dict(sd)
+    net.set_precision(prec)
+    return net, sd
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x6"])
+@pytest.mark.parametrize("case", SCNET_VARIANT_CASES, ids=[c[0] for c in SCNET_VARIANT_CASES])
+def test_scnet_constructor_variants_vs_oracle_and_reference(case, prec, golden_dir):
+    """The reference constructor's other switches (mymodel.py:145-149, 189-243; relpose_scnet_create_ex): batchnorm=0 (conv bias through the
+    loader's {scale, shift} table), skipLayer=0 (single-source decoder), head subsets.  Output against the fp32 oracle of the same variant and
+    against samples of the REFERENCE module's output (tests/golden/scnet_variants.npz), relative to the output's scale; the pre-activation
+    bottleneck and trunk layers against the oracle's like the default configuration."""
+    import torch
+    tag, S, tanh, seed, ds, mm, bn, skip, otype = case
+    net, sd = make_variant_net(S, tanh, seed, bn, skip, otype, prec)
+    x = oracle_scnet_input(500 + seed, ds, mm)
+    y = net(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    orc = TapOracle(sd, S, tanh, bn, skip, otype)
+    with torch.no_grad():
+        yo = orc.forward(torch.from_numpy(x)).numpy()
+    yg = y.cpu().numpy()
+    assert yg.shape == yo.shape
+    worst = 0.0
+    for bname, blocks in TAP_MAP.items():
+        t = net.read_tap(bname).cpu().numpy()
+        for (oname, ci, off, ch) in blocks:
+            if oname not in orc.calls:
+                assert not np.any(t[..., off:off + ch]), (bname, oname)      # a head that does not exist: its block is zero, not garbage
+                continue
+            o = orc.calls[oname][ci].numpy().transpose(0, 2, 3, 1)
+            # (batchnorm=0: the reference's conv output includes the bias; the library adds it in the consumer's loader)
+            if not bn:
+                o = o - sd[f"{oname}.0.bias"][None, None, None, :]
+            scale = np.abs(o).max() + 1e-30
+            err = np.abs(t[..., off:off + ch] - o).max() / scale
+            log("scnet_variant_layer", case=f"{tag}/{prec}", buffer=bname, layer=oname, call=ci, rel_err=err, scale=scale)
+            worst = max(worst, err)
+            assert err < 5e-4, (bname, oname, ci, err)
+    gv = np.load(os.path.join(golden_dir, "scnet_variants.npz"))
+    ref = gv[f"{tag}_out_val"]
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    eout = np.abs(yg - yo).max() / scale
+    eref = np.abs(yg.reshape(-1)[gv[f"{tag}_out_idx"]] - ref).max() / scale
+    log("scnet_variant_output", case=f"{tag}/{prec}", worst_layer_rel_err=worst, out_rel_err=eout, out_rel_err_vs_reference=eref, out_absmax=scale)
+    assert eout < 5e-4 and eref < 5e-4
+    # the flags of the evaluation.py plans are accepted and ignored by a variant: bitwise the plain forward
+    y2 = net(torch.from_numpy(x).cuda(), zero_warp=True, outputs="pose", self_tag=77)
+    y3 = net(torch.from_numpy(x).cuda(), self_tag=77)
+    assert torch.equal(y, y2) and torch.equal(y, y3)
+    # batches: BatchNorm groups of 2 images, as in the default configuration
+    xb = np.concatenate((x, x[::-1].copy(), x))
+    yb = net(torch.from_numpy(xb).cuda()).cpu().numpy()
+    assert np.abs(yb[:2] - yg).max() <= 1e-5 * scale and np.abs(yb[4:] - yg).max() <= 1e-5 * scale
+
+
+def test_scnet_variants_the_reference_cannot_run_are_refused():
+    from relativepose_amd import _lib
+    from relativepose_amd.model import SCNet
+    import ctypes as C
+    with pytest.raises(ValueError):
+        SCNet(SimpleNamespace(batchnorm=1, useTanh=1, skipLayer=0, outputType="rgbdnsf", snumclass=15))
+    with pytest.raises(ValueError):
+        SCNet(SimpleNamespace(batchnorm=1, useTanh=1, skipLayer=1, outputType="rgbdnksf", snumclass=15))
+    cfg = _lib.SCNetConfig()
+    cfg.struct_size = C.sizeof(_lib.SCNetConfig)
+    cfg.snumclass, cfg.use_tanh, cfg.batchnorm, cfg.skip_layer, cfg.output_mask = 15, 1, 1, 0, 31
+    assert not _lib.lib().relpose_scnet_create_ex(C.byref(cfg))
+    cfg.output_mask = 0
+    assert not _lib.lib().relpose_scnet_create_ex(C.byref(cfg))
+    cfg.output_mask, cfg.struct_size = 24, 8
+    assert not _lib.lib().relpose_scnet_create_ex(C.byref(cfg))
+    # a variant net refuses a state dict of another variant (missing keys), loudly
+    net = SCNet(SimpleNamespace(batchnorm=0, useTanh=1, skipLayer=1, outputType="rgbdnsf", snumclass=15))
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(weights.make_state_dict(1, 15))
 
 
 F16_LAYER_BOUND = 2e-2        # plain fp16 products: per-layer max error relative to the layer's scale (measured worst: see the log)

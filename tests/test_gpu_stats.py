@@ -68,3 +68,26 @@ def test_parse_data_and_evaluate_pairs_records(golden_dir, tmp_path, ds, mm, see
     want = gst[f"stats_{ds}_overlap"]
     assert np.allclose([rec["overlap"], rec["cam_dist"], rec["pc_dist"], rec["pc_nearest"]], want, rtol=1e-9, atol=1e-12)
     assert np.allclose(rec["R_gt"], gst[f"stats_{ds}_Rgt"]) and rec["R_pred_44"].shape == (4, 4) and rec["err_ad"] >= 0
+
+
+def test_parse_data_full_resolution_scannet_branch(golden_dir):
+    """util.parse_data :78-90 (scannet, a baseline method): the 480 x 640 kinect images back-projected whole through
+    relpose_depth2pc_full, no normals -- clouds and colours bit for bit the reference's (SHA-256 recorded at generation time)."""
+    import hashlib
+    from relativepose_amd import _lib, util
+    gf = np.load(os.path.join(golden_dir, "stats_full.npz"))
+    depth, rgb = synth.make_full_res_pair(int(gf["seed"]))
+    res = util.parse_data(depth, rgb, None, "scannet", "gs")
+    assert res[2] is None and res[3] is None
+    assert np.array_equal(res[0], depth[0, 0]) and np.array_equal(res[1], depth[0, 1])
+    for tag, pc, col in (("src", res[6], res[4]), ("tgt", res[7], res[5])):
+        assert len(pc) == int(gf[f"{tag}_n"])
+        assert np.array_equal(pc[:256], gf[f"{tag}_pc_head"])
+        assert hashlib.sha256(np.ascontiguousarray(pc, dtype=np.float64).tobytes()).hexdigest() == str(gf[f"{tag}_pc_sha"])
+        assert hashlib.sha256(np.ascontiguousarray(col, dtype=np.float64).tobytes()).hexdigest() == str(gf[f"{tag}_col_sha"])
+    # the reference defines the branch for this one shape only
+    import torch
+    d = torch.zeros(1, 240, 320, device="cuda")
+    pc = torch.empty(1, 240 * 320, 3, dtype=torch.float64, device="cuda")
+    va = torch.empty(1, 240 * 320, dtype=torch.uint8, device="cuda")
+    assert _lib.lib().relpose_depth2pc_full(_lib.ptr(d), _lib.ptr(pc), _lib.ptr(va), 1, 240, 320, None) != 0

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from cases import (E2E_CASES, E2E_N, E2E_WEIGHT_SEED, GEOM_CASES, MATCH_CASES, MATCH_METHODS, SCNET_CASES)
+from cases import (E2E_CASES, E2E_N, E2E_WEIGHT_SEED, GEOM_CASES, MATCH_CASES, MATCH_METHODS, SCNET_CASES, SCNET_VARIANT_CASES)
 from oracle import geom_oracle as G
 from oracle import pipeline_oracle as P
 from oracle import rp_oracle as M
@@ -156,6 +156,17 @@ def oracle_scnet_input(seed, ds, mm):
     return np.concatenate((np.concatenate((views[0], t2s), 1), np.concatenate((views[1], s2t), 1)))
 
 
+def test_depth2pc_full_resolution_kinect_matches_reference(golden_dir):
+    """util.depth2pc :497-507 (the 480 x 640 image the baselines' parse_data branch back-projects): the oracle bit for bit."""
+    import hashlib
+    gf = np.load(os.path.join(golden_dir, "stats_full.npz"))
+    depth, _ = synth.make_full_res_pair(int(gf["seed"]))
+    for v, tag in ((0, "src"), (1, "tgt")):
+        pc, mask = G.depth2pc(depth[0, v], "scannet")
+        assert pc.shape[0] == int(gf[f"{tag}_n"]) == int(mask.sum())
+        assert hashlib.sha256(np.ascontiguousarray(pc, dtype=np.float64).tobytes()).hexdigest() == str(gf[f"{tag}_pc_sha"])
+
+
 @pytest.mark.parametrize("case", SCNET_CASES)
 def test_scnet_matches_reference(gs, case):
     tag, S, tanh, seed, ds, mm = case
@@ -167,6 +178,37 @@ def test_scnet_matches_reference(gs, case):
     # same torch build, same ops -> expect (near) bit equality
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
     assert np.allclose(y[:, :, 40:72, 300:332], gs[f"{tag}_out_crop"], atol=1e-5)
+
+
+@pytest.mark.parametrize("case", SCNET_VARIANT_CASES, ids=[c[0] for c in SCNET_VARIANT_CASES])
+def test_scnet_constructor_variants_match_reference(golden_dir, case):
+    """The oracle's restatement of the other constructor switches (batchnorm=0, skipLayer=0, head subsets: mymodel.py:145-149,
+    189-243) against outputs of the reference module built with the same switches and fed the same seeded state dict."""
+    tag, S, tanh, seed, ds, mm, bn, skip, otype = case
+    gv = np.load(os.path.join(golden_dir, "scnet_variants.npz"))
+    net = SCNetOracle(weights.make_state_dict(seed, S, bn, skip, otype), S, tanh, bn, skip, otype)
+    y = net.forward_pairs(oracle_scnet_input(500 + seed, ds, mm)).numpy()
+    assert y.shape[1] == gv[f"{tag}_out_crop"].shape[1]
+    ref = gv[f"{tag}_out_val"]
+    got = y.reshape(-1)[gv[f"{tag}_out_idx"]]
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    assert np.allclose(y[:, :, 40:72, 300:332], gv[f"{tag}_out_crop"], atol=1e-5 * max(1.0, np.abs(ref).max()))
+
+
+def test_scnet_rejected_variants_fail_in_the_reference_too(golden_dir):
+    """skipLayer=0 with an rgb / n / d head and the 'k' head raise in the reference (recorded at generation time); the host mirror
+    refuses them up front (weights.layer_table / parse_output_type) instead of building something the reference cannot run."""
+    gv = np.load(os.path.join(golden_dir, "scnet_variants.npz"))
+    assert list(gv["rejected_fail_types"]) == ["RuntimeError", "NameError"]
+    with pytest.raises(ValueError):
+        weights.state_dict_spec(15, 1, 0, "rgbdnsf")
+    with pytest.raises(ValueError):
+        weights.state_dict_spec(15, 1, 1, "rgbdnksf")
+    # the default spec is untouched by the variant arguments
+    assert list(weights.state_dict_spec(15)) == list(weights.state_dict_spec(15, 1, 1, "rgbdnsf"))
+    assert "conv4.0.bias" in weights.state_dict_spec(15, 0) and "conv4.1.weight" not in weights.state_dict_spec(15, 0)
+    assert weights.state_dict_spec(15, 1, 0, "sf")["deconv8.0.weight"] == (512, 512, 3, 3)
+    assert weights.state_dict_spec(15, 1, 1, "sf")["deconv8.0.weight"] == (1024, 512, 3, 3)
 
 
 @pytest.fixture(scope="module")
