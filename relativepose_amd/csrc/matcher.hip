@@ -367,6 +367,9 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     const int32_t* segrow; double* part;
     double* part2;              // partial sums of the products done with helper workgroups (only ever written write-through)
     double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
+    double* partl;              // LDS: the partial sums of the pair's first meta_cap segments (one workgroup per pair; round 6) -- `part` beyond
+    double* Vl;                 // LDS copy of basis vectors 0 .. KL-1 (round 6: what is left of the CU's 160 KB behind the vectors and the segment
+    int KL;                     // table; a multiple of 4).  The re-orthogonalisation reads those from LDS, the rest from global: same sums, same order
     int C, Cmax, nseg, tri_rounds, max_prod;
     int fixed_checks;           // RELPOSE_TUNE_FIT_FIXED_CHECKS: convergence test every RP_LZ_CHECK steps (the round-2/3 rule; A/B switch)
     struct FitCtl* ctl;         // helper workgroups (G > 1): the pair's control block; xu = the published vectors [2][Cmax] (u, then h), part2 behind them
@@ -513,6 +516,7 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
             if (len > 3 * U) consume(1 % RP_SEG_DEPTH, 3 * U);
         }
         if (SC1) rp_st_sc1(f.part2 + sgm, acc);            // (helpers / a leader with helpers: write-through, read by the leader's row sums)
+        else if (sgm < f.meta_cap) f.partl[sgm] = acc;     // (LDS: no store -> L2 -> load round trip between the edge pass and the row sums)
         else *(RP_GLOBAL double*)(f.part + sgm) = acc;
     }
 }
@@ -545,7 +549,9 @@ __device__ __forceinline__ void seg_row_sums(const Fit1& f, double* out) {
     } else {
         for (int r = threadIdx.x; r < f.C; r += blockDim.x) {
             double acc = 0.0;
-            for (int sgm = f.sp[r]; sgm < f.sp[r + 1]; ++sgm) acc += *(RP_GLOBAL const double*)(f.part + sgm);
+            const int a = f.sp[r], b = f.sp[r + 1], bl = min(b, f.meta_cap);
+            for (int sgm = a; sgm < bl; ++sgm) acc += f.partl[sgm];                                    // (same order: LDS-resident segments come first)
+            for (int sgm = max(a, f.meta_cap); sgm < b; ++sgm) acc += *(RP_GLOBAL const double*)(f.part + sgm);
             out[r] = acc;
         }
     }
@@ -770,7 +776,8 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
     int nprod = 0;
     *converged = 1;
     while (true) {
-        for (int c = tid; c < C; c += blockDim.x) f.V[c] = f.vec[c];
+        if (f.KL > 0) { for (int c = tid; c < C; c += blockDim.x) f.Vl[c] = f.vec[c]; }
+        else for (int c = tid; c < C; c += blockDim.x) f.V[c] = f.vec[c];
         __syncthreads();
         int m = 0;
         double beta_last = 0.0, theta = 0.0;
@@ -792,6 +799,16 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
                 for (int i = wave; i <= j; i += nw) {
                     const double* vi = f.V + (size_t)i * f.Cmax;
                     double d = 0.0;
+                    if (i < f.KL) {                                        // (wave-uniform) an LDS-resident basis vector: the same sum in the same order
+                        const double* vl = f.Vl + (size_t)i * f.Cmax;
+                        for (int c0 = lane; c0 < C; c0 += 64 * 8) {       // 8 + 8 LDS reads in flight, then accumulated in order
+                            double v8[8], y8[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { const bool ok = c0 + 64 * q < C; v8[q] = ok ? vl[c0 + 64 * q] : 0.0; y8[q] = ok ? f.yy[c0 + 64 * q] : 0.0; }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) if (c0 + 64 * q < C) d += v8[q] * y8[q];
+                        }
+                    } else
                     for (int c0 = lane; c0 < C; c0 += 64 * VB) {          // VB loads in flight (one L2 round trip for C <= 1024 with VB = 16), then accumulated in order
                         double v8[VB];
 #pragma unroll
@@ -813,7 +830,18 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
                         const int c2 = c + blockDim.x;
                         const bool two = c2 < C;
                         double acc = f.yy[c], acc2 = two ? f.yy[c2] : 0.0;
-                        for (int i0 = 0; i0 <= j; i0 += 8) {
+                        const int jl = min(j + 1, f.KL);                  // vectors 0 .. jl-1 from LDS (4 at a time), the rest from global (8 in flight)
+                        for (int i0 = 0; i0 < jl; i0 += 4) {
+                            double v4[4], w4[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v4[q] = (i0 + q < jl) ? f.Vl[(size_t)(i0 + q) * f.Cmax + c] : 0.0;
+                                w4[q] = (two && i0 + q < jl) ? f.Vl[(size_t)(i0 + q) * f.Cmax + c2] : 0.0;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (i0 + q < jl) { acc -= f.cbuf[i0 + q] * v4[q]; acc2 -= f.cbuf[i0 + q] * w4[q]; }
+                        }
+                        for (int i0 = f.KL; i0 <= j; i0 += 8) {
                             double v8[8], w8[8];
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
@@ -830,7 +858,15 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
                 } else
                 for (int c = tid; c < C; c += blockDim.x) {
                     double acc = f.yy[c];
-                    for (int i0 = 0; i0 <= j; i0 += 8) {                   // 8 basis vectors' entries in flight
+                    const int jl = min(j + 1, f.KL);
+                    for (int i0 = 0; i0 < jl; i0 += 4) {
+                        double v4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v4[q] = (i0 + q < jl) ? f.Vl[(size_t)(i0 + q) * f.Cmax + c] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (i0 + q < jl) acc -= f.cbuf[i0 + q] * v4[q];
+                    }
+                    for (int i0 = f.KL; i0 <= j; i0 += 8) {                // 8 basis vectors' entries in flight
                         double v8[8];
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v8[q] = (i0 + q <= j) ? rp_ldg(f.V + (size_t)(i0 + q) * f.Cmax + c) : 0.0;
@@ -855,6 +891,10 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
             if (!invariant && j + 1 < RP_LZ_M) {
                 const double inv = 1.0 / beta;
                 double* vn = f.V + (size_t)(j + 1) * f.Cmax;
+                if (j + 1 < f.KL) {
+                    double* vln = f.Vl + (size_t)(j + 1) * f.Cmax;
+                    for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; vln[c] = v; f.vec[c] = v; }
+                } else
                 for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; rp_stg(vn + c, v); f.vec[c] = v; }
             }
             __syncthreads();
@@ -888,7 +928,8 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
         }
         if (!(theta > 0.0) && m == 1) {
             // A v0 = 0 (zero matrix / no active edges): keep the start vector, like the round-1 solver
-            for (int c = tid; c < C; c += blockDim.x) f.vec[c] = f.V[c];
+            if (f.KL > 0) { for (int c = tid; c < C; c += blockDim.x) f.vec[c] = f.Vl[c]; }
+            else for (int c = tid; c < C; c += blockDim.x) f.vec[c] = f.V[c];
             __syncthreads();
             return nprod;
         }
@@ -897,7 +938,15 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
         double nn[1] = {0.0};
         for (int c = tid; c < C; c += blockDim.x) {
             double acc = 0.0;
-            for (int i0 = 0; i0 < m; i0 += 8) {
+            const int ml = min(m, f.KL);
+            for (int i0 = 0; i0 < ml; i0 += 4) {
+                double v4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v4[q] = (i0 + q < ml) ? f.Vl[(size_t)(i0 + q) * f.Cmax + c] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (i0 + q < ml) acc += sv[i0 + q] * v4[q];
+            }
+            for (int i0 = f.KL; i0 < m; i0 += 8) {
                 double v8[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v8[q] = (i0 + q < m) ? rp_ldg(f.V + (size_t)(i0 + q) * f.Cmax + c) : 0.0;
@@ -1051,7 +1100,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
                                                                     double* __restrict__ pose, double* __restrict__ trace,
                                                                     int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out,
                                                                     long long* __restrict__ prof, int tri_rounds, FitCtl* __restrict__ ctl_all,
-                                                                    double* __restrict__ xu_all, int meta_cap) {
+                                                                    double* __restrict__ xu_all, int meta_cap, int basis_lds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[160];
     __shared__ double Rt[12];
@@ -1152,6 +1201,10 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
         f.rp = (int32_t*)(f.yy + g.Cmax); f.sp = f.rp + (g.Cmax + 1);
         f.meta = f.sp + (g.Cmax + 1); f.meta_cap = 0;          // (set once the table is filled, below)
     }
+    // the first basis_lds Lanczos vectors live in LDS behind the segment table (meta_cap is even: 8-byte aligned); 0 in the global layout
+    f.KL = GVEC ? 0 : basis_lds;
+    f.partl = GVEC ? nullptr : (double*)(f.meta + meta_cap);
+    f.Vl = GVEC ? nullptr : f.partl + meta_cap;
     f.red = red;
     const size_t eoff = (size_t)b * g.estride;
     f.col = g.col + eoff; f.wv = g.wv + eoff; f.xe = g.xe + eoff;
@@ -1248,11 +1301,24 @@ static size_t fit_lds_bytes(int32_t Cmax, bool in_lds) {
 // entries of the LDS segment table (row | length of a pair's first segments) behind that: enough for ~3 segments per row, within the CU's 160 KB
 static int fit_meta_cap(int32_t Cmax, int32_t seg_cap, bool in_lds) {
     if (!in_lds) return 0;
-    const long long room = (160 * 1024 - 2048 - (long long)fit_lds_bytes(Cmax, true)) / 4;
+    const long long room = (160 * 1024 - 2048 - (long long)fit_lds_bytes(Cmax, true)) / 12;     // 4 bytes of table + 8 of partial sum per segment
     long long want = 3ll * Cmax + 512;
     if (want > seg_cap) want = seg_cap;
     if (want > room) want = room;
+    want &= ~1ll;                                           // (even: the LDS basis vectors behind the table stay 8-byte aligned)
     return want < 0 ? 0 : (int)want;
+}
+// Lanczos basis vectors kept in LDS behind that (round 6): whatever the CU's 160 KB still hold, a multiple of 4, at most the whole basis.
+// N = 200 (Cmax = 1000): 12 of a cycle's <= 24 vectors; N = 400 (Cmax = 2000): 4.  RELPOSE_FIT_BASIS_LDS=0 (experiments build) = the round-5 layout.
+static int fit_basis_lds(int32_t Cmax, int meta_cap, bool in_lds) {
+    if (!in_lds) return 0;
+    static const int cap_env = RP_ENV("RELPOSE_FIT_BASIS_LDS") ? atoi(RP_ENV("RELPOSE_FIT_BASIS_LDS")) : RP_LZ_M;
+    const long long room = 160 * 1024 - 2048 - (long long)fit_lds_bytes(Cmax, true) - (long long)meta_cap * 12;
+    long long k = room / ((long long)Cmax * 8);
+    if (k > cap_env) k = cap_env;
+    if (k > RP_LZ_M) k = RP_LZ_M;
+    k &= ~3ll;
+    return k < 0 ? 0 : (int)k;
 }
 #define RP_MAX_CORRES RELPOSE_MAX_CORRESPONDENCES      // correspondences per pair (ns_max * topK): the fill kernel's row lists are uint16 in 8 * Cmax bytes of LDS
 
@@ -1424,7 +1490,8 @@ int relpose_match_pairs_ex(const RelposeMatchArgs* args) {
     {
         const bool in_lds = fit_in_lds(L.Cmax);
         const int meta_cap = fit_meta_cap(L.Cmax, L.seg_cap, in_lds);
-        const size_t lds = fit_lds_bytes(L.Cmax, in_lds) + (size_t)meta_cap * 4;
+        const int basis_lds = fit_basis_lds(L.Cmax, meta_cap, in_lds);
+        const size_t lds = fit_lds_bytes(L.Cmax, in_lds) + (size_t)meta_cap * 12 + (size_t)basis_lds * L.Cmax * 8;
         double* gvec = in_lds ? nullptr : (double*)(ws + L.gvec);
         static long long* prof = nullptr;
         if (RP_ENV("RELPOSE_FIT_PROF")) {
@@ -1457,7 +1524,7 @@ int relpose_match_pairs_ex(const RelposeMatchArgs* args) {
             RP_HIP(hipFuncSetAttribute((const void*)fit_pair_kernel<T_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
             hipLaunchKernelGGL((fit_pair_kernel<T_, G_>), dim3(G, kp->B), dim3(T_), lds, s, *kp, g, kc, p->topK, m, (double*)(ws + L.lz), gvec,  \
                                status, pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds, (FitCtl*)(ws + L.ctl),      \
-                               (double*)(ws + L.xu), meta_cap);                                                                         \
+                               (double*)(ws + L.xu), meta_cap, basis_lds);                                                              \
         }
         if (fit_threads == 512) { if (in_lds) RP_FIT_LAUNCH(512, false) else RP_FIT_LAUNCH(512, true) }
         else { if (in_lds) RP_FIT_LAUNCH(1024, false) else RP_FIT_LAUNCH(1024, true) }
