@@ -309,6 +309,13 @@ __global__ __launch_bounds__(256) void pair_fill_rows_kernel(RelposeKeypoints kp
         g.wv[eoff + pos] = w;
         nz += (w != 0.0) ? 1 : 0;
     }
+    // (r6) the unused slots of the row's last segment: column 0, weight 0 -- an edge pass then needs no per-slot predicate: a dead slot adds
+    // w * (...) = +-0 to a sum that is never -0 (seg_body)
+    for (int k = deg + lane; k < ((deg + RP_SEG - 1) / RP_SEG) * RP_SEG; k += 64) {
+        const size_t pos = seg_edge_index(seg0 + (k >> 5), k);
+        g.col[eoff + pos] = 0;
+        g.wv[eoff + pos] = 0.0;
+    }
     nz = rp_wave_sum_i(nz);
     if (lane == 0 && nz) atomicAdd(&g.counters[b * 4 + 2], nz);
 }
@@ -350,6 +357,8 @@ __device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, do
 #define RP_TRI_ROUNDS 4         // 64-way multisection rounds of the tridiagonal eigenvalue (6 bits each) before the Newton polish (>= 9: no polish)
 #endif
 #define RP_FIT1_MAXC 4500       // LDS: 3 vectors of C doubles + 2 x (C + 1) ints
+#define RP_FIT1_MAXC_HU 1024    // ... + the {h, u} pairs of the products (16 bytes per correspondence more): the 512-thread kernel's sizes.  (Measured at
+                                // Cmax = 2000 / 1024 threads: the pairs take the LDS of the basis vectors and buy nothing there: 5.63 -> 5.69 ms.)
 
 struct Fit1 {                   // LDS layout + per-pair pointers of the single-workgroup fit
     long long* prof;            // optional [16] cycle counters of block 0 (RELPOSE_FIT_PROF=1, experiments build)
@@ -364,9 +373,11 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     double* cbuf;               // [RP_LZ_M + 1] Gram-Schmidt coefficients
     double* tri;                // [4 * (RP_LZ_M + 1)] alpha, beta, s of the tridiagonal solve (the fourth block is spare)
     const int32_t* col; const double* wv; double* xe;      // this pair's edges (global, segment layout)
+    __amdgpu_buffer_rsrc_t rs_col, rs_wv, rs_xe;           // ... as buffer descriptors (seg_body's loads)
     const int32_t* segrow; double* part;
     double* part2;              // partial sums of the products done with helper workgroups (only ever written write-through)
     double* V;                  // [(RP_LZ_M + 1), Cmax] Lanczos basis (global scratch)
+    double* hu;                 // LDS [C][2]: {h_c, u_c} interleaved, the gather source of the leader's products (seg_body HU); null in the global layout
     double* partl;              // LDS: the partial sums of the pair's first meta_cap segments (one workgroup per pair; round 6) -- `part` beyond
     double* Vl;                 // LDS copy of basis vectors 0 .. KL-1 (round 6: what is left of the CU's 160 KB behind the vectors and the segment
     int KL;                     // table; a multiple of 4).  The re-orthogonalisation reads those from LDS, the rest from global: same sums, same order
@@ -429,11 +440,15 @@ __device__ __forceinline__ void rp_acquire_agent() { if (RP_FIT_FENCES) __builti
 // the 512-thread kernel, 4 in the 1024-thread one with its 128 VGPRs) << 4
 // SCALED (MODE 1 only): base = mu * xe, the 'spectral' method's rounds > 0 -- a compile-time choice: as a run-time one it cost every edge of
 // every method a multiplication and two selects
-template <int MODE, int RP_SEG_CFG, bool SC1, bool SCALED = false>
+// HU (MODE 1, one workgroup per pair, LDS layout; round 6): h and the Lanczos vector are gathered as ONE 16-byte entry {h_c, u_c} of Fit1::hu
+// (kept beside the two dense vectors by lanczos_top) -- one LDS instruction and one address per edge instead of two.
+template <int MODE, int RP_SEG_CFG, bool SC1, bool SCALED = false, bool HU = false>
 __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, bool store_x) {
     static_assert(!SCALED || MODE == 1, "SCALED is a MODE 1 variant");
+    static_assert(!HU || (MODE == 1 && !SC1), "HU is a MODE 1 variant of the leader's own passes");
     const double* base = SCALED ? f.xe : f.wv;
     constexpr int U = 8;                                  // edges per register batch; two batches in flight
+    constexpr bool PRED = SCALED;                         // per-slot predicate on the sums: only where the loaded weights are not zero-filled (xe)
     constexpr int RP_SEG_DEPTH = RP_SEG_CFG & 15, GQ = RP_SEG_CFG >> 4;
     static_assert((RP_SEG_DEPTH == 2 || RP_SEG_DEPTH == 4) && (GQ == 2 || GQ == 4 || GQ == 8), "seg_body configuration");
     {
@@ -450,30 +465,39 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
         const double hr = (MODE == 1) ? f.hh[r] : 0.0, ur = (MODE == 2) ? f.vec[r] : 0.0;
         double acc = 0.0;
         int cc[RP_SEG_DEPTH][U]; double w[RP_SEG_DEPTH][U];
-        // dead slots (beyond a shorter segment's length) load the segment's FIRST entry again (a clamped, valid address: no branch around the
-        // loads) and their LDS gathers are issued like everybody's; only the accumulation is predicated (see `consume`).  Gating whole
-        // batches with a ballot, or processing all 32 slots branch-free, measured 20-30 % slower.
+        // dead slots (beyond a shorter segment's length) of a loaded batch are loaded and gathered like everybody's (no branch around the loads;
+        // rounds 2-5 clamped their address to the segment's first entry and predicated the sums, round 6 zero-fills them when the rows are
+        // written).  Gating whole batches with a ballot, or processing all 32 slots branch-free, measured 20-30 % slower.
+        // (r6) buffer loads: the lane's byte offset of slot 0 in a VGPR, the slot's distance (a compile-time constant after unrolling) in the
+        // instruction's scalar / immediate offset -- no 64-bit address arithmetic per edge (it was half of an edge's vector instructions).  A dead
+        // slot's load returns whatever the slot holds (or 0 beyond the pair's region: the descriptor's range check); `consume` never uses it.
+        const int vc = (int)e0 * 4, vw = (int)e0 * 8;
+        const __amdgpu_buffer_rsrc_t rs_w = SCALED ? f.rs_xe : f.rs_wv;
         auto load = [&](int buf, int kb) {
 #pragma unroll
             for (int q = 0; q < U; ++q) {
-                const bool ok = kb + q < len;
-                const size_t e = e0 + (size_t)(ok ? kb + q : 0) * 64;      // clamped: stays inside this segment's slots
-                cc[buf][q] = *(RP_GLOBAL const int*)(f.col + e);
-                w[buf][q] = *(RP_GLOBAL const double*)(base + e);
+                cc[buf][q] = (int)__builtin_amdgcn_raw_buffer_load_b32(f.rs_col, vc, (kb + q) * 64 * 4, 0);
+                typedef unsigned rp_u32x2 __attribute__((__vector_size__(8)));
+                const rp_u32x2 wv2 = (rp_u32x2)__builtin_amdgcn_raw_buffer_load_b64(rs_w, vw, (kb + q) * 64 * 8, 0);
+                w[buf][q] = __builtin_bit_cast(double, wv2);
             }
         };
-        // The gathers of GQ edges are issued together, for dead slots too (their column is the segment's first one: a valid index),
-        // and only the ACCUMULATION is predicated (a select on the sum): with `if (live) { gather; multiply; add }` per edge every edge
-        // paid its own LDS round trip in a serial chain.  Same operations in the same order on the live slots: bitwise the same sums.
+        // The gathers of GQ edges are issued together, for dead slots too (column 0: a valid index); with `if (live) { gather; multiply; add }`
+        // per edge every edge paid its own LDS round trip in a serial chain.  Same operations in the same order on the live slots, +-0 added for
+        // a dead one (PRED, the 'spectral' rounds: a select on the sum instead): bitwise the same sums.
         auto consume = [&](int buf, int kb) {
 #pragma unroll
             for (int q0 = 0; q0 < U; q0 += GQ) {
                 double hv[GQ], uv[GQ];
 #pragma unroll
                 for (int q = 0; q < GQ; ++q) {
-                    const int c = cc[buf][q0 + q];
-                    hv[q] = (MODE == 1) ? f.hh[c] : 0.0;
-                    uv[q] = (MODE != 0) ? f.vec[c] : 0.0;
+                    // (a dead slot of a loaded batch holds column 0, weight 0 -- pair_fill_rows_kernel; the 'spectral' rounds' xe is not zero-filled: PRED)
+                    const int c = (!PRED || kb + q0 + q < len) ? cc[buf][q0 + q] : 0;
+                    if (HU) { const double2 p = *reinterpret_cast<const double2*>(f.hu + 2 * c); hv[q] = p.x; uv[q] = p.y; }
+                    else {
+                        hv[q] = (MODE == 1) ? f.hh[c] : 0.0;
+                        uv[q] = (MODE != 0) ? f.vec[c] : 0.0;
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < GQ; ++q) {
@@ -491,7 +515,7 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
                         val = x;
                     }
                     const double sum = acc + val;
-                    acc = live ? sum : acc;
+                    acc = (!PRED || live) ? sum : acc;                   // (!PRED: val is +-0 on a dead slot and acc is never -0: the same bits)
                 }
             }
         };
@@ -557,11 +581,11 @@ __device__ __forceinline__ void seg_row_sums(const Fit1& f, double* out) {
     }
     __syncthreads();
 }
-template <int MODE, int RP_SEG_DEPTH>
+template <int MODE, int RP_SEG_DEPTH, bool HU = false>
 __device__ __forceinline__ void seg_pass(const Fit1& f, double* out, double mu_xe, bool store_x) {
     const long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
-    if (MODE == 1 && mu_xe != 0.0) { for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<1, RP_SEG_DEPTH, false, true>(f, sgm, mu_xe, store_x); }
-    else for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<MODE, RP_SEG_DEPTH, false>(f, sgm, mu_xe, store_x);
+    if (MODE == 1 && mu_xe != 0.0) { for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<1, RP_SEG_DEPTH, false, true, HU>(f, sgm, mu_xe, store_x); }
+    else for (int sgm = threadIdx.x; sgm < f.nseg; sgm += blockDim.x) seg_body<MODE, RP_SEG_DEPTH, false, false, HU>(f, sgm, mu_xe, store_x);
     const long long t1_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
     __syncthreads();
     const long long t2_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -770,7 +794,7 @@ __device__ double tridiag_top(const double* alpha, const double* beta, int m, do
 __device__ __attribute__((noinline)) double lz_rate(double r_a, int m_a, double r_b, int m_b, double prev) { return rp_lz_rate(r_a, m_a, r_b, m_b, prev); }
 __device__ __attribute__((noinline)) int lz_steps_to_check(double r, double lrate, int max_steps) { return rp_lz_steps_to_check(r, lrate, RP_LZ_TOL, max_steps); }
 
-template <int DEPTH, int VB>    // VB: basis-vector entries a lane keeps in flight in the re-orthogonalisation (16 in the 512-thread kernel, 8 at 1024 threads: 128 VGPRs)
+template <int DEPTH, int VB, bool HU>    // HU: the products gather {h, u} pairs (Fit1::hu, kept up to date here); VB: basis-vector entries a lane keeps in flight in the re-orthogonalisation (16 in the 512-thread kernel, 8 at 1024 threads: 128 VGPRs)
 __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* lrate) {
     const int C = f.C, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     int nprod = 0;
@@ -778,6 +802,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
     while (true) {
         if (f.KL > 0) { for (int c = tid; c < C; c += blockDim.x) f.Vl[c] = f.vec[c]; }
         else for (int c = tid; c < C; c += blockDim.x) f.V[c] = f.vec[c];
+        if constexpr (HU) for (int c = tid; c < C; c += blockDim.x) *reinterpret_cast<double2*>(f.hu + 2 * c) = make_double2(f.hh[c], f.vec[c]);
         __syncthreads();
         int m = 0;
         double beta_last = 0.0, theta = 0.0;
@@ -789,7 +814,7 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
         for (int j = 0; j < RP_LZ_M && !done; ++j) {
             long long t0_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
             if (f.G > 1 && f.epoch[3] == 0) fit_dist_product<DEPTH>(f, f.yy, (int*)(f.epoch + 2));     // yy = A v_j with the helper workgroups
-            else seg_pass<1, DEPTH>(f, f.yy, mu_xe, false);                                // yy = A v_j   (barriers inside)
+            else seg_pass<1, DEPTH, HU>(f, f.yy, mu_xe, false);                            // yy = A v_j   (barriers inside)
             ++nprod;
             long long t1_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
             // classical Gram-Schmidt against v_0..v_j (its coefficient of v_j is alpha_j); a second pass only when the
@@ -893,9 +918,9 @@ __device__ int lanczos_top(const Fit1& f, double mu_xe, int* converged, double* 
                 double* vn = f.V + (size_t)(j + 1) * f.Cmax;
                 if (j + 1 < f.KL) {
                     double* vln = f.Vl + (size_t)(j + 1) * f.Cmax;
-                    for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; vln[c] = v; f.vec[c] = v; }
+                    for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; vln[c] = v; f.vec[c] = v; if (HU) f.hu[2 * c + 1] = v; }
                 } else
-                for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; rp_stg(vn + c, v); f.vec[c] = v; }
+                for (int c = tid; c < C; c += blockDim.x) { const double v = f.yy[c] * inv; rp_stg(vn + c, v); f.vec[c] = v; if (HU) f.hu[2 * c + 1] = v; }
             }
             __syncthreads();
             if (j == 0 && !f.fixed_checks) {                                       // the start vector's own residual: free
@@ -1094,13 +1119,16 @@ __device__ __forceinline__ void write_pose_lds(double* out, const double* Rt) {
 #ifndef RP_FIT_EPT
 #define RP_FIT_EPT(T_) ((T_) == 512 ? 1 : 0)
 #endif
-template <int THREADS, bool GVEC>       // GVEC: the three per-correspondence vectors + row / segment pointers in global memory (else LDS)
+// LAYOUT 0: everything in LDS incl. the {h, u} pairs of the products (Cmax <= RP_FIT1_MAXC_HU); 2: the same without the pairs (up to RP_FIT1_MAXC: they
+// would not fit); 1 = GVEC: the three per-correspondence vectors + row / segment pointers in global memory
+template <int THREADS, int LAYOUT>
 __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, Graph g, RpPairConsts kc, int topK, int method,
                                                                     double* __restrict__ lz_basis, double* __restrict__ gvec, int32_t* __restrict__ status,
                                                                     double* __restrict__ pose, double* __restrict__ trace,
                                                                     int32_t* __restrict__ counts_out, int32_t* __restrict__ eig_iters_out,
                                                                     long long* __restrict__ prof, int tri_rounds, FitCtl* __restrict__ ctl_all,
                                                                     double* __restrict__ xu_all, int meta_cap, int basis_lds) {
+    constexpr bool GVEC = (LAYOUT == 1), HUL = (LAYOUT == 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[160];
     __shared__ double Rt[12];
@@ -1128,6 +1156,9 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             f.meta = nullptr; f.meta_cap = 0;
             const size_t eoffh = (size_t)b * g.estride;
             f.col = g.col + eoffh; f.wv = g.wv + eoffh; f.xe = g.xe + eoffh;
+            f.rs_col = __builtin_amdgcn_make_buffer_rsrc((void*)f.col, 0, (int)(g.estride * 4), 0x00020000);
+            f.rs_wv = __builtin_amdgcn_make_buffer_rsrc((void*)f.wv, 0, (int)(g.estride * 8), 0x00020000);
+            f.rs_xe = __builtin_amdgcn_make_buffer_rsrc((void*)f.xe, 0, (int)(g.estride * 8), 0x00020000);
             f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
             f.nseg = f.sp[C];
             unsigned last = 0, hseen = 0;       // product number / h version seen last
@@ -1189,7 +1220,9 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     f.ctl = ctl; f.xu = xu_all + (size_t)b * (2 * (size_t)g.Cmax + g.seg_cap); f.part2 = f.xu + 2 * (size_t)g.Cmax; f.G = G; f.epoch = &cl_s[0];
     const int32_t* rpg = g.rowptr + (size_t)b * (g.Cmax + 1);
     const int32_t* spg = g.segptr + (size_t)b * (g.Cmax + 1);
-    f.tri = (double*)smem; f.cbuf = f.tri + 4 * (RP_LZ_M + 1);
+    // (LDS layout: the {h, u} pairs first -- 16-byte aligned for their ds_read_b128 gathers --, then the tridiagonal scratch, the vectors, ...)
+    f.hu = HUL ? (double*)smem : nullptr;
+    f.tri = (double*)smem + (HUL ? 2 * (size_t)g.Cmax : 0); f.cbuf = f.tri + 4 * (RP_LZ_M + 1);
     // (a compile-time choice: with a run-time one the compiler no longer knows the address space and emits FLAT accesses for the
     // LDS layout -- measured +50 % on the whole kernel)
     if constexpr (GVEC) {   // more correspondences than LDS holds: the three vectors in global scratch, row / segment pointers read in place
@@ -1208,6 +1241,9 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     f.red = red;
     const size_t eoff = (size_t)b * g.estride;
     f.col = g.col + eoff; f.wv = g.wv + eoff; f.xe = g.xe + eoff;
+    f.rs_col = __builtin_amdgcn_make_buffer_rsrc((void*)f.col, 0, (int)(g.estride * 4), 0x00020000);
+    f.rs_wv = __builtin_amdgcn_make_buffer_rsrc((void*)f.wv, 0, (int)(g.estride * 8), 0x00020000);
+    f.rs_xe = __builtin_amdgcn_make_buffer_rsrc((void*)f.xe, 0, (int)(g.estride * 8), 0x00020000);
     f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
     f.V = lz_basis + (size_t)b * (RP_LZ_M + 1) * g.Cmax;
     if constexpr (!GVEC) {
@@ -1265,7 +1301,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             __syncthreads();
             if (G > 1) fit_publish_h(f);
             int conv = 1;
-            const int np = lanczos_top<DEPTH, (THREADS == 512 ? 16 : 8)>(f, (!sm && round > 0) ? kc.mu : 0.0, &conv, &lrate);       // rounds > 0: warm start from f.vec
+            const int np = lanczos_top<DEPTH, (THREADS == 512 ? 16 : 8), HUL>(f, (!sm && round > 0) ? kc.mu : 0.0, &conv, &lrate);       // rounds > 0: warm start from f.vec
             all_converged &= conv;
             if (eig_iters_out && tid == 0) eig_iters_out[b * 5 + round] = np;
             long long tf_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -1295,8 +1331,10 @@ bool kp_ok(const RelposeKeypoints* kp, const RelposeParams* p) {
 // The fit keeps 3 vectors of C doubles + the row / segment pointers of a pair in LDS up to RP_FIT1_MAXC correspondences; beyond
 // that (or with RELPOSE_TUNE_FIT_GLOBAL_VECTORS) the same kernel keeps them in global scratch (gvec; rowptr / segptr in place).
 static bool fit_in_lds(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && g_rp_tune[RELPOSE_TUNE_FIT_GLOBAL_VECTORS] == 0; }
+static bool fit_hu(int32_t Cmax, bool in_lds) { return in_lds && Cmax <= RP_FIT1_MAXC_HU; }
 static size_t fit_lds_bytes(int32_t Cmax, bool in_lds) {
-    return (size_t)(5 * (RP_LZ_M + 1)) * 8 + 16 + (in_lds ? (size_t)Cmax * 24 + (size_t)(Cmax + 1) * 8 : 0);
+    return (size_t)(5 * (RP_LZ_M + 1)) * 8 + 16 + (in_lds ? (size_t)Cmax * (fit_hu(Cmax, true) ? 40 : 24) + (size_t)(Cmax + 1) * 8 : 0);     // (40 = three vectors + the {h, u} pairs)
+    // NB: whoever launches layout 0 must have sized the LDS with fit_hu() true, i.e. Cmax <= RP_FIT1_MAXC_HU (the dispatch below guarantees it)
 }
 // entries of the LDS segment table (row | length of a pair's first segments) behind that: enough for ~3 segments per row, within the CU's 160 KB
 static int fit_meta_cap(int32_t Cmax, int32_t seg_cap, bool in_lds) {
@@ -1526,8 +1564,9 @@ int relpose_match_pairs_ex(const RelposeMatchArgs* args) {
                                status, pose, trace, dbg ? dbg->counts : nullptr, eig_iters, prof, tri_rounds, (FitCtl*)(ws + L.ctl),      \
                                (double*)(ws + L.xu), meta_cap, basis_lds);                                                              \
         }
-        if (fit_threads == 512) { if (in_lds) RP_FIT_LAUNCH(512, false) else RP_FIT_LAUNCH(512, true) }
-        else { if (in_lds) RP_FIT_LAUNCH(1024, false) else RP_FIT_LAUNCH(1024, true) }
+        // (512 threads <=> Cmax <= 1024 <=> the {h, u} pairs when in LDS: layout 0; the 1024-thread kernel's LDS layout is 2, without them)
+        if (fit_threads == 512 && (fit_hu(L.Cmax, in_lds) || !in_lds)) { if (in_lds) RP_FIT_LAUNCH(512, 0) else RP_FIT_LAUNCH(512, 1) }
+        else { if (!in_lds) RP_FIT_LAUNCH(1024, 1) else RP_FIT_LAUNCH(1024, 2) }
 #undef RP_FIT_LAUNCH
         RP_CHECK_LAUNCH();
         if (prof) {       // experiments build only: synchronises
