@@ -336,7 +336,7 @@ __device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, do
 }
 
 // ------------------------------------------------------------------ single-workgroup fit (the default path)
-// One 1024-thread workgroup per scan pair runs the WHOLE fit of rpmodule.py:212-315 in one launch: status
+// One workgroup per scan pair (512 threads up to 1024 correspondences, 768 beyond) runs the WHOLE fit of rpmodule.py:212-315 in one launch: status
 // finalisation, geometry gather, degrees, the IRLS iterations and the five spectral rounds.  The pair's
 // compatibility graph (~31 k directed edges at N = 200) is streamed from L2 once per matrix-vector product in the
 // segment layout (see Graph): a lane walks one segment of <= 32 edges of one row, a wave reads 64 consecutive entries
@@ -348,7 +348,7 @@ __device__ __forceinline__ void corr_geom(const FitCtx& f, int c, double* sp, do
 // (rpmodule.py:273), where round 1 ran a capped power iteration.  Rounds 2..5 start from the previous round's
 // eigenvector.  A pair that is still not converged after RP_LZ_MAXPROD products gets RELPOSE_NOT_CONVERGED.
 // All reductions have a fixed order: results are bitwise reproducible and independent of the batch.
-#define RP_FIT1_THREADS 1024
+#define RP_FIT1_THREADS 1024      // (the rounds 2-5 size of the large kernel: experiments build only since round 6)
 #define RP_LZ_M 24              // Lanczos steps per cycle (basis size)
 #define RP_LZ_CHECK 8           // convergence test every 8 steps
 #define RP_LZ_MAXPROD 192       // products per eigen-solve before giving up
@@ -1301,7 +1301,10 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             __syncthreads();
             if (G > 1) fit_publish_h(f);
             int conv = 1;
-            const int np = lanczos_top<DEPTH, (THREADS == 512 ? 16 : 8), HUL>(f, (!sm && round > 0) ? kc.mu : 0.0, &conv, &lrate);       // rounds > 0: warm start from f.vec
+#ifndef RP_FIT_VB
+#define RP_FIT_VB(T_) ((T_) == 512 ? 16 : 8)
+#endif
+            const int np = lanczos_top<DEPTH, RP_FIT_VB(THREADS), HUL>(f, (!sm && round > 0) ? kc.mu : 0.0, &conv, &lrate);       // rounds > 0: warm start from f.vec
             all_converged &= conv;
             if (eig_iters_out && tid == 0) eig_iters_out[b * 5 + round] = np;
             long long tf_ = f.prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -1540,9 +1543,12 @@ int relpose_match_pairs_ex(const RelposeMatchArgs* args) {
         const int tri_rounds = (RP_ENV("RELPOSE_TRI_ROUNDS") ? atoi(RP_ENV("RELPOSE_TRI_ROUNDS")) : RP_TRI_ROUNDS) |
                                ((g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] > 0 ? g_rp_tune[RELPOSE_TUNE_FIT_MAX_PRODUCTS] : RP_LZ_MAXPROD) << 8) |
                                ((g_rp_tune[RELPOSE_TUNE_FIT_FIXED_CHECKS] != 0 ? 1 : 0) << 24);
-        // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences,
-        // 1024 beyond (N = 400: the edge passes dominate).  RELPOSE_FIT_THREADS = 512 | 1024 overrides (experiments build).
-        const int fit_threads = RP_ENV("RELPOSE_FIT_THREADS") ? atoi(RP_ENV("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : RP_FIT1_THREADS);
+        // workgroup size: 512 threads (no register spills: IRLS twice as fast) while every thread still owns at most two correspondences; beyond,
+        // 768 in the LDS layout (round 6: three waves per SIMD and a 170-register budget -- measured at N = 400, B = 32, same box: 640 threads 5.56 ms,
+        // 768 5.38, 896 5.76, 1024 5.66: the edge passes are no slower than with 16 waves and the IRLS spills less; at N = 200: 384 threads 3.12,
+        // 512 2.82, 640 2.97, 768 2.98), in the global layout too (N = 400 forced into it: 12.83 vs 13.15 ms at 1024).  RELPOSE_FIT_THREADS = 1024
+        // brings the rounds 2-5 kernel back (experiments build).
+        const int fit_threads = RP_ENV("RELPOSE_FIT_THREADS") ? atoi(RP_ENV("RELPOSE_FIT_THREADS")) : (L.Cmax <= 1024 ? 512 : 768);
         // helper workgroups per pair for the matrix-vector products (see FitCtl): a LATENCY tool.  Alone on the chip the matcher of 32
         // N = 400 pairs drops from 7.7 to 5.1 ms with 7 helpers per pair, but helpers sit on a CU each for the whole fit, mostly
         // polling, and inside the pipeline they take those CUs from the SCNet kernels of the other slot: configs[2] 462 -> 400 pairs/s,
@@ -1566,7 +1572,11 @@ int relpose_match_pairs_ex(const RelposeMatchArgs* args) {
         }
         // (512 threads <=> Cmax <= 1024 <=> the {h, u} pairs when in LDS: layout 0; the 1024-thread kernel's LDS layout is 2, without them)
         if (fit_threads == 512 && (fit_hu(L.Cmax, in_lds) || !in_lds)) { if (in_lds) RP_FIT_LAUNCH(512, 0) else RP_FIT_LAUNCH(512, 1) }
-        else { if (!in_lds) RP_FIT_LAUNCH(1024, 1) else RP_FIT_LAUNCH(1024, 2) }
+#ifdef RP_EXPERIMENTS
+        else if (fit_threads == 1024) { if (in_lds) RP_FIT_LAUNCH(1024, 2) else RP_FIT_LAUNCH(1024, 1) }
+#endif
+        else if (!in_lds) RP_FIT_LAUNCH(768, 1)
+        else RP_FIT_LAUNCH(768, 2)
 #undef RP_FIT_LAUNCH
         RP_CHECK_LAUNCH();
         if (prof) {       // experiments build only: synchronises
