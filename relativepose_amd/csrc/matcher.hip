@@ -45,13 +45,20 @@ struct Graph {                 // per-batch device arrays of the pair-compatibil
     double* state;             // [B, 4, Cmax]  deg, gP, gN, rsum
     double* geo;               // [B, Cmax, 12]  sp, tp, sn, tn of every correspondence (gathered once per fit)
     int32_t* pairC;            // [B] number of correspondences of a pair whose fit is running, 0 otherwise
-    // Edge storage: every row is cut into SEGMENTS of <= 32 edges; segment s = segptr[c] + k / 32 lives in slot s % 64 of wave-slice
-    // s / 64, edge k % 32 of it at ((s >> 6) << 11) + ((k & 31) << 6) + (s & 63): the 64 lanes of a wave, each walking its own
-    // segment, read 64 consecutive entries per step (SELL-64 over segments).  The bitmap holds the full symmetric adjacency.
+    // Edge storage: every row is cut into SEGMENTS of <= 32 edges; segment s lives in slot s % 64 of wave-slice s / 64, edge k % 32 of it at
+    // ((s >> 6) << 11) + ((k & 31) << 6) + (s & 63): the 64 lanes of a wave, each walking its own segment, read 64 consecutive entries per step
+    // (SELL-64 over segments).  (r6) Segment numbering: first every row's FULL segments (32 edges), row by row -- row c owns
+    // segptr[c] .. segptr[c+1]-1, segptr[C] = their number --, then the rows' last, PARTIAL segments sorted by length class
+    // (25-31, 17-24, 9-16, 1-8 edges; row order within a class): segpart[c] or -1, segpart[C] = all segments.  A wave of the edge passes thus
+    // sees 64 segments of (almost always) one class and skips the 8-edge batches none of them has -- with the rows' segments numbered row by
+    // row (rounds 2-5) nearly every wave ran all four batches for its shortest segments (30 % of the slots dead at N = 200).  A row's sum
+    // still adds its segments' partial sums in the row's own order (full ones, then the partial one): bitwise the same results.
+    // The bitmap holds the full symmetric adjacency.
     int32_t seg_cap;           // segments per pair the edge arrays are sized for (multiple of 64)
     int64_t estride;           // entries of col / wv / xe per pair
-    int32_t* segptr;           // [B, Cmax+1] first segment of every row
-    int32_t* segrow;           // [B, seg_cap] row of every segment
+    int32_t* segptr;           // [B, Cmax+1] first FULL segment of every row; [C] = number of full segments
+    int32_t* segpart;          // [B, Cmax+1] the row's partial segment (-1: none); [C] = number of segments
+    int32_t* segrow;           // [B, seg_cap] row | length << 16 of every segment (the fit's segment-table word)
     double* part;              // [B, seg_cap] per-segment partial sums of the edge passes
 };
 #define RP_SEG 32
@@ -113,32 +120,57 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(RelposeKeypoints kp, Gr
     }
     const int total_edges = carry_s;
     __syncthreads();
-    {                            // first segment of every row + the row of every segment
+    {                            // segment numbering (see Graph): full segments row by row, then the partial ones by length class; the row of every segment
         int32_t* sp = g.segptr + (size_t)b * (g.Cmax + 1);
+        int32_t* pp = g.segpart + (size_t)b * (g.Cmax + 1);
         int32_t* sr = g.segrow + (size_t)b * g.seg_cap;
-        if (threadIdx.x == 0) carry_s = 0;
+        __shared__ unsigned long long wsum2[16];
+        __shared__ unsigned long long carry2_s;
+        if (threadIdx.x == 0) { carry_s = 0; carry2_s = 0ull; }
         __syncthreads();
         for (int base = 0; base < C; base += 1024) {
             const int c = base + threadIdx.x;
             const int deg = (c < C) ? g.upcnt[(size_t)b * g.Cmax + c] : 0;
-            const int v = (deg + RP_SEG - 1) / RP_SEG;
+            const int v = deg / RP_SEG, rem = deg % RP_SEG;
+            const int cls = rem ? (rem + 7) >> 3 : 0;                               // 1 .. 4 (8-edge batches of the partial segment), 0: none
+            const unsigned long long key = cls ? 1ull << (16 * (cls - 1)) : 0ull;  // four 16-bit counters (<= Cmax <= 8192 rows each) in one scan
             int inc = v;
+            unsigned long long inc2 = key;
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1) { int t = __shfl_up(inc, m, 64); if (lane >= m) inc += t; }
-            if (lane == 63) wsum[wave] = inc;
+            for (int m = 1; m < 64; m <<= 1) {
+                const int t = __shfl_up(inc, m, 64);
+                const unsigned long long t2 = __shfl_up(inc2, m, 64);
+                if (lane >= m) { inc += t; inc2 += t2; }
+            }
+            if (lane == 63) { wsum[wave] = inc; wsum2[wave] = inc2; }
             __syncthreads();
             int pre = carry_s;
-            for (int w = 0; w < wave; ++w) pre += wsum[w];
+            unsigned long long pre2 = carry2_s;
+            for (int w = 0; w < wave; ++w) { pre += wsum[w]; pre2 += wsum2[w]; }
             if (c < C) {
                 const int first = pre + inc - v;
                 sp[c] = first;
-                if (first + v <= g.seg_cap) for (int i = 0; i < v; ++i) sr[first + i] = c;
+                if (first + v <= g.seg_cap) for (int i = 0; i < v; ++i) sr[first + i] = c | (RP_SEG << 16);
+                // (rank of the row's partial segment within its class, class in the top bits: turned into a segment number below)
+                pp[c] = cls ? (int)(((pre2 + inc2 - key) >> (16 * (cls - 1))) & 0xffffull) | (cls << 16) : -1;
             }
             __syncthreads();
-            if (threadIdx.x == 1023) carry_s = pre + inc;
+            if (threadIdx.x == 1023) { carry_s = pre + inc; carry2_s = pre2 + inc2; }
             __syncthreads();
         }
-        if (threadIdx.x == 0) sp[C] = carry_s;
+        const int nfull = carry_s;
+        const unsigned long long tot = carry2_s;
+        const int n4 = (int)((tot >> 48) & 0xffff), n3 = (int)((tot >> 32) & 0xffff), n2 = (int)((tot >> 16) & 0xffff), n1 = (int)(tot & 0xffff);
+        for (int c = threadIdx.x; c < C; c += 1024) {
+            const int e = pp[c];
+            if (e < 0) continue;
+            const int cls = e >> 16, rank = e & 0xffff;
+            const int rem = g.upcnt[(size_t)b * g.Cmax + c] % RP_SEG;
+            const int s_ = nfull + (cls == 4 ? 0 : cls == 3 ? n4 : cls == 2 ? n4 + n3 : n4 + n3 + n2) + rank;     // longest class first
+            pp[c] = s_;
+            if (s_ < g.seg_cap) sr[s_] = c | (rem << 16);
+        }
+        if (threadIdx.x == 0) { sp[C] = nfull; pp[C] = nfull + n4 + n3 + n2 + n1; }
     }
     if (threadIdx.x == 0) {
         const int total = total_edges;
@@ -290,7 +322,9 @@ __global__ __launch_bounds__(256) void pair_fill_rows_kernel(RelposeKeypoints kp
     load_corr(kp, g, b, topK, keff, c, me);
     const size_t eoff = (size_t)b * g.estride;
     const int row_start = g.rowptr[(size_t)b * (g.Cmax + 1) + c];
-    const int seg0 = g.segptr[(size_t)b * (g.Cmax + 1) + c];
+    const int seg0 = g.segptr[(size_t)b * (g.Cmax + 1) + c];                  // the row's full segments: seg0, seg0 + 1, ...
+    const int segp = g.segpart[(size_t)b * (g.Cmax + 1) + c];                 // ... and its partial one (edges nfe .. deg - 1)
+    const int nfe = deg / RP_SEG * RP_SEG;
     int nz = 0;
     for (int k = lane; k < deg; k += 64) {
         const int x = list[k];
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(256) void pair_fill_rows_kernel(RelposeKeypoints kp
             const RpPairEval ev = rp_pair_eval(me.ps, me.ns, me.pt, me.nt, o.ps, o.ns, o.pt, o.nt, kc);
             w = rp_pair_weight(ev, me.f, o.f, me.ws, o.ws, me.wt, o.wt, kc);
         }
-        const size_t pos = seg_edge_index(seg0 + (k >> 5), k);
+        const size_t pos = seg_edge_index(k < nfe ? seg0 + (k >> 5) : segp, k);
         g.col[eoff + pos] = x;
         g.wv[eoff + pos] = w;
         nz += (w != 0.0) ? 1 : 0;
@@ -312,7 +346,7 @@ __global__ __launch_bounds__(256) void pair_fill_rows_kernel(RelposeKeypoints kp
     // (r6) the unused slots of the row's last segment: column 0, weight 0 -- an edge pass then needs no per-slot predicate: a dead slot adds
     // w * (...) = +-0 to a sum that is never -0 (seg_body)
     for (int k = deg + lane; k < ((deg + RP_SEG - 1) / RP_SEG) * RP_SEG; k += 64) {
-        const size_t pos = seg_edge_index(seg0 + (k >> 5), k);
+        const size_t pos = seg_edge_index(segp, k);
         g.col[eoff + pos] = 0;
         g.wv[eoff + pos] = 0.0;
     }
@@ -365,8 +399,9 @@ struct Fit1 {                   // LDS layout + per-pair pointers of the single-
     double* vec;                // [C] current Lanczos vector / eigenvector (gather source of the products)
     double* hh;                 // [C] h = relu(50 - r)
     double* yy;                 // [C] product output
-    int32_t* rp;                // [C + 1] CSR row pointers (row lengths)
-    int32_t* sp;                // [C + 1] first segment of every row
+    int32_t* sp;                // [C + 1] first full segment of every row (Graph::segptr)
+    int32_t* pp;                // [C + 1] the row's partial segment or -1 (Graph::segpart)
+    int nfull;                  // segments below this number are full (32 edges)
     int32_t* meta;              // [meta_cap] LDS: row | length << 16 of the pair's first meta_cap segments (constant over the fit; 0 entries: helpers, global layout)
     int meta_cap;
     double* red;                // [160] reduction scratch
@@ -457,9 +492,7 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
         int r, len;
         if (sgm < f.meta_cap) { const int mw = f.meta[sgm]; r = mw & 0xffff; len = mw >> 16; }
         else {
-            r = f.segrow[sgm];
-            const int k0 = (sgm - f.sp[r]) * RP_SEG;
-            len = min(RP_SEG, (f.rp[r + 1] - f.rp[r]) - k0);
+            const int mw = f.segrow[sgm]; r = mw & 0xffff; len = mw >> 16;
         }
         const size_t e0 = seg_edge_index(sgm, 0);
         const double hr = (MODE == 1) ? f.hh[r] : 0.0, ur = (MODE == 2) ? f.vec[r] : 0.0;
@@ -567,6 +600,10 @@ __device__ __forceinline__ void seg_row_sums(const Fit1& f, double* out) {
                     if (b0 + k + q < b1) acc1 += w[q];
                 }
             }
+            const int p0 = f.pp[r0], p1 = two ? f.pp[r1] : -1;                     // the rows' partial segments come last, as they always did
+            const double v0 = p0 >= 0 ? rp_ld_sc1(f.part2 + p0) : 0.0, v1 = p1 >= 0 ? rp_ld_sc1(f.part2 + p1) : 0.0;
+            if (p0 >= 0) acc0 += v0;
+            if (p1 >= 0) acc1 += v1;
             out[r0] = acc0;
             if (two) out[r1] = acc1;
         }
@@ -576,6 +613,8 @@ __device__ __forceinline__ void seg_row_sums(const Fit1& f, double* out) {
             const int a = f.sp[r], b = f.sp[r + 1], bl = min(b, f.meta_cap);
             for (int sgm = a; sgm < bl; ++sgm) acc += f.partl[sgm];                                    // (same order: LDS-resident segments come first)
             for (int sgm = max(a, f.meta_cap); sgm < b; ++sgm) acc += *(RP_GLOBAL const double*)(f.part + sgm);
+            const int p = f.pp[r];                                                 // the row's partial segment comes last, as it always did
+            if (p >= 0) acc += p < f.meta_cap ? f.partl[p] : *(RP_GLOBAL const double*)(f.part + p);
             out[r] = acc;
         }
     }
@@ -1152,7 +1191,8 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             f.C = C; f.Cmax = g.Cmax;
             f.ctl = ctl; f.xu = xu_all + (size_t)b * (2 * (size_t)g.Cmax + g.seg_cap); f.part2 = f.xu + 2 * (size_t)g.Cmax; f.G = G;
             f.vec = (double*)smem; f.hh = f.vec + g.Cmax;                        // the published u and h
-            f.rp = g.rowptr + (size_t)b * (g.Cmax + 1); f.sp = g.segptr + (size_t)b * (g.Cmax + 1);      // (global: read in place)
+            f.sp = g.segptr + (size_t)b * (g.Cmax + 1);      // (global: read in place)
+            f.pp = g.segpart + (size_t)b * (g.Cmax + 1);
             f.meta = nullptr; f.meta_cap = 0;
             const size_t eoffh = (size_t)b * g.estride;
             f.col = g.col + eoffh; f.wv = g.wv + eoffh; f.xe = g.xe + eoffh;
@@ -1160,7 +1200,7 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
             f.rs_wv = __builtin_amdgcn_make_buffer_rsrc((void*)f.wv, 0, (int)(g.estride * 8), 0x00020000);
             f.rs_xe = __builtin_amdgcn_make_buffer_rsrc((void*)f.xe, 0, (int)(g.estride * 8), 0x00020000);
             f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
-            f.nseg = f.sp[C];
+            f.nfull = f.sp[C]; f.nseg = f.pp[C];
             unsigned last = 0, hseen = 0;       // product number / h version seen last
             for (;;) {
                 if (tid == 0) {
@@ -1218,8 +1258,8 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     const long long tstart_ = prof ? (long long)__builtin_readcyclecounter() : 0;
     f.C = C; f.Cmax = g.Cmax;
     f.ctl = ctl; f.xu = xu_all + (size_t)b * (2 * (size_t)g.Cmax + g.seg_cap); f.part2 = f.xu + 2 * (size_t)g.Cmax; f.G = G; f.epoch = &cl_s[0];
-    const int32_t* rpg = g.rowptr + (size_t)b * (g.Cmax + 1);
     const int32_t* spg = g.segptr + (size_t)b * (g.Cmax + 1);
+    const int32_t* ppg = g.segpart + (size_t)b * (g.Cmax + 1);
     // (LDS layout: the {h, u} pairs first -- 16-byte aligned for their ds_read_b128 gathers --, then the tridiagonal scratch, the vectors, ...)
     f.hu = HUL ? (double*)smem : nullptr;
     f.tri = (double*)smem + (HUL ? 2 * (size_t)g.Cmax : 0); f.cbuf = f.tri + 4 * (RP_LZ_M + 1);
@@ -1227,12 +1267,12 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     // LDS layout -- measured +50 % on the whole kernel)
     if constexpr (GVEC) {   // more correspondences than LDS holds: the three vectors in global scratch, row / segment pointers read in place
         f.vec = gvec + (size_t)b * 3 * g.Cmax; f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
-        f.rp = const_cast<int32_t*>(rpg); f.sp = const_cast<int32_t*>(spg);
+        f.sp = const_cast<int32_t*>(spg); f.pp = const_cast<int32_t*>(ppg);
         f.meta = nullptr; f.meta_cap = 0;
     } else {
         f.vec = f.cbuf + (RP_LZ_M + 1); f.hh = f.vec + g.Cmax; f.yy = f.hh + g.Cmax;
-        f.rp = (int32_t*)(f.yy + g.Cmax); f.sp = f.rp + (g.Cmax + 1);
-        f.meta = f.sp + (g.Cmax + 1); f.meta_cap = 0;          // (set once the table is filled, below)
+        f.sp = (int32_t*)(f.yy + g.Cmax); f.pp = f.sp + (g.Cmax + 1);
+        f.meta = f.pp + (g.Cmax + 1); f.meta_cap = 0;          // (set once the table is filled, below)
     }
     // the first basis_lds Lanczos vectors live in LDS behind the segment table (meta_cap is even: 8-byte aligned); 0 in the global layout
     f.KL = GVEC ? 0 : basis_lds;
@@ -1247,17 +1287,15 @@ __global__ __launch_bounds__(THREADS) void fit_pair_kernel(RelposeKeypoints kp, 
     f.segrow = g.segrow + (size_t)b * g.seg_cap; f.part = g.part + (size_t)b * g.seg_cap;
     f.V = lz_basis + (size_t)b * (RP_LZ_M + 1) * g.Cmax;
     if constexpr (!GVEC) {
-        for (int c = tid; c <= C; c += blockDim.x) { f.rp[c] = rpg[c]; f.sp[c] = spg[c]; }
+        for (int c = tid; c <= C; c += blockDim.x) { f.sp[c] = spg[c]; f.pp[c] = ppg[c]; }
     }
     __syncthreads();
-    f.nseg = f.sp[C];
+    f.nfull = f.sp[C]; f.nseg = f.pp[C];
     if constexpr (!GVEC) {
         const int32_t* segrow_g = g.segrow + (size_t)b * g.seg_cap;
         const int nm = min(f.nseg, meta_cap);
         for (int sgm = tid; sgm < nm; sgm += blockDim.x) {
-            const int r = segrow_g[sgm];
-            const int k0 = (sgm - f.sp[r]) * RP_SEG;
-            f.meta[sgm] = r | (min(RP_SEG, (f.rp[r + 1] - f.rp[r]) - k0) << 16);
+            f.meta[sgm] = segrow_g[sgm];
         }
         __syncthreads();
         f.meta_cap = nm;
@@ -1336,7 +1374,7 @@ bool kp_ok(const RelposeKeypoints* kp, const RelposeParams* p) {
 static bool fit_in_lds(int32_t Cmax) { return Cmax <= RP_FIT1_MAXC && g_rp_tune[RELPOSE_TUNE_FIT_GLOBAL_VECTORS] == 0; }
 static bool fit_hu(int32_t Cmax, bool in_lds) { return in_lds && Cmax <= RP_FIT1_MAXC_HU; }
 static size_t fit_lds_bytes(int32_t Cmax, bool in_lds) {
-    return (size_t)(5 * (RP_LZ_M + 1)) * 8 + 16 + (in_lds ? (size_t)Cmax * (fit_hu(Cmax, true) ? 40 : 24) + (size_t)(Cmax + 1) * 8 : 0);     // (40 = three vectors + the {h, u} pairs)
+    return (size_t)(5 * (RP_LZ_M + 1)) * 8 + 16 + (in_lds ? (size_t)Cmax * (fit_hu(Cmax, true) ? 40 : 24) + (size_t)(Cmax + 1) * 8 : 0);     // (40 = three vectors + the {h, u} pairs; 8 = the rows' full-segment and partial-segment tables)
     // NB: whoever launches layout 0 must have sized the LDS with fit_hu() true, i.e. Cmax <= RP_FIT1_MAXC_HU (the dispatch below guarantees it)
 }
 // entries of the LDS segment table (row | length of a pair's first segments) behind that: enough for ~3 segments per row, within the CU's 160 KB
@@ -1364,7 +1402,7 @@ static int fit_basis_lds(int32_t Cmax, int meta_cap, bool in_lds) {
 #define RP_MAX_CORRES RELPOSE_MAX_CORRESPONDENCES      // correspondences per pair (ns_max * topK): the fill kernel's row lists are uint16 in 8 * Cmax bytes of LDS
 
 struct WsLayout {
-    size_t corres_j, corres_w, keff, bitmap, upcnt, counters, rowptr, col, wv, xe, state, geo, lz, gvec, segptr, segrow, part, ctl, xu, total;
+    size_t corres_j, corres_w, keff, bitmap, upcnt, counters, rowptr, col, wv, xe, state, geo, lz, gvec, segptr, segpart, segrow, part, ctl, xu, total;
     int32_t Cmax, Wmax, seg_cap;
     int64_t max_edges, estride;
 };
@@ -1392,6 +1430,7 @@ WsLayout ws_layout(int32_t B, int32_t ns_max, int32_t topK, int64_t max_edges) {
     L.wv = take((size_t)B * L.estride * 8);
     L.xe = take((size_t)B * L.estride * 8);
     L.segptr = take((size_t)B * (L.Cmax + 1) * 4);
+    L.segpart = take((size_t)B * (L.Cmax + 1) * 4);
     L.segrow = take((size_t)B * L.seg_cap * 4);
     L.part = take((size_t)B * L.seg_cap * 8);
     L.state = take((size_t)B * 4 * L.Cmax * 8);
@@ -1509,7 +1548,7 @@ int relpose_match_pairs_ex(const RelposeMatchArgs* args) {
     g.rowptr = (int32_t*)(ws + L.rowptr); g.col = (int32_t*)(ws + L.col);
     g.wv = (double*)(ws + L.wv); g.xe = (double*)(ws + L.xe); g.state = (double*)(ws + L.state); g.geo = (double*)(ws + L.geo);
     g.seg_cap = L.seg_cap; g.estride = L.estride;
-    g.segptr = (int32_t*)(ws + L.segptr); g.segrow = (int32_t*)(ws + L.segrow); g.part = (double*)(ws + L.part);
+    g.segptr = (int32_t*)(ws + L.segptr); g.segpart = (int32_t*)(ws + L.segpart); g.segrow = (int32_t*)(ws + L.segrow); g.part = (double*)(ws + L.part);
     RP_HIP(hipMemsetAsync(ws + L.counters, 0, (size_t)kp->B * 16, s));
     int rc = rp_launch_affinity(*p, *kp, dbg ? dbg->wij : nullptr, cj, cw, keff, s, call_affinity);
     if (rc) return rc;
