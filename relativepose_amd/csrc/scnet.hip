@@ -1716,13 +1716,15 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     const size_t pix = pix0 + threadIdx.x;
     const float* pd = hd.d2 + pix * 224;
     const float* pa = hd.a1 + pix * 192;
-    float a3[12], as_[24], af[32];                     // rgb 0:3 | n 4:7 | d 8:11 (padded quads), s, f
+    // accumulators as PAIRS: one v_pk_fma_f32 (two independent fused multiply-adds: the same roundings as two v_fma_f32) per weight pair --
+    // half the vector instructions of the 4352 multiply-adds a pixel costs (round 6)
+    rp_v2f a3[6], as_[12], af[16];                     // rgb 0:3 | n 4:7 | d 8:11 (padded quads), s, f
 #pragma unroll
-    for (int o = 0; o < 12; ++o) a3[o] = 0.f;
+    for (int o = 0; o < 6; ++o) a3[o] = (rp_v2f){0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < 24; ++o) as_[o] = 0.f;
+    for (int o = 0; o < 12; ++o) as_[o] = (rp_v2f){0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < 32; ++o) af[o] = 0.f;
+    for (int o = 0; o < 16; ++o) af[o] = (rp_v2f){0.f, 0.f};
     // One 128-byte line (32 channels) of a pixel at a time: all 8 loads are issued back to back so the line is
     // fetched once (a wave touches 64 lines per load instruction; interleaving compute between the loads of a
     // line let other waves evict it from the 32 KB L1 first).  The NEXT line's loads are issued before this line's arithmetic
@@ -1740,12 +1742,11 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                              \
                 const float2 sc = ssl[(SSROW) + q * 4 + t];                                              \
                 const float v = lrelu(xv[t] * sc.x + sc.y, LRELU);                                       \
+                const rp_v2f vv = {v, v};                                                                \
                 _Pragma("unroll") for (int j = 0; j < (NQ4); ++j) {                                      \
                     const float4 w4 = *reinterpret_cast<const float4*>(&wl[(WOFF) + (q * 4 + t) * (WSTRIDE) + j * 4]); \
-                    ACC[(OBASE) + j * 4 + 0] = fmaf(v, w4.x, ACC[(OBASE) + j * 4 + 0]);                  \
-                    ACC[(OBASE) + j * 4 + 1] = fmaf(v, w4.y, ACC[(OBASE) + j * 4 + 1]);                  \
-                    ACC[(OBASE) + j * 4 + 2] = fmaf(v, w4.z, ACC[(OBASE) + j * 4 + 2]);                  \
-                    ACC[(OBASE) + j * 4 + 3] = fmaf(v, w4.w, ACC[(OBASE) + j * 4 + 3]);                  \
+                    ACC[(OBASE) / 2 + j * 2 + 0] = __builtin_elementwise_fma(vv, (rp_v2f){w4.x, w4.y}, ACC[(OBASE) / 2 + j * 2 + 0]); \
+                    ACC[(OBASE) / 2 + j * 2 + 1] = __builtin_elementwise_fma(vv, (rp_v2f){w4.z, w4.w}, ACC[(OBASE) / 2 + j * 2 + 1]); \
                 }                                                                                        \
             }                                                                                            \
         }                                                                                                \
@@ -1761,7 +1762,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             const float4 v = rp_ldg4(reinterpret_cast<const float*>(snp + m));
-            a3[4 * m] = v.x; a3[4 * m + 1] = v.y; a3[4 * m + 2] = v.z; a3[4 * m + 3] = v.w;
+            a3[2 * m] = (rp_v2f){v.x, v.y}; a3[2 * m + 1] = (rp_v2f){v.z, v.w};
         }
         if constexpr (POSE) { RP_HEAD_LOAD(xa, pd + 32) } else { RP_HEAD_LOAD(xb, pd) }
     } else {
@@ -1777,7 +1778,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
         }
         if (hd.snap_mode == 1) {
 #pragma unroll
-            for (int m = 0; m < 3; ++m) rp_stg4(reinterpret_cast<float*>(snp + m), make_float4(a3[4 * m], a3[4 * m + 1], a3[4 * m + 2], a3[4 * m + 3]));
+            for (int m = 0; m < 3; ++m) rp_stg4(reinterpret_cast<float*>(snp + m), make_float4(a3[2 * m].x, a3[2 * m].y, a3[2 * m + 1].x, a3[2 * m + 1].y));
         }
     }
     if constexpr (POSE) {
@@ -1801,12 +1802,12 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadsDesc hd) {
     // bias, tanh, store (cf is even: 8-byte stores; a lane's cf floats are contiguous in the NHWC output)
     float r[cf + 1];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) { r[o] = POSE ? 0.f : a3[o] + hd.bias[o]; r[3 + o] = a3[4 + o] + hd.bias[3 + o]; }
-    r[6] = a3[8] + hd.bias[6];
+    for (int o = 0; o < 3; ++o) { r[o] = POSE ? 0.f : a3[o >> 1][o & 1] + hd.bias[o]; r[3 + o] = a3[2 + (o >> 1)][o & 1] + hd.bias[3 + o]; }
+    r[6] = a3[4].x + hd.bias[6];
 #pragma unroll
-    for (int o = 0; o < S; ++o) r[7 + o] = POSE ? 0.f : as_[o] + hd.bias[7 + o];
+    for (int o = 0; o < S; ++o) r[7 + o] = POSE ? 0.f : as_[o >> 1][o & 1] + hd.bias[7 + o];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) { const float v = af[k] + hd.bias[7 + S + k]; r[7 + S + k] = hd.use_tanh ? tanhf(v) : v; }
+    for (int k = 0; k < 32; ++k) { const float v = af[k >> 1][k & 1] + hd.bias[7 + S + k]; r[7 + S + k] = hd.use_tanh ? tanhf(v) : v; }
     float* o = hd.out + pix * cf;
 #pragma unroll
     for (int k = 0; k < cf / 2; ++k) *reinterpret_cast<float2*>(o + 2 * k) = make_float2(r[2 * k], r[2 * k + 1]);
