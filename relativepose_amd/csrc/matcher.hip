@@ -509,9 +509,10 @@ __device__ __forceinline__ void seg_body(const Fit1& f, int sgm, double mu_xe, b
         auto load = [&](int buf, int kb) {
 #pragma unroll
             for (int q = 0; q < U; ++q) {
-                cc[buf][q] = (int)__builtin_amdgcn_raw_buffer_load_b32(f.rs_col, vc, (kb + q) * 64 * 4, 0);
+                // (the slot's offset inside the batch folds into the instruction's 12-bit immediate, the batch's offset is one scalar per batch)
+                cc[buf][q] = (int)__builtin_amdgcn_raw_buffer_load_b32(f.rs_col, vc + q * 64 * 4, kb * 64 * 4, 0);
                 typedef unsigned rp_u32x2 __attribute__((__vector_size__(8)));
-                const rp_u32x2 wv2 = (rp_u32x2)__builtin_amdgcn_raw_buffer_load_b64(rs_w, vw, (kb + q) * 64 * 8, 0);
+                const rp_u32x2 wv2 = (rp_u32x2)__builtin_amdgcn_raw_buffer_load_b64(rs_w, vw + q * 64 * 8, kb * 64 * 8, 0);
                 w[buf][q] = __builtin_bit_cast(double, wv2);
             }
         };

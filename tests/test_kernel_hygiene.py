@@ -91,13 +91,21 @@ def test_headline_kernels_keep_their_register_budget(device_asm):
     spill_free = [("conv_s2_tile_kernelILi2ELi2ELi16ELb0ELi0E",), ("conv_s2_tile_kernelILi1ELi4ELi8ELb1ELi0E",), ("conv_s2_strip_kernelILi4ELi0E",),
                   ("deconv_tile_kernelILi1ELi1ELi4ELi16ELb0ELi0E",), ("deconv_tile_kernelILi1ELi2ELi4ELi16ELb0ELi0E",),
                   ("deconv_tile_kernelILi1ELi1ELi4ELi8ELb1ELi0E",), ("conv1_mfma_kernel",), ("heads_kernelILi15E",), ("heads_kernelILi21E",),
-                  ("resize_out_kernel",), ("fit_pair_kernelILi512ELb0E",), ("conv_igemm_kernelILi2ELi2ELi2ELi2ELb1ELb0ELi0E",),
+                  ("resize_out_kernel",), ("conv_igemm_kernelILi2ELi2ELi2ELi2ELb1ELb0ELi0E",),
                   ("conv_igemm_kernelILi2ELi2ELi2ELi2ELb1ELb1ELi0E",)]
     for parts in spill_free:
         for n in find(*parts):
             assert k[n]["vgpr_spill_count"] == 0, (n, k[n])
-    for n in find("fit_pair_kernelILi1024E") + find("affinity_tile_kernel"):
+    for n in find("affinity_tile_kernel"):
         assert k[n]["vgpr_count"] <= 128, (n, k[n])
+    # the fit's 512-thread kernel: at most a handful of long-lived values parked in scratch AROUND the eigen-solves (round 6: 17 dwords -- the
+    # IRLS's cached correspondence, stored before the first Lanczos cycle and reloaded behind the last; none inside an edge pass or the
+    # re-orthogonalisation: profiles/r06_matcher.txt measures the kernel 21 % faster than the spill-free round-5 one)
+    for n in find("fit_pair_kernelILi512ELi0E"):
+        assert k[n]["vgpr_spill_count"] <= 24, (n, k[n])
+    # the fit's large kernel (more than 1024 correspondences: 768 threads since round 6) keeps three waves per SIMD
+    for n in find("fit_pair_kernelILi768E"):
+        assert k[n]["vgpr_count"] <= 170, (n, k[n])
     # the affinity tile kernel keeps no array in scratch memory (round 4: a select between elements of the source-row array had turned into
     # a dynamically indexed load and sent the whole array -- 128+ bytes per lane -- to scratch, re-read in every pooled evaluation); the
     # fused variant does not spill at all, the materialising one at most a few registers around its (cold) dense-window path
