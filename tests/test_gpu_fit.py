@@ -119,7 +119,7 @@ def test_thousand_keypoints_fit_converges_and_matches_reference(golden_dir):
 
 def test_largest_lds_resident_fit_equals_global_layout():
     """The largest pair whose per-correspondence vectors still live in LDS (900 keypoints x topK 5 = 4500 correspondences = RP_FIT1_MAXC: the
-    1024-thread kernel with ~158 KB of dynamic LDS incl. the segment table) against the same pair forced into the global-scratch layout:
+    768-thread kernel (1024 threads in rounds 2-5) with ~158 KB of dynamic LDS incl. the segment table) against the same pair forced into the global-scratch layout:
     the two run the same arithmetic in the same order -> bitwise equal poses, status and product counts; converged; the planted motion."""
     import torch
     from relativepose_amd import _lib, rpmodule
@@ -133,6 +133,30 @@ def test_largest_lds_resident_fit_equals_global_layout():
     log("fit_lds_limit", status=int(lds.status[0]), products_per_round=lds.eig_iters[0].cpu().tolist(), surviving_pairs=int(lds.counts[0, 1]),
         rot_err_vs_ground_truth=float(np.linalg.norm(pose[:3, :3] - G[:3, :3])))
     assert int(lds.status[0]) == 0 and np.linalg.norm(pose[:3, :3] - G[:3, :3]) < 5e-2
+
+
+@pytest.mark.parametrize("N", [204, 205, 13, 64])
+def test_fit_kernel_boundaries_equal_their_global_layout_twin(N):
+    """Round 6 gave the fit three kernel shapes: 512 threads with the {h, u} pair gathers up to 1024 correspondences (N = 204, topK 5: 1020),
+    768 threads beyond (N = 205: 1025), and the global-vector layout; and renumbered the segments (full ones row by row, partial ones by
+    length class).  Either side of the boundary, a tiny pair (every row a single short segment) and a pair with exactly 64-keypoint views:
+    the LDS layout and the same pair forced into the global layout run the same sums in the same order -> bitwise equal; and the planted
+    motion comes back."""
+    import torch
+    from relativepose_amd import _lib, rpmodule
+    S, T, G = synth.make_match_case(N, 4300 + N, inlier=0.6, noise=0.002)
+    para = rpmodule.opts(0.3, 0.3, 0.04, 0.009)
+    lds = _run([(S, T)], para, debug=True)
+    with _lib.tuning(fit_global_vectors=1):
+        glob = _run([(S, T)], para, debug=True)
+    assert torch.equal(lds.pose, glob.pose) and torch.equal(lds.status, glob.status) and torch.equal(lds.eig_iters, glob.eig_iters)
+    with _lib.tuning(fit_cluster=2):
+        two = _run([(S, T)], para, debug=True)
+    assert torch.equal(lds.pose, two.pose) and torch.equal(lds.eig_iters, two.eig_iters)
+    pose = lds.pose[0].cpu().numpy()
+    e_gt = float(np.linalg.norm(pose[:3, :3] - G[:3, :3]))
+    log("fit_kernel_boundary", N=N, status=int(lds.status[0]), products_per_round=lds.eig_iters[0].cpu().tolist(), rot_err_vs_ground_truth=e_gt)
+    assert int(lds.status[0]) == 0 and e_gt < 5e-2
 
 
 def test_capacity_limits_largest_pair_runs_and_beyond_is_refused():
