@@ -22,6 +22,20 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, r);
 }
 // stage one thread's share of a chunk into `buf`: NLD activation float4 (with the transform) + NB weight float4 (plain copy)
+// STG 1: PRE-SPLIT activations (what an own pass or the producer layer's epilogue would have written: 6 bytes per element): loaded and stored as they are
+template <int NLD, int NB>
+__device__ __forceinline__ void stage_copy(float* buf, const float4* __restrict__ ga, const float4* __restrict__ gb, size_t off, int st_tid) {
+    constexpr int NC = (NLD * 3 + 1) / 2;                    // 16-byte loads for the same elements at 6 bytes each
+    float4 x[NC > 0 ? NC : 1], w[NB > 0 ? NB : 1];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) x[i] = ga[off + (size_t)i * 256 + st_tid];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) w[i] = gb[(off & 0xffff) + (size_t)i * 256 + st_tid];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) *reinterpret_cast<float4*>(buf + ((i * 256 + st_tid) * 4) % (AROWS * LD - 4)) = x[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(buf + AROWS * LD + ((i * 256 + st_tid) * 4) % (BROWS * LD - 4)) = w[i];
+}
 template <int NLD, int NB>
 __device__ __forceinline__ void stage(float* buf, const float4* __restrict__ ga, const float4* __restrict__ gb, size_t off, int st_tid, float sc, float sh) {
     float4 x[NLD > 0 ? NLD : 1], w[NB > 0 ? NB : 1];
@@ -68,6 +82,66 @@ __device__ __forceinline__ void multiply(const float* buf, floatx16 (&acc)[PH], 
             for (int t = 0; t < 6; ++t) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta[t]], b[tb[t]], acc[p], 0, 0, 0);
         }
     }
+}
+// MODE 2: the present structure with pre-split activations (stage_copy); MODE 3: the same, software-pipelined over chunks in double-buffered LDS (the next chunk's
+// loads are issued before this chunk's MFMAs, its LDS writes after them: ONE barrier per chunk)
+template <int MODE, int PH, int NSTEP, int NLD, int NB, int OCC>
+__global__ __launch_bounds__(256, OCC) void k2(float* out, const float4* ga, const float4* gb, int chunks, size_t gmask) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < (MODE == 3 ? 2 : 1) * TILE; i += blockDim.x) lds[i] = __int_as_float(0x3f803f80 + (i * 2654435761u >> 20));
+    __syncthreads();
+    floatx16 acc[PH];
+    for (int p = 0; p < PH; ++p) for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    size_t off = ((size_t)blockIdx.x * 7919 * 4096) & gmask;
+    if (MODE == 2) {
+        for (int c = 0; c < chunks; ++c) {
+            stage_copy<NLD, NB>(lds, ga, gb, off, tid);
+            off = (off + NLD * 256) & gmask;
+            __syncthreads();
+            multiply<PH, NSTEP>(lds, acc, wave, lane);
+            __syncthreads();
+        }
+    } else {
+        constexpr int NC = (NLD * 3 + 1) / 2;
+        float4 x[NC > 0 ? NC : 1], w[NB > 0 ? NB : 1];
+        stage_copy<NLD, NB>(lds, ga, gb, off, tid);
+        off = (off + NLD * 256) & gmask;
+        __syncthreads();
+        for (int c = 0; c < chunks; ++c) {
+            float* cur = lds + (c & 1) * TILE;
+            float* nxt = lds + ((c + 1) & 1) * TILE;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) x[i] = ga[off + (size_t)i * 256 + tid];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) w[i] = gb[(off & 0xffff) + (size_t)i * 256 + tid];
+            multiply<PH, NSTEP>(cur, acc, wave, lane);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) *reinterpret_cast<float4*>(nxt + ((i * 256 + tid) * 4) % (AROWS * LD - 4)) = x[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(nxt + AROWS * LD + ((i * 256 + tid) * 4) % (BROWS * LD - 4)) = w[i];
+            off = (off + NLD * 256) & gmask;
+            __syncthreads();
+        }
+    }
+    float sum = 0;
+    for (int p = 0; p < PH; ++p) for (int r = 0; r < 16; ++r) sum += acc[p][r];
+    out[blockIdx.x * 256 + tid] = sum;
+}
+template <int MODE, int PH, int NSTEP, int NLD, int NB, int OCC>
+void run2(float* d, const float4* ga, const float4* gb, size_t gmask, const char* name) {
+    const size_t lds = (size_t)(MODE == 3 ? 2 : 1) * TILE * 4;
+    (void)hipFuncSetAttribute((const void*)k2<MODE, PH, NSTEP, NLD, NB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = 256 * OCC * 4, chunks = 96;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k2<MODE, PH, NSTEP, NLD, NB, OCC><<<blocks, 256, lds>>>(d, ga, gb, 8, gmask);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); k2<MODE, PH, NSTEP, NLD, NB, OCC><<<blocks, 256, lds>>>(d, ga, gb, chunks, gmask); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    hipError_t err = hipGetLastError();
+    const double mfma = (double)blocks * 4 * chunks * NSTEP * PH * 6;
+    const double tf = mfma * 2.0 * 32 * 32 * 16 / ms / 1e9;
+    printf("%-86s %7.1f bf16 TFLOP/s = %4.1f %% of 2500 (%.2f ms)%s\n", name, tf, tf / 25.0, ms, err ? " ERROR" : "");
 }
 template <int MODE, int PH, int NSTEP, int NLD, int NB, int OCC>
 __global__ __launch_bounds__(MODE ? 512 : 256, OCC) void k(float* out, const float4* ga, const float4* gb, int chunks, size_t gmask) {
@@ -225,6 +299,9 @@ int main() {
     run<0, 4, 4, 10, 12, 1>(d, ga, gb, gmask & ~(size_t)255, "present structure, chunk twice as long (96 MFMAs), 1 WG/CU");
     run<1, 4, 4, 10, 12, 1>(d, ga, gb, gmask & ~(size_t)255, "producer / consumer, chunk twice as long (96 MFMAs; LDS as above), 1 WG/CU");
     run<1, 4, 2, 3, 3, 1>(d, ga, gb, gmask & ~(size_t)255, "producer / consumer, 60 % of the staging work, 1 WG/CU");
+    run2<2, 4, 2, 5, 6, 2>(d, ga, gb, gmask & ~(size_t)255, "present structure, PRE-SPLIT activations (staging = copy, no vector work), 2 WG/CU");
+    run2<3, 4, 2, 5, 6, 1>(d, ga, gb, gmask & ~(size_t)255, "pre-split + software-pipelined over chunks (1 barrier/chunk, 2 LDS buffers), 1 WG/CU");
+    run2<2, 4, 2, 5, 0, 2>(d, ga, gb, gmask & ~(size_t)255, "present structure, pre-split activations, NO weight staging, 2 WG/CU");
     // 16-channel chunks (24 MFMAs per computing wave and chunk), TWO computing waves per SIMD; a staging thread's share of a chunk scales with 1 / staging threads
     run16<4, 2, 4, 5, 6, 2>(d, ga, gb, gmask & ~(size_t)255, "16-ch chunks: 4 computing + 2 staging waves, 2 WG/CU");
     run16<4, 4, 4, 3, 3, 2>(d, ga, gb, gmask & ~(size_t)255, "16-ch chunks: 4 computing + 4 staging waves, 2 WG/CU");
