@@ -268,6 +268,75 @@ __global__ __launch_bounds__((NCW + NPW) * 64, OCC) void k16(float* out, const f
     for (int p = 0; p < PH; ++p) for (int r = 0; r < 16; ++r) sum += acc[p][r];
     if (!producer) out[(blockIdx.x * NCW * 64 + tid) & 0xfffff] = sum;
 }
+// all waves stage AND multiply (the present division of labour), but 16-channel chunks in double-buffered LDS with ONE barrier per chunk: a wave issues the next
+// chunk's loads, multiplies this chunk, transforms + writes the next chunk into the other buffer, barrier.  MI computing tiles of 32 rows per wave.
+template <int MI, int PH, int NLD, int NB, int OCC>
+__global__ __launch_bounds__(256, OCC) void k16u(float* out, const float4* ga, const float4* gb, int chunks, size_t gmask) {
+    constexpr int AR = 128 * MI + 32, T16 = (AR + BROWS) * LD16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * T16; i += blockDim.x) lds[i] = __int_as_float(0x3f803f80 + (i * 2654435761u >> 20));
+    __syncthreads();
+    floatx16 acc[MI][PH];
+    for (int m = 0; m < MI; ++m) for (int p = 0; p < PH; ++p) for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
+    size_t off = ((size_t)blockIdx.x * 7919 * 4096) & gmask;
+    stage16<NLD, NB, 256, AR>(lds, ga, gb, off, tid, 1.01f, 0.01f);
+    off = (off + NLD * 256) & gmask;
+    __syncthreads();
+    for (int c = 0; c < chunks; ++c) {
+        const float* cur = lds + (c & 1) * T16;
+        float* nxt = lds + ((c + 1) & 1) * T16;
+        float4 x[NLD], w[NB];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) x[i] = ga[off + (size_t)i * 256 + tid];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) w[i] = gb[(off & 0xffff) + (size_t)i * 256 + tid];
+#pragma unroll
+        for (int m = 0; m < MI; ++m) multiply16<PH, AR>(cur, acc[m], wave * MI + m, lane);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            float v[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+            unsigned hi[2], mid[2], lo[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float a = fmaf(v[2 * p], 1.01f, 0.01f), b = fmaf(v[2 * p + 1], 1.01f, 0.01f);
+                a = fmaxf(a, 0.1f * a); b = fmaxf(b, 0.1f * b);
+                hi[p] = pk_bf16(a, b);
+                const float ra = a - __uint_as_float(hi[p] << 16), rb = b - __uint_as_float(hi[p] & 0xffff0000u);
+                mid[p] = pk_bf16(ra, rb);
+                lo[p] = pk_bf16(ra - __uint_as_float(mid[p] << 16), rb - __uint_as_float(mid[p] & 0xffff0000u));
+            }
+            const int e = (i * 256 + tid) * 4;
+            float* row = nxt + (e >> 4) % AR * LD16 + ((e & 15) >> 1);
+            *reinterpret_cast<uint2*>(row) = make_uint2(hi[0], hi[1]);
+            *reinterpret_cast<uint2*>(row + 8) = make_uint2(mid[0], mid[1]);
+            *reinterpret_cast<uint2*>(row + 16) = make_uint2(lo[0], lo[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(nxt + AR * LD16 + ((i * 256 + tid) * 4) % (BROWS * LD16 - 4)) = w[i];
+        off = (off + NLD * 256) & gmask;
+        __syncthreads();
+    }
+    float sum = 0;
+    for (int m = 0; m < MI; ++m) for (int p = 0; p < PH; ++p) for (int r = 0; r < 16; ++r) sum += acc[m][p][r];
+    out[blockIdx.x * 256 + tid] = sum;
+}
+template <int MI, int PH, int NLD, int NB, int OCC>
+void run16u(float* d, const float4* ga, const float4* gb, size_t gmask, const char* name) {
+    constexpr int AR = 128 * MI + 32, T16 = (AR + BROWS) * LD16;
+    const size_t lds = (size_t)2 * T16 * 4;
+    (void)hipFuncSetAttribute((const void*)k16u<MI, PH, NLD, NB, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = 256 * OCC * 4, chunks = 192;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k16u<MI, PH, NLD, NB, OCC><<<blocks, 256, lds>>>(d, ga, gb, 8, gmask);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); k16u<MI, PH, NLD, NB, OCC><<<blocks, 256, lds>>>(d, ga, gb, chunks, gmask); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    hipError_t err = hipGetLastError();
+    const double mfma = (double)blocks * 4 * MI * chunks * PH * 6;
+    const double tf = mfma * 2.0 * 32 * 32 * 16 / ms / 1e9;
+    printf("%-86s %7.1f bf16 TFLOP/s = %4.1f %% of 2500 (%.2f ms, %zu KB LDS)%s\n", name, tf, tf / 25.0, ms, lds / 1024, err ? " ERROR" : "");
+}
 template <int NCW, int NPW, int PH, int NLD, int NB, int OCC>
 void run16(float* d, const float4* ga, const float4* gb, size_t gmask, const char* name) {
     constexpr int AR = 32 * NCW + 32, T16 = (AR + BROWS) * LD16;
@@ -307,6 +376,10 @@ int main() {
     run16<4, 4, 4, 3, 3, 2>(d, ga, gb, gmask & ~(size_t)255, "16-ch chunks: 4 computing + 4 staging waves, 2 WG/CU");
     run16<8, 4, 4, 5, 3, 1>(d, ga, gb, gmask & ~(size_t)255, "16-ch chunks: 8 computing + 4 staging waves (256-row tile), 1 WG/CU");
     run16<8, 8, 4, 3, 2, 1>(d, ga, gb, gmask & ~(size_t)255, "16-ch chunks: 8 computing + 8 staging waves (256-row tile), 1 WG/CU");
+    run16u<1, 4, 3, 3, 2>(d, ga, gb, gmask & ~(size_t)255, "16-ch chunks, every wave stages + multiplies, 1 barrier/chunk (2 LDS buffers), 2 WG/CU");
+    run16u<1, 4, 3, 3, 3>(d, ga, gb, gmask & ~(size_t)255, "the same, 3 WG/CU allowed");
+    run16u<2, 4, 5, 3, 1>(d, ga, gb, gmask & ~(size_t)255, "the same, TWO 32-row tiles per wave (128 accumulators: half the weight-fragment reads), 1 WG/CU");
+    run16u<2, 4, 5, 3, 2>(d, ga, gb, gmask & ~(size_t)255, "the same, two tiles per wave, 2 WG/CU");
     run16<4, 2, 4, 0, 0, 2>(d, ga, gb, gmask & ~(size_t)255, "16-ch chunks: 4 + 2 waves, NO staging work, 2 WG/CU");
     run16<8, 4, 4, 0, 0, 1>(d, ga, gb, gmask & ~(size_t)255, "16-ch chunks: 8 + 4 waves, NO staging work, 1 WG/CU");
     return 0;
