@@ -165,6 +165,44 @@ def test_matcher_ops_equal_cabi(ctx):
         ops.match_pairs(*kp, O.params_list(para), para.topK, 9, 0)
 
 
+def test_meta_kernels_predict_the_real_outputs(ctx):
+    """The Meta ("fake") kernels of torch.ops.relpose.* give the shapes and dtypes the HIP implementations return (incl. scnet_forward,
+    whose channel count comes from the net behind the handle)."""
+    torch, dev, net, S = ctx.torch, ctx.dev, ctx.net, ctx.S
+    from relativepose_amd import ops as O
+    ops = torch.ops.relpose
+    meta = lambda t: torch.empty(t.shape, dtype=t.dtype, device="meta")
+
+    def same(real, fake):
+        real = real if isinstance(real, (tuple, list)) else (real,)
+        fake = fake if isinstance(fake, (tuple, list)) else (fake,)
+        assert len(real) == len(fake)
+        for r, f in zip(real, fake):
+            assert tuple(r.shape) == tuple(f.shape) and r.dtype == f.dtype, (r.shape, f.shape, r.dtype, f.dtype)
+
+    rgb, nrm, dep, d = _inputs(ctx)
+    view = ops.build_view(rgb, nrm, dep, 0)
+    same(view, ops.build_view(meta(rgb), meta(nrm), meta(dep), 0))
+    n = view.shape[0]
+    x = torch.zeros(n, 16, 160, 640, device=dev)
+    x[:, :8] = view
+    same(ops.scnet_forward(x, net.handle), ops.scnet_forward(meta(x), net.handle))
+    same(ops.pano2pc(dep, 0), ops.pano2pc(meta(dep), 0))
+    same(ops.apply_mask(view[:, :7].contiguous(), 0), ops.apply_mask(meta(view[:, :7]), 0))
+    pose = torch.eye(4, dtype=torch.float64, device=dev)[None].repeat(n, 1, 1)
+    same(ops.pose_inverse(pose), ops.pose_inverse(meta(pose)))
+    same(ops.warp(view, pose, 0), ops.warp(meta(view), meta(pose), 0))
+    cases = [synth.make_match_case(n, 300 + n)[:2] for n in (60, 90)]
+    from relativepose_amd import rpmodule
+    kp = rpmodule.pack_keypoints(cases, dev)
+    para = rpmodule.opts(0.3, 0.25, 0.04, 0.009)
+    mk = tuple(meta(t) for t in kp)
+    same(ops.match_pairs(*kp, O.params_list(para), para.topK, 0, 0), ops.match_pairs(*mk, O.params_list(para), para.topK, 0, 0))
+    for want in (True, False):
+        same(ops.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], O.params_list(para), para.topK, want),
+             ops.affinity_topk(mk[2], mk[3], mk[6], mk[7], mk[8], mk[9], O.params_list(para), para.topK, want))
+
+
 def test_rputil_shims_equal_reference_goldens(ctx, golden_dir):
     """rputil.getPixel / rputil.interpolate with the reference's signatures reproduce the reference's own outputs."""
     torch = ctx.torch

@@ -81,6 +81,36 @@ def test_torch_ops_registered_and_cuda_only():
     assert ops.params_list(rpmodule.opts())[6] == 0.01 and len(ops.PARAM_ORDER) == 8
 
 
+def test_torch_ops_have_meta_kernels():
+    """Shape functions for every operator (Meta dispatch key): graphs with torch.ops.relpose.* can be traced without a GPU."""
+    import torch
+    from relativepose_amd import ops  # noqa: F401
+    m = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device="meta")
+    R = torch.ops.relpose
+    f64, i32 = torch.float64, torch.int32
+    assert R.pose_inverse(m(3, 4, 4, dt=f64)).shape == (3, 4, 4)
+    pc, valid = R.pano2pc(m(2, 160, 640), 0)
+    assert pc.shape == (2, 3, 102400) and pc.dtype == f64 and valid.shape == (2, 102400) and valid.dtype == torch.uint8
+    assert R.build_view(m(2, 3, 160, 640), m(2, 3, 160, 640), m(2, 160, 640), 0).shape == (2, 8, 160, 640)
+    x, mask = R.apply_mask(m(2, 7, 160, 640), 0)
+    assert x.shape == (2, 7, 160, 640) and mask.shape == (2, 1, 160, 640)
+    assert R.warp(m(2, 8, 160, 640), m(2, 4, 4, dt=f64), 0).shape == (2, 8, 160, 640)
+    x16 = m(2, 16, 160, 640)
+    assert R.warp_pairs_(x16, m(2, 4, 4, dt=f64), 0) is x16
+    pc, nn, ft = R.sample_primitives(m(2, 54, 160, 640), 22, m(2, 3, 160, 640), m(2, 160, 640), m(2, 80, 2, dt=f64), m(2, dt=i32), 0, 0, 0)
+    assert pc.shape == nn.shape == (2, 80, 3) and pc.dtype == f64 and ft.shape == (2, 80, 32) and ft.dtype == torch.float32
+    kp = (m(4, 80, 3, dt=f64), m(4, 80, 3, dt=f64), m(4, 80, 32), m(4, 80, dt=f64), m(4, 90, 3, dt=f64), m(4, 90, 3, dt=f64), m(4, 90, 32),
+          m(4, 90, dt=f64), m(4, dt=i32), m(4, dt=i32))
+    pose, status = R.match_pairs(*kp, [0.] * 8, 5, 0, 100000)
+    assert pose.shape == (4, 4, 4) and pose.dtype == f64 and status.shape == (4,) and status.dtype == i32
+    wij, cj, cw, keff = R.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], [0.] * 8, 5, True)
+    assert wij.shape == (4, 80, 90) and cj.shape == cw.shape == (4, 80, 5) and cj.dtype == i32 and cw.dtype == f64 and keff.shape == (4,)
+    assert R.affinity_topk(kp[2], kp[3], kp[6], kp[7], kp[8], kp[9], [0.] * 8, 5, False)[0].numel() == 0
+    pts, w, npts = R.keypoints_reference(m(4, 54, 160, 640), 22, m(100, dt=i32), m(100, 2), m(100, dt=i32), m(5, dt=i32), 60, 5, 9,
+                                         m(4, 200, dt=i32), m(4, 200, 2, dt=f64), 0)
+    assert pts.shape == (4, 200, 2) and w.shape == (4, 200) and npts.shape == (4,)
+
+
 def test_wc_fixture_generator_is_deterministic_and_geometric():
     from cases import WC_CASES, WC_KW
     d, pts, ptw, T = synth.make_wc_pair(WC_CASES[0], **WC_KW)
