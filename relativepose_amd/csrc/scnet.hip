@@ -2694,7 +2694,10 @@ void Builder::end_group() {
     static const long wt_env = RP_ENV("RELPOSE_WANT_TILES") ? atol(RP_ENV("RELPOSE_WANT_TILES")) : 0;
     static const long wt64_env = RP_ENV("RELPOSE_WANT_TILES64") ? atol(RP_ENV("RELPOSE_WANT_TILES64")) : 0;
     static const int ms_env = RP_ENV("RELPOSE_MIN_SLICE") ? atoi(RP_ENV("RELPOSE_MIN_SLICE")) : 0;
-    const long want_tiles = cfg == 7 ? (wt64_env > 0 ? wt64_env : 2048) : (wt_env > 0 ? wt_env : 3000);
+    // (the three-piece bf16 kernels finish a tile in about 3/4 of the fp32 kernels' time, and the split-K reduction they then wait for is the same: half the
+    // split pays in the loop -- configs[1], same box, 2 x 40 steps: 3000 tiles 785.3 pairs/s, 2000: 785.2, 1500: 790.5, 1000: 789.6, 700: 789.0; the 64 x 64
+    // bottleneck tiles stay at 2048: 1024 / 512 / 256 / 64 give 785.9 / 784.5 / 778.1 / 741.3 against 785.5)
+    const long want_tiles = cfg == 7 ? (wt64_env > 0 ? wt64_env : 2048) : (wt_env > 0 ? wt_env : (net->prec >= RELPOSE_PREC_BF16X9 ? 1500 : 3000));
     const int min_slice = ms_env > 0 ? ms_env : 8;
     while (!dtile && s2_cfg < 0 && tiles * ksplit < want_tiles && ksplit < 64 && min_kt / (ksplit * 2) >= min_slice) ksplit *= 2;
     if (force_ksplit && !dtile && s2_cfg < 0) ksplit = force_ksplit;
